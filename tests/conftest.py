@@ -1,0 +1,31 @@
+"""pytest configuration: registers the `gpu` marker and makes the repo root, the package directory
+(`eddie-wang-hackathon2023_amd/`, a script directory laid out like the reference's
+examples/whisper/) and the oracle importable."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "eddie-wang-hackathon2023_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
