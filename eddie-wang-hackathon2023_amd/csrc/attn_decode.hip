@@ -1,0 +1,395 @@
+// Decode-time attention for the Whisper decoder: self-attention over the (int8 or fp16) KV cache
+// with in-place append, and cross-attention over the per-utterance fp16 cross K/V.
+//
+// Arithmetic contract (what the oracle restates):
+//   q, k are multiplied by d^-0.25 and rounded to fp16 (W/torch_model.py:93-95), scores are
+//   fp32 dot products rounded to fp16, softmax runs in fp32 over the whole key range
+//   (torch_model.py:100-101; attention.py:385-398), probabilities are rounded to fp16, P.V
+//   accumulates in fp32 and is rounded to fp16.
+//   int8 KV: present = sat_s8(rne(x * (1/t))), past is used as fp16(q8) * t, the tokens of the
+//   current call are used un-quantised (attention.py:281-348; same contract as the MMHA kernel,
+//   decoderMaskedMultiheadAttentionTemplate.h:1501-1517, Utils.h:2276-2286,2357-2390).
+//
+// Design reference for the single-token kernel: MaskedMultiheadAttention
+// (R/cpp/tensorrt_llm/kernels/decoderMaskedMultiheadAttention/...Template.h:1195-2188): one
+// block per (head, sequence), q.K over the cache, block softmax, V accumulation.  Here:
+//
+// * self-attention: one wave per (b, h).  <= 448 keys: lane-per-key dot products (a key row is
+//   64 B int8 / 128 B fp16, neighbouring lanes read neighbouring rows), wave-shuffle softmax,
+//   lane-per-dim V accumulation.  The cache append happens in the same kernel.
+// * cross-attention: the dominant HBM stream of a batched decode step (2 * H * 1500 * 64 * 2 B
+//   = 7.68 MB per utterance per layer at large-v2).  One workgroup of 256 threads per
+//   (b, h, key-split).  K and V are streamed with wave-wide 16-byte loads: one load instruction
+//   covers 8 whole rows (1 KiB contiguous), 8 lanes share a row and combine their partial dot
+//   products with three DPP-style shuffles.  Scores for the whole key range live in LDS, so the
+//   softmax is the exact two-pass one (no online rescaling), then V is streamed the same way.
+#include "common.h"
+#include "kernels.h"
+
+namespace wm {
+
+constexpr float ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25
+constexpr int MAX_L = 4;                              // query tokens per call handled per pass
+
+// ------------------------------------------------------------------------------------------------
+// self-attention
+// ------------------------------------------------------------------------------------------------
+template <bool I8>
+__global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
+    constexpr int MAXT = 512;
+    __shared__ float s_p[MAXT];
+    __shared__ h16 s_q[64], s_knew[MAX_L][64], s_vnew[MAX_L][64];
+
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int C = p.H * 64;
+    const float t_dq = p.kv_scale;
+    const float inv_t = 1.0f / p.kv_scale;
+    const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.B * p.L * p.ldp;
+
+    // ---- this call's q, k, v for the head: sum the split-K slabs, add bias, round to fp16 --------
+    // lane = head dim
+    for (int i = 0; i < p.L; ++i) {
+        const int m = b * p.L + i;
+        float q = 0.f, k = 0.f, v = 0.f;
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float* row = p.part + (size_t)s * sstride + (size_t)m * p.ldp + h * 64 + lane;
+            q += row[0]; k += row[C]; v += row[2 * C];
+        }
+        q = r16(q + (p.bias ? (float)p.bias[h * 64 + lane] : 0.f));
+        k = r16(k + (p.bias ? (float)p.bias[C + h * 64 + lane] : 0.f));
+        v = r16(v + (p.bias ? (float)p.bias[2 * C + h * 64 + lane] : 0.f));
+        if (p.amax) {     // calibration hook: max |q|,|k|,|v| of this layer (smoothquant.py:117-175, F8)
+            const float a = wave_max(fmaxf(fabsf(q), fmaxf(fabsf(k), fabsf(v))));
+            if (lane == 0) atomicMax((unsigned int*)p.amax, __float_as_uint(a));   // a >= 0: bit order = value order
+        }
+        s_knew[i][lane] = (h16)k;
+        s_vnew[i][lane] = (h16)v;
+        // append to the cache (present), position T + i
+        const size_t off_k = (size_t)b * p.present_bstride + ((size_t)(0 * p.H + h) * p.present_cap + p.T + i) * 64 + lane;
+        const size_t off_v = (size_t)b * p.present_bstride + ((size_t)(1 * p.H + h) * p.present_cap + p.T + i) * 64 + lane;
+        if (I8) {
+            ((int8_t*)p.present)[off_k] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(k * inv_t)));
+            ((int8_t*)p.present)[off_v] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(v * inv_t)));
+        } else {
+            ((h16*)p.present)[off_k] = (h16)k;
+            ((h16*)p.present)[off_v] = (h16)v;
+        }
+        // stash q rows in registers via LDS later; keep q of token i in s_q when processed
+        if (i == 0) s_q[lane] = (h16)r16(q * ATTN_SCALE);
+        // queries beyond the first are recomputed below (L is tiny: 1 or 3)
+    }
+    // copy-forward: when present is a different buffer than past (the reference's concat
+    // semantics, attention.py:296-306), move the T cached rows of this head
+    const bool inplace = (p.past == p.present) && (p.past_cap == p.present_cap) && (p.past_bstride == p.present_bstride);
+    if (!inplace && p.T > 0) {
+        const int es = I8 ? 1 : 2;
+        for (int kv = 0; kv < 2; ++kv) {
+            const unsigned char* src = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(kv * p.H + h) * p.past_cap * 64) * es;
+            unsigned char* dst = (unsigned char*)p.present + ((size_t)b * p.present_bstride + (size_t)(kv * p.H + h) * p.present_cap * 64) * es;
+            const int n16 = p.T * 64 * es / 16;
+            for (int c = lane; c < n16; c += 64) ((uint4*)dst)[c] = ((const uint4*)src)[c];
+        }
+    }
+    __syncthreads();
+
+    const unsigned char* pastK = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(0 * p.H + h) * p.past_cap * 64) * (I8 ? 1 : 2);
+    const unsigned char* pastV = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(1 * p.H + h) * p.past_cap * 64) * (I8 ? 1 : 2);
+
+    for (int i = 0; i < p.L; ++i) {
+        if (i > 0) {    // recompute q of token i (cheap) into s_q
+            const int m = b * p.L + i;
+            float q = 0.f;
+            for (int s = 0; s < p.ksplit; ++s) q += p.part[(size_t)s * sstride + (size_t)m * p.ldp + h * 64 + lane];
+            q = r16(q + (p.bias ? (float)p.bias[h * 64 + lane] : 0.f));
+            __syncthreads();
+            s_q[lane] = (h16)r16(q * ATTN_SCALE);
+            __syncthreads();
+        }
+        const int nk = p.T + i + 1;                 // causal: past + new tokens 0..i
+        // ---- scores: lane-per-key -------------------------------------------------------------
+        float mx = -INFINITY;
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+            const int j = j0 + lane;
+            float sc = -INFINITY;
+            if (j < nk) {
+                float acc = 0.f;
+                if (j < p.T) {
+                    if (I8) {
+                        const uint4* kr = (const uint4*)(pastK + (size_t)j * 64);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint4 w = kr[c];
+                            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int8_t q8 = (int8_t)((ws[e >> 2] >> (8 * (e & 3))) & 0xff);
+                                const float kd = r16(r16((float)q8 * t_dq) * ATTN_SCALE);
+                                acc += (float)s_q[c * 16 + e] * kd;
+                            }
+                        }
+                    } else {
+                        const half8v* kr = (const half8v*)(pastK + (size_t)j * 128);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const half8v w = kr[c];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                acc += (float)s_q[c * 8 + e] * r16((float)w[e] * ATTN_SCALE);
+                        }
+                    }
+                } else {
+                    const h16* kn = s_knew[j - p.T];
+#pragma unroll 8
+                    for (int e = 0; e < 64; ++e) acc += (float)s_q[e] * r16((float)kn[e] * ATTN_SCALE);
+                }
+                sc = r16(acc);
+            }
+            if (j < MAXT) s_p[j] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        __syncthreads();
+        for (int j = lane; j < nk; j += 64) {
+            const float e = __expf(s_p[j] - mx);
+            s_p[j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        __syncthreads();
+        for (int j = lane; j < nk; j += 64) s_p[j] = r16(s_p[j] * inv);
+        __syncthreads();
+        // ---- P.V: lane-per-dim ----------------------------------------------------------------
+        float o = 0.f;
+        int j = 0;
+        if (I8) {
+            for (; j < p.T; ++j) o += s_p[j] * r16((float)((const int8_t*)pastV)[(size_t)j * 64 + lane] * t_dq);
+        } else {
+            for (; j < p.T; ++j) o += s_p[j] * (float)((const h16*)pastV)[(size_t)j * 64 + lane];
+        }
+        for (; j < nk; ++j) o += s_p[j] * (float)s_vnew[j - p.T][lane];
+        p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)o;
+        __syncthreads();
+    }
+}
+
+int launch_attn_self(const AttnSelfParams& p, hipStream_t stream) {
+    WM_REQUIRE(p.L >= 1 && p.L <= MAX_L, "attn_self: L=%d out of range [1,%d]", p.L, MAX_L);
+    WM_REQUIRE(p.T + p.L <= 512, "attn_self: T+L=%d exceeds 512", p.T + p.L);
+    WM_REQUIRE(p.T + p.L <= p.present_cap, "attn_self: present capacity %d < T+L=%d", p.present_cap, p.T + p.L);
+    WM_REQUIRE(!p.int8_kv || p.kv_scale > 0.f, "attn_self: int8 KV needs a positive scale");
+    if (p.int8_kv)
+        hipLaunchKernelGGL(attn_self_kernel<true>, dim3(p.H, p.B), dim3(64), 0, stream, p);
+    else
+        hipLaunchKernelGGL(attn_self_kernel<false>, dim3(p.H, p.B), dim3(64), 0, stream, p);
+    WM_LAUNCH_CHECK(stream, "attn_self");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-attention
+// ------------------------------------------------------------------------------------------------
+// 256 threads = 4 waves; wave w, pass c covers keys [c*32*4 + w*32 ... ) in groups of 8 rows per
+// load instruction (lane -> row lane>>3, 16-byte column lane&7), 4 instructions in flight.
+constexpr int CROSS_MAX_KEYS = 1536;
+
+template <int L>
+__global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
+    __shared__ float s_sc[L][CROSS_MAX_KEYS];
+    __shared__ float s_red[L][4][2];
+    __shared__ float s_o[4][L][64];
+
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int sub = lane & 7, rowi = lane >> 3;           // 16-byte column, row inside an 8-row group
+    const int per_split = (((p.Tk + p.nsplit - 1) / p.nsplit) + 7) & ~7;
+    const int k_begin = sp * per_split, k_end = min(p.Tk, k_begin + per_split);
+    const int nkeys = max(0, k_end - k_begin);
+    if (nkeys == 0) {          // empty split (only possible when nsplit > 1): neutral element
+        for (int idx = tid; idx < L * 66; idx += 256) {
+            float* w = p.ws + ((((size_t)b * p.H + h) * p.nsplit + sp) * L) * 66;
+            w[idx] = (idx % 66 == 0) ? -INFINITY : 0.f;
+        }
+        return;
+    }
+
+    const h16* K = p.kv + (size_t)b * p.kv_bstride + ((size_t)(0 * p.H + h) * p.Tk) * 64;
+    const h16* V = p.kv + (size_t)b * p.kv_bstride + ((size_t)(1 * p.H + h) * p.Tk) * 64;
+
+    const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.B * L * p.ldp;
+    // ---- q: this lane's 8 dims (sub*8 .. +8) for each of the L tokens ---------------------------
+    float qf[L][8];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int m = b * L + i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = h * 64 + sub * 8 + e;
+            float q = 0.f;
+            for (int s = 0; s < p.ksplit; ++s) q += p.part[(size_t)s * sstride + (size_t)m * p.ldp + col];
+            q = r16(q + (p.bias ? (float)p.bias[col] : 0.f));
+            qf[i][e] = r16(q * ATTN_SCALE);
+        }
+    }
+
+    // ---- pass 1: scores ---------------------------------------------------------------------------
+    // a wave handles 32 rows per iteration (4 loads of 8 rows), the 4 waves stride by 128 rows
+    float mx[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) mx[i] = -INFINITY;
+    for (int r0 = wid * 32; r0 < nkeys; r0 += 128) {
+        half8v kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * 8 + rowi;
+            const int rr = min(r, nkeys - 1);
+            kv[u] = __builtin_nontemporal_load((const half8v*)(K + (size_t)(k_begin + rr) * 64 + sub * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * 8 + rowi;
+            float ks[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ks[e] = r16((float)kv[u][e] * ATTN_SCALE);
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += qf[i][e] * ks[e];
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                acc += __shfl_xor(acc, 4);
+                const float sc = r16(acc);
+                if (r < nkeys) {
+                    if (sub == 0) s_sc[i][r] = sc;
+                    mx[i] = fmaxf(mx[i], sc);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const float m = wave_max(mx[i]);
+        if (lane == 0) s_red[i][wid][0] = m;
+    }
+    __syncthreads();
+    float gmax[L], gsum[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        gmax[i] = fmaxf(fmaxf(s_red[i][0][0], s_red[i][1][0]), fmaxf(s_red[i][2][0], s_red[i][3][0]));
+        float s = 0.f;
+        for (int j = tid; j < nkeys; j += 256) {
+            const float e = __expf(s_sc[i][j] - gmax[i]);
+            s_sc[i][j] = e;
+            s += e;
+        }
+        s = wave_sum(s);
+        if (lane == 0) s_red[i][wid][1] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < L; ++i) gsum[i] = s_red[i][0][1] + s_red[i][1][1] + s_red[i][2][1] + s_red[i][3][1];
+    const bool single = (p.nsplit == 1);
+    if (single) {       // exact two-pass softmax: normalise and round the probabilities to fp16
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const float inv = 1.0f / gsum[i];
+            for (int j = tid; j < nkeys; j += 256) s_sc[i][j] = r16(s_sc[i][j] * inv);
+        }
+        __syncthreads();
+    }
+
+    // ---- pass 2: P.V --------------------------------------------------------------------------------
+    float o[L][8];
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[i][e] = 0.f;
+    for (int r0 = wid * 32; r0 < nkeys; r0 += 128) {
+        half8v vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = min(r0 + u * 8 + rowi, nkeys - 1);
+            vv[u] = __builtin_nontemporal_load((const half8v*)(V + (size_t)(k_begin + r) * 64 + sub * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * 8 + rowi;
+            if (r < nkeys) {
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const float pr = s_sc[i][r];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[i][e] += pr * (float)vv[u][e];
+                }
+            }
+        }
+    }
+    // reduce over the 8 row-lanes sharing a column group (lane bits 3..5), then over the 4 waves
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = o[i][e];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            o[i][e] = v;
+        }
+    if (rowi == 0) {
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_o[wid][i][sub * 8 + e] = o[i][e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < L * 64; idx += 256) {
+        const int i = idx >> 6, d = idx & 63;
+        const float v = s_o[0][i][d] + s_o[1][i][d] + s_o[2][i][d] + s_o[3][i][d];
+        if (single) {
+            p.out[(size_t)(b * L + i) * p.ldo + h * 64 + d] = (h16)v;
+        } else {
+            float* w = p.ws + ((((size_t)b * p.H + h) * p.nsplit + sp) * L + i) * 66;
+            w[2 + d] = v;
+            if (d == 0) { w[0] = gmax[i]; w[1] = gsum[i]; }
+        }
+    }
+}
+
+// combine the key-range splits: softmax-weighted merge of (max, sum, unnormalised o)
+__global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams p) {
+    const int h = blockIdx.x, b = blockIdx.y, i = blockIdx.z, d = threadIdx.x;
+    const float* w = p.ws + ((((size_t)b * p.H + h) * p.nsplit) * p.L + i) * 66;
+    const size_t stride = (size_t)p.L * 66;
+    float m = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) m = fmaxf(m, w[s * stride]);
+    float den = 0.f, num = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const float f = __expf(w[s * stride] - m);
+        den += w[s * stride + 1] * f;
+        num += w[s * stride + 2 + d] * f;
+    }
+    p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + d] = (h16)(num / den);
+}
+
+int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream) {
+    WM_REQUIRE(p.L >= 1 && p.L <= MAX_L, "attn_cross: L=%d out of range [1,%d]", p.L, MAX_L);
+    WM_REQUIRE(p.Tk >= 1 && p.Tk <= CROSS_MAX_KEYS, "attn_cross: Tk=%d out of range", p.Tk);
+    WM_REQUIRE(p.nsplit >= 1 && (p.nsplit == 1 || p.ws != nullptr), "attn_cross: split needs a workspace");
+    dim3 grid(p.H, p.B, p.nsplit);
+    switch (p.L) {
+        case 1: hipLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL(attn_cross_kernel<2>, grid, dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(attn_cross_kernel<3>, grid, dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL(attn_cross_kernel<4>, grid, dim3(256), 0, stream, p); break;
+    }
+    WM_LAUNCH_CHECK(stream, "attn_cross");
+    if (p.nsplit > 1) {
+        hipLaunchKernelGGL(attn_cross_combine_kernel, dim3(p.H, p.B, p.L), dim3(64), 0, stream, p);
+        WM_LAUNCH_CHECK(stream, "attn_cross_combine");
+    }
+    return 0;
+}
+
+}  // namespace wm

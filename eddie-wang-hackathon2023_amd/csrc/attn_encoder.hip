@@ -1,0 +1,214 @@
+// Bidirectional self-attention of the Whisper audio encoder (T = 1500 frames, head size 64):
+// flash-style, never materialising the T x T score matrix.
+//
+// Replaces the unfused QK^T / softmax / PV TensorRT ops of Attention.forward
+// (R/tensorrt_llm/layers/attention.py:385-406) and W/torch_model.py:88-103.
+// Arithmetic contract: q, k arrive already multiplied by d^-0.25 and rounded to fp16 (done in the
+// QKV GEMM epilogue, exactly torch_model.py:93-95); scores = fp32 MFMA accumulation rounded to
+// fp16; softmax in fp32 (online form); probabilities rounded to fp16; P.V fp32, rounded to fp16.
+//
+// gfx950 design (wave64, MFMA 16x16x32 f16):
+//  * the kernel computes S^T = K . Q^T instead of Q . K^T.  In the MFMA C/D layout a lane then
+//    owns ONE query (column lane & 15) and holds 4 keys per 16-key block in its registers, so
+//      - the row softmax is in-register plus two cross-lane steps (xor 16, xor 32),
+//      - exp(S^T) converted to fp16 IS the B operand of the second product O^T = V^T . P^T
+//        (B[k = key][n = query], 8 keys per lane) -- no LDS round trip, no lane movement,
+//      - the O^T accumulators share the lane -> query map, so the online rescale is per lane.
+//  * V^T as the A operand comes from the row-major [key][dim] LDS tile through
+//    ds_read_b64_tr_b16 (hardware transposed read): lane i of a 16-lane group receives 4 keys of
+//    dim i.  The MFMA's k index is mapped to keys as k = 8g + j <-> key 16 (j >> 2) + 4g + (j & 3)
+//    inside each 32-key chunk, which is exactly how the S^T accumulators are laid out.
+//  * K/V tiles of 64 keys are register-staged one tile ahead into a double-buffered LDS image
+//    with 144-byte rows; one barrier per tile.  Each wave owns QB blocks of 16 queries and
+//    re-uses every K / V fragment for all of them.
+#include "common.h"
+#include "kernels.h"
+
+namespace wm {
+
+constexpr int KT_KEYS = 64;
+constexpr int AROW = 144;                      // LDS bytes per key row (64 halves + pad)
+constexpr int KV_TILE = KT_KEYS * AROW;        // 9216
+
+template <int QB>
+__global__ __launch_bounds__(256) void attn_encoder_kernel(AttnEncParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * KV_TILE];
+    auto sK = [&](int b) { return smem + b * 2 * KV_TILE; };
+    auto sV = [&](int b) { return smem + b * 2 * KV_TILE + KV_TILE; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int C = p.H * 64;
+    const int q_base = blockIdx.x * (64 * QB) + wid * (16 * QB);
+    const h16* base = p.qkv + (size_t)b * p.T * p.ld;
+
+    // ---- Q^T fragments: B operand, lane -> query li, dims 32s + 8g .. +8 --------------------------
+    half8v qf[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int qrow = q_base + qb * 16 + li;
+        if (qrow > p.T - 1) qrow = p.T - 1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            qf[qb][s] = *(const half8v*)(base + (size_t)qrow * p.ld + h * 64 + s * 32 + g * 8);
+    }
+
+    // ---- K/V staging: 512 16-byte chunks per tile each, 2 per thread ----------------------------
+    uint4 rk[2], rv[2];
+    int st_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+        st_off[i] = (c >> 3) * AROW + (c & 7) * 16;
+    }
+    auto load_kv = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i;
+            int key = tile * KT_KEYS + (c >> 3);
+            if (key > p.T - 1) key = p.T - 1;
+            const h16* row = base + (size_t)key * p.ld + h * 64 + (c & 7) * 8;
+            rk[i] = *(const uint4*)(row + C);
+            rv[i] = *(const uint4*)(row + 2 * C);
+        }
+    };
+    auto store_kv = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(uint4*)(sK(buf) + st_off[i]) = rk[i];
+            *(uint4*)(sV(buf) + st_off[i]) = rv[i];
+        }
+    };
+
+    float4v o[4][QB];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) o[db][qb] = float4v{0.f, 0.f, 0.f, 0.f};
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+
+    const int ntiles = (p.T + KT_KEYS - 1) / KT_KEYS;
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+
+    // LDS addresses: K A-operand (row = key li, dims 8g..): li*AROW + g*16 (+ kb*16*AROW + s*64)
+    const int k_off = li * AROW + g * 16;
+    // V transposed read: lane i of its 16-lane group supplies row (i >> 2), columns 4 * (i & 3) ..
+    const int v_off = (4 * g + (li >> 2)) * AROW + (li & 3) * 8;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) load_kv(t + 1);
+
+        // ---- S^T = K . Q^T : [64 keys] x [16 QB queries] ------------------------------------------
+        float4v sacc[4][QB];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const half8v k0 = *(const half8v*)(sK(cur) + k_off + kb * 16 * AROW);
+            const half8v k1 = *(const half8v*)(sK(cur) + k_off + kb * 16 * AROW + 64);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float4v a = float4v{0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[qb][0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[qb][1], a, 0, 0, 0);
+                sacc[kb][qb] = a;
+            }
+        }
+        // ---- mask the tail, round to fp16, online softmax (per lane = per query) ------------------
+        const int key0 = t * KT_KEYS + 4 * g;          // + 16 kb + r
+        const bool tail = (t == ntiles - 1) && (p.T % KT_KEYS != 0);
+        half8v pf[2][QB];                              // P^T fragments per 32-key chunk
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = r16(sacc[kb][qb][r]);
+                    if (tail && key0 + 16 * kb + r >= p.T) s = -INFINITY;
+                    sacc[kb][qb][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qb], mx);
+            const float alpha = __expf(m_run[qb] - m_new);
+            m_run[qb] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const h16 ph = (h16)__expf(sacc[kb][qb][r] - m_new);
+                    ps += (float)ph;
+                    pf[kb >> 1][qb][(kb & 1) * 4 + r] = ph;
+                }
+            ps += __shfl_xor(ps, 16);
+            ps += __shfl_xor(ps, 32);
+            l_run[qb] = l_run[qb] * alpha + ps;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
+        }
+        // ---- O^T += V^T . P^T ------------------------------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const unsigned char* va = sV(cur) + v_off + (c * 32) * AROW + db * 32;
+                const short4r lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4r*)(va));
+                const short4r hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4r*)(va + 16 * AROW));
+                half8v vf;
+                const half4v l4 = __builtin_bit_cast(half4v, lo), h4 = __builtin_bit_cast(half4v, hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vf[j] = l4[j]; vf[4 + j] = h4[j]; }
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c][qb], o[db][qb], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) store_kv(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane owns query li, dims 16 db + 4 g + r ------------------------------
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = q_base + qb * 16 + li;
+        if (qrow >= p.T) continue;
+        const float inv = 1.0f / l_run[qb];
+        h16* dst = p.out + ((size_t)b * p.T + qrow) * p.ldo + h * 64;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            half4v w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = (h16)(o[db][qb][r] * inv);
+            *(half4v*)(dst + db * 16 + g * 4) = w;
+        }
+    }
+}
+
+int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream) {
+    WM_REQUIRE(p.T >= 1 && p.H >= 1 && p.B >= 1, "attn_encoder: bad shape");
+    WM_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "attn_encoder: leading dimensions must keep 16-byte alignment");
+    // QB = 2: 128 queries per workgroup.  (QB = 4 halves LDS traffic per MFMA; chosen when the
+    // grid still fills the chip.)
+    const long wgs4 = (long)((p.T + 255) / 256) * p.H * p.B;
+    if (wgs4 >= 1024) {
+        dim3 grid((p.T + 255) / 256, p.H, p.B);
+        hipLaunchKernelGGL(attn_encoder_kernel<4>, grid, dim3(256), 0, stream, p);
+    } else {
+        dim3 grid((p.T + 127) / 128, p.H, p.B);
+        hipLaunchKernelGGL(attn_encoder_kernel<2>, grid, dim3(256), 0, stream, p);
+    }
+    WM_LAUNCH_CHECK(stream, "attn_encoder");
+    return 0;
+}
+
+}  // namespace wm

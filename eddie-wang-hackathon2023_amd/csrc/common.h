@@ -1,0 +1,77 @@
+// Shared device/host helpers for the gfx950 Whisper engine.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace wm {
+
+typedef _Float16 h16;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef short short4r __attribute__((__vector_size__(4 * sizeof(short))));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+// ---- status / last error (thread local) ------------------------------------------------
+void set_error(const char* fmt, ...);
+#define WM_CHECK_HIP(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            wm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                          __LINE__);                                                        \
+            return 2;                                                                       \
+        }                                                                                   \
+    } while (0)
+#define WM_REQUIRE(cond, ...)                                                               \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            wm::set_error(__VA_ARGS__);                                                     \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+// debug: WM_SYNC_CHECK=1 synchronises and checks after every launch (the reference's
+// sync_check_cuda_error, cudaUtils.h:103-134)
+int post_launch_check(hipStream_t s, const char* what);
+#define WM_LAUNCH_CHECK(stream, what)                                                       \
+    do {                                                                                    \
+        int _r = wm::post_launch_check(stream, what);                                       \
+        if (_r) return _r;                                                                  \
+    } while (0)
+
+// ---- device helpers ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float r16(float x) { return (float)(h16)x; }   // round through fp16
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_tanh(float x) {
+    return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+// 4 signed int8 packed in a dword -> 4 fp16 (exact).  s8 ^ 0x80 = u8 in [0,255];
+// 0x6400 | u8 is the fp16 number 1024 + u8; subtracting 1152 gives the signed value.
+__device__ __forceinline__ void cvt_s8x4_f16x4(uint32_t w, half2v& lo, half2v& hi) {
+    uint32_t u = w ^ 0x80808080u;
+    uint32_t a = __builtin_amdgcn_perm(0x64646464u, u, 0x07010700u);   // bytes: [64,u1,64,u0]
+    uint32_t b = __builtin_amdgcn_perm(0x64646464u, u, 0x07030702u);   // bytes: [64,u3,64,u2]
+    const half2v k = {(h16)1152.0f, (h16)1152.0f};
+    lo = __builtin_bit_cast(half2v, a) - k;
+    hi = __builtin_bit_cast(half2v, b) - k;
+}
+
+}  // namespace wm

@@ -1,0 +1,580 @@
+// Engine objects and the C ABI (include/whisper_mi355.h): blob parsing, weight residency and the
+// kernel sequences of the three engines of the reference's Whisper example:
+//   encoder        WhisperEncoder.forward   R/tensorrt_llm/models/whisper/model.py:149-172
+//   cross K/V      CrossAttn_KV.forward     model.py:469-540
+//   decoder step   WhisperDecoder.forward   model.py:241-299, block :61-122
+// Everything is enqueued on the caller's stream into caller-owned buffers; nothing allocates or
+// synchronises here (the contract of Session.run, session.py:148-178).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/whisper_mi355.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace wm {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int post_launch_check(hipStream_t s, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return 2; }
+    static int sync_check = -1;
+    if (sync_check < 0) { const char* v = getenv("WM_SYNC_CHECK"); sync_check = (v && v[0] == '1') ? 1 : 0; }
+    if (sync_check) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("kernel %s faulted: %s", what, hipGetErrorString(e)); return 2; }
+    }
+    return 0;
+}
+
+// ---- blob format (written by weight.py: write_engine_blob) ---------------------------------------
+#pragma pack(push, 1)
+struct BlobHeader {
+    char magic[8];            // "WM355ENG"
+    uint32_t version;         // 1
+    uint32_t kind;            // WM_ENGINE_*
+    uint32_t n_tensors;
+    uint32_t flags;           // WM_FLAG_*
+    int32_t dims[10];         // wm_dims order
+    uint64_t data_offset;     // from blob start, 256-byte aligned
+    uint64_t data_bytes;
+};
+struct BlobTensor {
+    char name[64];
+    uint32_t dtype;           // 0 f16, 1 i8, 2 f32, 3 i32
+    uint32_t ndim;
+    uint64_t shape[4];
+    uint64_t offset;          // from data_offset, 256-byte aligned
+    uint64_t nbytes;
+};
+#pragma pack(pop)
+
+struct Tensor { const unsigned char* ptr = nullptr; uint32_t dtype = 0; uint64_t shape[4] = {0, 0, 0, 0}; uint64_t nbytes = 0; };
+
+struct Lin {                  // one Linear: weight (row-major or tile-linear), optional scale, bias
+    const void* w = nullptr; const h16* s = nullptr; const h16* b = nullptr;
+    int N = 0, K = 0, n_blocks = 0;
+};
+struct EncLayer { const h16 *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, out, mlp1, mlp2; };
+struct DecLayer {
+    const h16 *ln1g, *ln1b, *lncg, *lncb, *ln2g, *ln2b;
+    Lin qkv, out, cq, cout, mlp1, mlp2;
+    float kv_scale = 1.f;
+};
+
+}  // namespace wm
+
+using namespace wm;
+
+struct wm_engine {
+    int kind = 0; uint32_t flags = 0; wm_dims dims{}; int device = 0;
+    unsigned char* dev = nullptr; size_t dev_bytes = 0;
+    std::map<std::string, Tensor> t;
+    std::map<std::string, float> scalars;      // host copies of 4-byte fp32 tensors (kv scales)
+    // encoder
+    Lin conv1, conv2; const h16* enc_pos = nullptr; const h16 *lnpg = nullptr, *lnpb = nullptr;
+    std::vector<EncLayer> enc;
+    // cross
+    std::vector<Lin> ckv;
+    // decoder
+    const void* emb_t = nullptr; int emb_blocks = 0; const h16 *lnfg = nullptr, *lnfb = nullptr;
+    std::vector<DecLayer> dec;
+    bool w8() const { return flags & WM_FLAG_WEIGHT_ONLY_INT8; }
+    bool i8kv() const { return flags & WM_FLAG_INT8_KV; }
+    int gelu() const { return (flags & WM_FLAG_GELU_TANH) ? 2 : 1; }
+};
+
+namespace {
+
+int find(const wm_engine* e, const std::string& name, Tensor* out, bool required = true) {
+    auto it = e->t.find(name);
+    if (it == e->t.end()) {
+        if (required) { set_error("engine blob has no tensor '%s'", name.c_str()); return 1; }
+        *out = Tensor{};
+        return 0;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// weight `base`.w (+ .s when weight-only) + optional `base`.b
+int get_lin(const wm_engine* e, const std::string& base, bool tiled, bool quantisable, bool need_bias, Lin* l) {
+    Tensor w, s, b;
+    if (find(e, base + (tiled ? ".t" : ".w"), &w)) return 1;
+    l->w = w.ptr;
+    const bool q = quantisable && e->w8();
+    if ((w.dtype == 1) != q) { set_error("tensor %s: dtype does not match the engine's weight-only flag", base.c_str()); return 1; }
+    if (tiled) {           // shape = [n_blocks, k_tiles, 64, 16 bytes]
+        l->n_blocks = (int)w.shape[0];
+        l->N = l->n_blocks * 16;
+        l->K = (int)w.shape[1] * (q ? 64 : 32);
+    } else {
+        l->N = (int)w.shape[0]; l->K = (int)w.shape[1];
+    }
+    if (q) { if (find(e, base + ".s", &s)) return 1; l->s = (const h16*)s.ptr; }
+    if (find(e, base + ".b", &b, need_bias)) return 1;
+    l->b = (const h16*)b.ptr;
+    return 0;
+}
+
+int get_vec(const wm_engine* e, const std::string& name, const h16** out) {
+    Tensor t;
+    if (find(e, name, &t)) return 1;
+    *out = (const h16*)t.ptr;
+    return 0;
+}
+
+int resolve(wm_engine* e) {
+    const wm_dims& d = e->dims;
+    char buf[96];
+    if (e->kind == WM_ENGINE_ENCODER) {
+        if (get_lin(e, "conv1", false, false, true, &e->conv1)) return 1;
+        if (get_lin(e, "conv2", false, false, true, &e->conv2)) return 1;
+        if (get_vec(e, "pos", &e->enc_pos)) return 1;
+        if (get_vec(e, "ln_post.g", &e->lnpg) || get_vec(e, "ln_post.b", &e->lnpb)) return 1;
+        e->enc.resize(d.n_audio_layer);
+        for (int i = 0; i < d.n_audio_layer; ++i) {
+            EncLayer& L = e->enc[i];
+            snprintf(buf, sizeof(buf), "blocks.%d.", i);
+            const std::string p(buf);
+            if (get_vec(e, p + "attn_ln.g", &L.ln1g) || get_vec(e, p + "attn_ln.b", &L.ln1b) ||
+                get_vec(e, p + "mlp_ln.g", &L.ln2g) || get_vec(e, p + "mlp_ln.b", &L.ln2b)) return 1;
+            if (get_lin(e, p + "qkv", false, true, true, &L.qkv) || get_lin(e, p + "out", false, true, true, &L.out) ||
+                get_lin(e, p + "mlp1", false, true, true, &L.mlp1) || get_lin(e, p + "mlp2", false, true, true, &L.mlp2)) return 1;
+        }
+    } else if (e->kind == WM_ENGINE_CROSS_KV) {
+        e->ckv.resize(d.n_text_layer);
+        for (int i = 0; i < d.n_text_layer; ++i) {
+            snprintf(buf, sizeof(buf), "blocks.%d.kv", i);
+            if (get_lin(e, buf, false, true, true, &e->ckv[i])) return 1;
+        }
+    } else if (e->kind == WM_ENGINE_DECODER) {
+        Tensor emb;
+        if (find(e, "emb.t", &emb)) return 1;
+        e->emb_t = emb.ptr; e->emb_blocks = (int)emb.shape[0];
+        if (get_vec(e, "ln.g", &e->lnfg) || get_vec(e, "ln.b", &e->lnfb)) return 1;
+        e->dec.resize(d.n_text_layer);
+        for (int i = 0; i < d.n_text_layer; ++i) {
+            DecLayer& L = e->dec[i];
+            snprintf(buf, sizeof(buf), "blocks.%d.", i);
+            const std::string p(buf);
+            if (get_vec(e, p + "attn_ln.g", &L.ln1g) || get_vec(e, p + "attn_ln.b", &L.ln1b) ||
+                get_vec(e, p + "cross_ln.g", &L.lncg) || get_vec(e, p + "cross_ln.b", &L.lncb) ||
+                get_vec(e, p + "mlp_ln.g", &L.ln2g) || get_vec(e, p + "mlp_ln.b", &L.ln2b)) return 1;
+            if (get_lin(e, p + "qkv", true, true, true, &L.qkv) || get_lin(e, p + "out", true, true, true, &L.out) ||
+                get_lin(e, p + "cq", true, true, true, &L.cq) || get_lin(e, p + "cout", true, true, true, &L.cout) ||
+                get_lin(e, p + "mlp1", true, true, true, &L.mlp1) || get_lin(e, p + "mlp2", true, true, true, &L.mlp2)) return 1;
+            if (e->i8kv()) {
+                auto it = e->scalars.find(p + "kv_scale");
+                if (it == e->scalars.end()) { set_error("int8-KV engine lacks %skv_scale", p.c_str()); return 1; }
+                L.kv_scale = it->second;
+                if (!(L.kv_scale > 0.f)) { set_error("%skv_scale must be positive", p.c_str()); return 1; }
+            }
+        }
+    } else {
+        set_error("unknown engine kind %d", e->kind);
+        return 1;
+    }
+    return 0;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Carver {            // bump allocator over the caller's workspace
+    unsigned char* base; size_t cap; size_t off = 0;
+    template <typename T> T* take(size_t n) {
+        off = align_up(off);
+        T* p = (T*)(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+// ---- encoder -------------------------------------------------------------------------------------
+struct EncWs { h16 *melT, *c1, *x, *xn, *qkv, *ctx, *hid; size_t total; };
+EncWs carve_encoder(const wm_engine* e, int B, void* ws) {
+    const wm_dims& d = e->dims;
+    const size_t T = d.n_audio_ctx, Tin = 2 * T, C = d.n_audio_state;
+    Carver c{(unsigned char*)ws, 0};
+    EncWs w;
+    w.melT = c.take<h16>(B * (Tin + 2) * d.n_mels + 512);
+    w.c1 = c.take<h16>(B * (Tin + 2) * C + 512);
+    w.x = c.take<h16>(B * T * C);
+    w.xn = c.take<h16>(B * T * C);
+    w.qkv = c.take<h16>(B * T * 3 * C);
+    w.ctx = c.take<h16>(B * T * C);
+    w.hid = c.take<h16>(B * T * 4 * C);
+    w.total = align_up(c.off);
+    return w;
+}
+
+int big(const Lin& l, const wm_engine* e, const h16* A, int lda, int M, h16* Cout, int ldc, int act,
+        const h16* residual, int ldr, hipStream_t s, GemmBigParams* custom = nullptr) {
+    GemmBigParams p{};
+    if (custom) p = *custom;
+    p.A = A; p.lda = lda; p.M = M; p.K = l.K; p.W = l.w; p.N = l.N; p.w8 = l.s != nullptr;
+    p.scale = l.s; p.bias = l.b; p.C = Cout; p.ldc = ldc; p.act = act;
+    if (!custom) { p.residual = residual; p.ldr = ldr; }
+    return launch_gemm_big(p, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int wm_version(void) { return 1; }
+const char* wm_last_error(void) { return g_err; }
+int wm_device_count(int* out) {
+    WM_CHECK_HIP(hipGetDeviceCount(out));
+    return 0;
+}
+
+int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** out) {
+    WM_REQUIRE(blob && out, "wm_engine_create: null argument");
+    WM_REQUIRE(nbytes >= sizeof(BlobHeader), "engine blob too small (%zu bytes)", nbytes);
+    const BlobHeader* h = (const BlobHeader*)blob;
+    WM_REQUIRE(memcmp(h->magic, "WM355ENG", 8) == 0, "not a whisper_mi355 engine blob (bad magic)");
+    WM_REQUIRE(h->version == 1, "unsupported engine blob version %u", h->version);
+    WM_REQUIRE(sizeof(BlobHeader) + (size_t)h->n_tensors * sizeof(BlobTensor) <= h->data_offset &&
+                   h->data_offset + h->data_bytes <= nbytes, "engine blob is truncated");
+    wm_engine* e = new wm_engine();
+    e->kind = (int)h->kind; e->flags = h->flags; e->device = device;
+    memcpy(&e->dims, h->dims, sizeof(wm_dims));
+    hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess) err = hipMalloc((void**)&e->dev, h->data_bytes ? h->data_bytes : 256);
+    if (err == hipSuccess) err = hipMemcpy(e->dev, (const unsigned char*)blob + h->data_offset, h->data_bytes, hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        set_error("wm_engine_create: device %d: %s", device, hipGetErrorString(err));
+        if (e->dev) (void)hipFree(e->dev);
+        delete e;
+        return 2;
+    }
+    e->dev_bytes = h->data_bytes;
+    const BlobTensor* tt = (const BlobTensor*)((const unsigned char*)blob + sizeof(BlobHeader));
+    for (uint32_t i = 0; i < h->n_tensors; ++i) {
+        Tensor t;
+        if (tt[i].offset + tt[i].nbytes > h->data_bytes) {
+            set_error("tensor %.64s exceeds the blob", tt[i].name);
+            (void)hipFree(e->dev); delete e; return 1;
+        }
+        t.ptr = e->dev + tt[i].offset; t.dtype = tt[i].dtype; t.nbytes = tt[i].nbytes;
+        memcpy(t.shape, tt[i].shape, sizeof(t.shape));
+        char nm[65]; memcpy(nm, tt[i].name, 64); nm[64] = 0;
+        e->t[nm] = t;
+        if (t.dtype == 2 && t.nbytes == 4) {
+            float v;
+            memcpy(&v, (const unsigned char*)blob + h->data_offset + tt[i].offset, 4);
+            e->scalars[nm] = v;
+        }
+    }
+    if (resolve(e)) { (void)hipFree(e->dev); delete e; return 1; }
+    *out = e;
+    return 0;
+}
+
+void wm_engine_destroy(wm_engine* e) {
+    if (!e) return;
+    if (e->dev) { (void)hipSetDevice(e->device); (void)hipFree(e->dev); }
+    delete e;
+}
+
+int wm_engine_info(const wm_engine* e, int32_t* kind, uint32_t* flags, wm_dims* dims) {
+    WM_REQUIRE(e, "wm_engine_info: null engine");
+    if (kind) *kind = e->kind;
+    if (flags) *flags = e->flags;
+    if (dims) *dims = e->dims;
+    return 0;
+}
+size_t wm_engine_weight_bytes(const wm_engine* e) { return e ? e->dev_bytes : 0; }
+
+// ================================================================================================ encoder
+size_t wm_encoder_workspace_bytes(const wm_engine* e, int batch) {
+    if (!e || e->kind != WM_ENGINE_ENCODER || batch < 1) return 0;
+    return carve_encoder(e, batch, nullptr).total;
+}
+
+int wm_encoder_forward(const wm_engine* e, const void* mel, int B, void* out, void* workspace,
+                       size_t workspace_bytes, wm_stream_t stream_) {
+    WM_REQUIRE(e && e->kind == WM_ENGINE_ENCODER, "wm_encoder_forward: not an encoder engine");
+    WM_REQUIRE(mel && out && workspace && B >= 1, "wm_encoder_forward: null argument or empty batch");
+    hipStream_t s = (hipStream_t)stream_;
+    const wm_dims& d = e->dims;
+    const int T = d.n_audio_ctx, Tin = 2 * T, C = d.n_audio_state, H = d.n_audio_head, M = B * T;
+    WM_REQUIRE(C == H * 64, "head size must be 64 (n_state %d, heads %d)", C, H);
+    EncWs w = carve_encoder(e, B, workspace);
+    WM_REQUIRE(workspace_bytes >= w.total, "encoder workspace too small: %zu < %zu", workspace_bytes, w.total);
+
+    // mel -> token-major, zero padded; slack after the last row is read by the K=256 view (x 0 weights)
+    WM_CHECK_HIP(hipMemsetAsync(w.melT + (size_t)B * (Tin + 2) * d.n_mels, 0, 512 * sizeof(h16), s));
+    if (launch_mel_transpose_pad((const h16*)mel, B, d.n_mels, Tin, w.melT, s)) return 2;
+    // conv1 (k3 s1 p1) + GELU as a GEMM over a strided view: row t = padded rows t, t+1, t+2
+    {
+        GemmBigParams p{};
+        p.a_rows = Tin; p.a_bstride = (long)(Tin + 2) * d.n_mels;
+        p.c_rows = Tin; p.c_bstride = (long)(Tin + 2) * C;
+        WM_REQUIRE(e->conv1.K >= 3 * d.n_mels, "conv1 weight K=%d < 3*n_mels", e->conv1.K);
+        if (big(e->conv1, e, w.melT, d.n_mels, B * Tin, w.c1 + C, C, e->gelu(), nullptr, 0, s, &p)) return 2;
+        if (launch_zero_pad_rows(w.c1, B, Tin + 2, C, s)) return 2;
+    }
+    // conv2 (k3 s2 p1) + GELU + positional embedding: row t = padded rows 2t, 2t+1, 2t+2
+    {
+        GemmBigParams p{};
+        p.a_rows = T; p.a_bstride = (long)(Tin + 2) * C;
+        p.residual = e->enc_pos; p.ldr = C; p.res_mod = T;
+        if (big(e->conv2, e, w.c1, 2 * C, M, w.x, C, e->gelu(), nullptr, 0, s, &p)) return 2;
+    }
+    const float qk_scale = 0.35355339059327373f;    // 64^-0.25
+    for (int i = 0; i < d.n_audio_layer; ++i) {
+        const EncLayer& L = e->enc[i];
+        if (launch_layernorm(w.x, C, M, C, L.ln1g, L.ln1b, w.xn, C, s)) return 2;
+        {
+            GemmBigParams p{};
+            p.colscale_n = 2 * C; p.colscale = qk_scale;
+            if (big(L.qkv, e, w.xn, C, M, w.qkv, 3 * C, 0, nullptr, 0, s, &p)) return 2;
+        }
+        AttnEncParams ap{w.qkv, 3 * C, B, T, H, w.ctx, C};
+        if (launch_attn_encoder(ap, s)) return 2;
+        if (big(L.out, e, w.ctx, C, M, w.x, C, 0, w.x, C, s)) return 2;
+        if (launch_layernorm(w.x, C, M, C, L.ln2g, L.ln2b, w.xn, C, s)) return 2;
+        if (big(L.mlp1, e, w.xn, C, M, w.hid, 4 * C, e->gelu(), nullptr, 0, s)) return 2;
+        if (big(L.mlp2, e, w.hid, 4 * C, M, w.x, C, 0, w.x, C, s)) return 2;
+    }
+    if (launch_layernorm(w.x, C, M, C, e->lnpg, e->lnpb, (h16*)out, C, s)) return 2;
+    return 0;
+}
+
+// ================================================================================================ cross K/V
+size_t wm_cross_kv_workspace_bytes(const wm_engine* e, int batch) { (void)e; (void)batch; return 256; }
+
+int wm_cross_kv(const wm_engine* e, const void* xa, int B, void* const* out_layers, void* workspace,
+                size_t workspace_bytes, wm_stream_t stream_) {
+    (void)workspace; (void)workspace_bytes;
+    WM_REQUIRE(e && e->kind == WM_ENGINE_CROSS_KV, "wm_cross_kv: not a cross-attention K/V engine");
+    WM_REQUIRE(xa && out_layers && B >= 1, "wm_cross_kv: null argument or empty batch");
+    hipStream_t s = (hipStream_t)stream_;
+    const wm_dims& d = e->dims;
+    const int T = d.n_audio_ctx, C = d.n_text_state, H = d.n_text_head;
+    for (int i = 0; i < d.n_text_layer; ++i) {
+        WM_REQUIRE(out_layers[i], "wm_cross_kv: output %d is null", i);
+        GemmBigParams p{};
+        p.out_mode = 1; p.hs_T = T; p.hs_H = H; p.hs_kv = -1;
+        if (big(e->ckv[i], e, (const h16*)xa, C, B * T, (h16*)out_layers[i], 0, 0, nullptr, 0, s, &p)) return 2;
+    }
+    return 0;
+}
+
+// ================================================================================================ decoder
+namespace {
+struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total; };
+
+int cross_nsplit(int B, int H) {
+    // fill >= ~2 workgroups per CU with (b, h, split) triples
+    int n = (512 + B * H - 1) / (B * H);
+    if (n < 1) n = 1;
+    if (n > 16) n = 16;
+    return n;
+}
+
+DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
+    const wm_dims& d = e->dims;
+    const size_t C = d.n_text_state, M = (size_t)B * L;
+    Carver c{(unsigned char*)ws, 0};
+    DecWs w;
+    w.x = c.take<h16>(M * C); w.xn = c.take<h16>(M * C); w.ctx = c.take<h16>(M * C); w.hid = c.take<h16>(M * 4 * C);
+    // split-K slabs: the widest product is ksplit * N over the six Linears; ksplit <= 24 by construction
+    size_t widest = 0;
+    const int Mc = (int)(M < 64 ? M : 64);
+    const bool q = e->w8();
+    const int Ns[6] = {(int)(3 * C), (int)C, (int)C, (int)C, (int)(4 * C), (int)C};
+    const int Ks[6] = {(int)C, (int)C, (int)C, (int)C, (int)C, (int)(4 * C)};
+    for (int i = 0; i < 6; ++i) {
+        const int s = skinny_default_ksplit(Mc, Ks[i], Ns[i] / 16, q);
+        widest = widest > (size_t)s * Ns[i] ? widest : (size_t)s * Ns[i];
+    }
+    w.part_elems = widest * M;
+    w.part = c.take<float>(w.part_elems);
+    w.nsplit = cross_nsplit(B, d.n_text_head);
+    w.cross_ws = c.take<float>((size_t)B * d.n_text_head * w.nsplit * L * 66);
+    w.total = align_up(c.off);
+    return w;
+}
+
+// skinny GEMM over all M rows in chunks of 64; slabs laid out [ksplit][M_total][ldp]
+int skinny_all(const Lin& l, const h16* A, int lda, int M, float* part, int* ksplit_out, hipStream_t s) {
+    const int Mc = M < 64 ? M : 64;
+    const int ks = skinny_default_ksplit(Mc, l.K, l.n_blocks, l.s != nullptr);
+    for (int r0 = 0; r0 < M; r0 += 64) {
+        GemmSkinnyParams p{};
+        p.A = A + (size_t)r0 * lda; p.lda = lda; p.M = (M - r0) < 64 ? (M - r0) : 64; p.K = l.K;
+        p.Wt = l.w; p.n_blocks = l.n_blocks; p.w8 = l.s != nullptr; p.scale = l.s; p.ksplit = ks;
+        p.part = part + (size_t)r0 * l.N; p.part_sstride = (long)M * l.N;
+        if (launch_gemm_skinny(p, s)) return 2;
+    }
+    *ksplit_out = ks;
+    return 0;
+}
+}  // namespace
+
+size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new) {
+    if (!e || e->kind != WM_ENGINE_DECODER || batch < 1 || n_new < 1) return 0;
+    return carve_decoder(e, batch, n_new, nullptr).total;
+}
+
+int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream_) {
+    WM_REQUIRE(e && e->kind == WM_ENGINE_DECODER, "wm_decoder_step: not a decoder engine");
+    WM_REQUIRE(io && io->tokens && io->positional_embedding && io->present && io->cross && io->logits && io->workspace,
+               "wm_decoder_step: null argument");
+    hipStream_t s = (hipStream_t)stream_;
+    const wm_dims& d = e->dims;
+    const int B = io->batch, L = io->n_new, T = io->n_past, C = d.n_text_state, H = d.n_text_head, M = B * L;
+    WM_REQUIRE(B >= 1 && L >= 1 && L <= 4 && T >= 0, "wm_decoder_step: bad batch/n_new/n_past (%d, %d, %d)", B, L, T);
+    WM_REQUIRE(T + L <= d.n_text_ctx, "wm_decoder_step: T+L=%d exceeds n_text_ctx=%d", T + L, d.n_text_ctx);
+    WM_REQUIRE(T == 0 || io->past, "wm_decoder_step: n_past > 0 needs past buffers");
+    WM_REQUIRE(C == H * 64, "head size must be 64");
+    DecWs w = carve_decoder(e, B, L, io->workspace);
+    WM_REQUIRE(io->workspace_bytes >= w.total, "decoder workspace too small: %zu < %zu", io->workspace_bytes, w.total);
+
+    EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
+                   (const h16*)io->positional_embedding, w.x, C, d.n_vocab};
+    if (launch_embed(ep, s)) return 2;
+
+    auto finish = [&](const Lin& l, int ks, int mode, const h16* g, const h16* bta, h16* out, int ldo, int N) {
+        RowFinishParams p{};
+        p.part = w.part; p.ksplit = ks; p.M = M; p.N = N; p.ldp = l.N; p.part_sstride = (long)M * l.N;
+        p.bias = l.b; p.mode = mode; p.gelu_kind = e->gelu(); p.x = w.x; p.ldx = C; p.ln_g = g; p.ln_b = bta;
+        p.out = out; p.ldo = ldo;
+        return launch_row_finish(p, s);
+    };
+
+    int ks = 0;
+    if (launch_layernorm(w.x, C, M, C, e->dec[0].ln1g, e->dec[0].ln1b, w.xn, C, s)) return 2;
+    for (int i = 0; i < d.n_text_layer; ++i) {
+        const DecLayer& Lr = e->dec[i];
+        // ---- self-attention -----------------------------------------------------------------------
+        if (skinny_all(Lr.qkv, w.xn, C, M, w.part, &ks, s)) return 2;
+        {
+            AttnSelfParams p{};
+            p.part = w.part; p.ksplit = ks; p.ldp = Lr.qkv.N; p.part_sstride = (long)M * Lr.qkv.N; p.bias = Lr.qkv.b;
+            p.B = B; p.L = L; p.T = T; p.H = H;
+            WM_REQUIRE(io->present[i], "wm_decoder_step: present[%d] is null", i);
+            p.present = io->present[i]; p.present_cap = io->present_capacity; p.present_bstride = (long)2 * H * io->present_capacity * 64;
+            if (T > 0) {
+                WM_REQUIRE(io->past[i], "wm_decoder_step: past[%d] is null", i);
+                p.past = io->past[i]; p.past_cap = io->past_capacity; p.past_bstride = (long)2 * H * io->past_capacity * 64;
+            } else { p.past = p.present; p.past_cap = p.present_cap; p.past_bstride = p.present_bstride; }
+            p.int8_kv = e->i8kv(); p.kv_scale = Lr.kv_scale; p.out = w.ctx; p.ldo = C;
+            p.amax = io->qkv_amax ? io->qkv_amax + i : nullptr;
+            if (launch_attn_self(p, s)) return 2;
+        }
+        if (skinny_all(Lr.out, w.ctx, C, M, w.part, &ks, s)) return 2;
+        if (finish(Lr.out, ks, 0, Lr.lncg, Lr.lncb, w.xn, C, C)) return 2;
+        // ---- cross-attention ----------------------------------------------------------------------
+        if (skinny_all(Lr.cq, w.xn, C, M, w.part, &ks, s)) return 2;
+        {
+            AttnCrossParams p{};
+            p.part = w.part; p.ksplit = ks; p.ldp = Lr.cq.N; p.part_sstride = (long)M * Lr.cq.N; p.bias = Lr.cq.b;
+            p.B = B; p.L = L; p.H = H; p.Tk = d.n_audio_ctx;
+            WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
+            p.kv = (const h16*)io->cross[i]; p.kv_bstride = (long)2 * H * d.n_audio_ctx * 64;
+            p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
+            if (launch_attn_cross(p, s)) return 2;
+        }
+        if (skinny_all(Lr.cout, w.ctx, C, M, w.part, &ks, s)) return 2;
+        if (finish(Lr.cout, ks, 0, Lr.ln2g, Lr.ln2b, w.xn, C, C)) return 2;
+        // ---- MLP ----------------------------------------------------------------------------------
+        if (skinny_all(Lr.mlp1, w.xn, C, M, w.part, &ks, s)) return 2;
+        if (finish(Lr.mlp1, ks, 1, nullptr, nullptr, w.hid, 4 * C, 4 * C)) return 2;
+        if (skinny_all(Lr.mlp2, w.hid, 4 * C, M, w.part, &ks, s)) return 2;
+        const bool last = (i + 1 == d.n_text_layer);
+        if (finish(Lr.mlp2, ks, 0, last ? e->lnfg : e->dec[i + 1].ln1g, last ? e->lnfb : e->dec[i + 1].ln1b, w.xn, C, C)) return 2;
+    }
+    // ---- logits = ln(x) . E^T (fp16 out, whisper/model.py:288-290) ----------------------------------
+    for (int r0 = 0; r0 < M; r0 += 64) {
+        GemmSkinnyParams p{};
+        p.A = w.xn + (size_t)r0 * C; p.lda = C; p.M = (M - r0) < 64 ? (M - r0) : 64; p.K = C;
+        p.Wt = e->emb_t; p.n_blocks = e->emb_blocks; p.w8 = 0; p.ksplit = 1;
+        p.out = (h16*)io->logits + (size_t)r0 * d.n_vocab; p.ldc = d.n_vocab; p.n_valid = d.n_vocab;
+        if (launch_gemm_skinny(p, s)) return 2;
+    }
+    return 0;
+}
+
+// ================================================================================================ greedy
+int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream) {
+    WM_REQUIRE(io && io->logits && io->tokens && io->sum_logprobs, "wm_greedy_step: null argument");
+    GreedyParams p{};
+    p.logits = (const h16*)io->logits; p.ld_row = io->row_stride; p.B = io->batch; p.V = io->n_vocab;
+    p.tokens = io->tokens; p.ld_tok = io->tokens_ld; p.cur_len = io->cur_len; p.sum_logprobs = io->sum_logprobs;
+    p.suppress_mask = io->suppress_mask; p.blank = io->blank; p.n_blank = io->n_blank;
+    p.sample_begin = io->sample_begin; p.eot = io->eot; p.timestamp_begin = io->timestamp_begin;
+    p.max_initial_ts = io->max_initial_timestamp_index; p.apply_rules = io->apply_rules; p.n_done = io->n_done;
+    return launch_greedy(p, (hipStream_t)stream);
+}
+
+// ================================================================================================ kernel-level
+int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, const void* scale,
+            const void* bias, const void* residual, int ldr, int act, void* C, int ldc, wm_stream_t stream) {
+    GemmBigParams p{};
+    p.A = (const h16*)A; p.lda = lda; p.M = M; p.K = K; p.W = W; p.N = N; p.w8 = w8;
+    p.scale = (const h16*)scale; p.bias = (const h16*)bias; p.C = (h16*)C; p.ldc = ldc;
+    p.residual = (const h16*)residual; p.ldr = ldr; p.act = act;
+    return launch_gemm_big(p, (hipStream_t)stream);
+}
+
+int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_blocks, int w8,
+                   const void* scale, int ksplit, float* part, wm_stream_t stream) {
+    GemmSkinnyParams p{};
+    p.A = (const h16*)A; p.lda = lda; p.M = M; p.K = K; p.Wt = Wt; p.n_blocks = n_blocks; p.w8 = w8;
+    p.scale = (const h16*)scale; p.ksplit = ksplit; p.part = part;
+    return launch_gemm_skinny(p, (hipStream_t)stream);
+}
+int wm_gemm_skinny_default_ksplit(int M, int K, int n_blocks, int w8) { return skinny_default_ksplit(M, K, n_blocks, w8); }
+
+int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta, void* out, int ldo,
+                 wm_stream_t stream) {
+    return launch_layernorm((const h16*)x, ldx, M, N, (const h16*)gamma, (const h16*)beta, (h16*)out, ldo, (hipStream_t)stream);
+}
+
+int wm_attn_encoder(const void* qkv, int ld, int B, int T, int H, void* out, int ldo, wm_stream_t stream) {
+    AttnEncParams p{(const h16*)qkv, ld, B, T, H, (h16*)out, ldo};
+    return launch_attn_encoder(p, (hipStream_t)stream);
+}
+
+int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void* kv, void* out, int nsplit,
+                         float* ws, wm_stream_t stream) {
+    AttnCrossParams p{};
+    p.part = q; p.ksplit = 1; p.ldp = H * 64; p.bias = nullptr;
+    p.B = B; p.L = L; p.H = H; p.Tk = Tk; p.kv = (const h16*)kv; p.kv_bstride = (long)2 * H * Tk * 64;
+    p.out = (h16*)out; p.ldo = H * 64; p.nsplit = nsplit; p.ws = ws;
+    return launch_attn_cross(p, (hipStream_t)stream);
+}
+
+int wm_attn_decode_self(const float* qkv, int B, int L, int T, int H, const void* past, int past_cap,
+                        void* present, int present_cap, int int8_kv, float kv_scale, void* out, wm_stream_t stream) {
+    AttnSelfParams p{};
+    p.part = qkv; p.ksplit = 1; p.ldp = 3 * H * 64; p.bias = nullptr;
+    p.B = B; p.L = L; p.T = T; p.H = H;
+    p.present = present; p.present_cap = present_cap; p.present_bstride = (long)2 * H * present_cap * 64;
+    if (T > 0 && past) { p.past = past; p.past_cap = past_cap; p.past_bstride = (long)2 * H * past_cap * 64; }
+    else { p.past = present; p.past_cap = present_cap; p.past_bstride = p.present_bstride; }
+    p.int8_kv = int8_kv; p.kv_scale = kv_scale; p.out = (h16*)out; p.ldo = H * 64;
+    return launch_attn_self(p, (hipStream_t)stream);
+}
+
+int wm_quantize_i8(const void* x, void* q, int64_t n, float inv_scale, wm_stream_t stream) {
+    return launch_quantize_i8((const h16*)x, (int8_t*)q, (long)n, inv_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// Weight-streaming GEMM for the decode path: M <= 64 activation rows (M = B for a decode step,
+// 3B for the prefill) against a weight matrix that is read from HBM exactly once.
+//
+// Replaces WeightOnlyQuantMatmulPlugin::enqueue's M == 1 GEMV
+// (R/cpp/tensorrt_llm/kernels/weightOnlyMatrixVectorMultiplication.cu:136-205,371-378) and its
+// small-M CUTLASS branch (weightOnlyQuantMatmulPlugin.cpp:182-197), plus the fp16 MatMul of the
+// non-quantised engines and the tied logits projection (whisper/model.py:290).
+//
+// Weight layout ("tile-linear", written by weight.py): the [N][K] matrix is cut into tiles of
+// 16 output channels x KT input channels, KT = 64 (int8) or 32 (fp16), each tile 1024 contiguous
+// bytes ordered by lane: lane l holds 16 bytes = channel (l & 15), inputs [KT/4 * (l >> 4), +KT/4).
+// Tiles are ordered [n_block][k_tile].  One wave-wide 16-byte load therefore fetches 1 KiB of
+// contiguous HBM and lands every lane's bytes already in the B-operand layout of
+// v_mfma_f32_16x16x32_f16 (B[k = 8 * (lane >> 4) + j][n = lane & 15]); int8 tiles feed two MFMAs
+// (their first / second 8 inputs per lane) after an exact int8 -> fp16 expansion in registers.
+// There is no LDS round trip for the streamed operand; only the small activation block is staged
+// in LDS (shared by the 4 waves of a workgroup, each wave owning a different 16-channel block).
+//
+// Parallelism: grid = ceil(n_blocks / 4) x ksplit workgroups.  K slices write fp32 partial slabs
+// part[s][m][n] (already multiplied by the per-channel scale); the consumer kernel sums the slabs
+// in a fixed order (deterministic, unlike atomics) together with bias / residual / LN / GELU.
+#include "common.h"
+#include "kernels.h"
+
+namespace wm {
+
+constexpr int KC = 256;                 // activation chunk staged per barrier (inputs)
+constexpr int A_ROW = KC * 2 + 16;      // LDS row stride in bytes
+
+template <bool W8, int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyParams p) {
+    constexpr int KT = W8 ? 64 : 32;          // inputs per weight tile
+    constexpr int TPC = KC / KT;              // tiles per chunk: 4 (int8) / 8 (fp16)
+    __shared__ __attribute__((aligned(16))) unsigned char sA[MT * 16 * A_ROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nwg_n = (p.n_blocks + 3) >> 2;
+    const int bn = blockIdx.x % nwg_n, ks = blockIdx.x / nwg_n;
+    const int nb = bn * 4 + wid;                          // this wave's 16-channel block
+    const bool wave_active = nb < p.n_blocks;
+
+    const int kt_total = p.K / KT;
+    const int tps = (kt_total + p.ksplit - 1) / p.ksplit;  // tiles per split
+    const int t_begin = ks * tps;
+    const int t_end = min(kt_total, t_begin + tps);
+
+    const u32x4* wt = (const u32x4*)p.Wt + ((size_t)(wave_active ? nb : 0) * kt_total) * 64 + lane;
+
+    float4v acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 wreg[TPC];
+    auto load_w = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < TPC; ++i) {
+            const int t = t0 + i;
+            if (wave_active && t < t_end) wreg[i] = __builtin_nontemporal_load(wt + (size_t)t * 64);
+        }
+    };
+    load_w(t_begin);
+
+    const int frag_row = (lane & 15) * A_ROW;
+    for (int t0 = t_begin; t0 < t_end; t0 += TPC) {
+        // ---- stage A[:, t0*KT .. +KC) into LDS (zero rows >= M, zero columns >= K) ----------
+        const int k0 = t0 * KT;
+        for (int c = tid; c < MT * 16 * (KC / 8); c += 256) {
+            const int r = c / (KC / 8), cc = c % (KC / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < p.M && k0 + cc * 8 < p.K) v = *(const uint4*)(p.A + (size_t)r * p.lda + k0 + cc * 8);
+            *(uint4*)(sA + r * A_ROW + cc * 16) = v;
+        }
+        __syncthreads();
+        u32x4 wcur[TPC];
+#pragma unroll
+        for (int i = 0; i < TPC; ++i) wcur[i] = wreg[i];
+        if (t0 + TPC < t_end) load_w(t0 + TPC);       // next chunk's weights fly during the MFMAs
+        if (wave_active) {
+#pragma unroll
+            for (int i = 0; i < TPC; ++i) {
+                if (t0 + i < t_end) {
+                    if (W8) {
+                        half2v h[8];
+                        cvt_s8x4_f16x4(wcur[i].x, h[0], h[1]);
+                        cvt_s8x4_f16x4(wcur[i].y, h[2], h[3]);
+                        cvt_s8x4_f16x4(wcur[i].z, h[4], h[5]);
+                        cvt_s8x4_f16x4(wcur[i].w, h[6], h[7]);
+                        half8v b0, b1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            b0[2 * j] = h[j][0]; b0[2 * j + 1] = h[j][1];
+                            b1[2 * j] = h[4 + j][0]; b1[2 * j + 1] = h[4 + j][1];
+                        }
+                        // lane's 16 inputs start at 16 * (lane >> 4) inside the 64-wide tile
+                        const unsigned char* ab = sA + frag_row + (i * 64 + (lane >> 4) * 16) * 2;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const half8v a0 = *(const half8v*)(ab + mt * 16 * A_ROW);
+                            const half8v a1 = *(const half8v*)(ab + mt * 16 * A_ROW + 16);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[mt], 0, 0, 0);
+                        }
+                    } else {
+                        const half8v b0 = __builtin_bit_cast(half8v, wcur[i]);
+                        const unsigned char* ab = sA + frag_row + (i * 32 + (lane >> 4) * 8) * 2;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const half8v a0 = *(const half8v*)(ab + mt * 16 * A_ROW);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[mt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    const int col = nb * 16 + (lane & 15);
+    const float sc = (W8 && p.scale) ? (float)p.scale[col] : 1.0f;
+    const int ldp = p.n_blocks * 16;
+    const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.M * ldp;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + (lane >> 4) * 4 + r;
+            if (row >= p.M) continue;
+            const float v = acc[mt][r] * sc;
+            if (p.out) {
+                if (col < p.n_valid) p.out[(size_t)row * p.ldc + col] = (h16)v;
+            } else {
+                p.part[(size_t)ks * sstride + (size_t)row * ldp + col] = v;
+            }
+        }
+    }
+}
+
+int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
+    const int kt_total = K / (w8 ? 64 : 32);
+    const int nwg_n = (n_blocks + 3) / 4;
+    int s = (768 + nwg_n - 1) / nwg_n;                 // aim for ~3 workgroups per CU
+    const int min_tiles = w8 ? 2 : 4;                  // at least 2 KiB (int8) / 4 KiB (fp16) per wave
+    s = min(s, max(1, kt_total / min_tiles));
+    // partial-slab traffic (2 * s * M * N * 4 B) should stay below the weight bytes (N * K * es)
+    const int es = w8 ? 1 : 2;
+    const int cap = max(1, (K * es) / (8 * max(M, 1)));
+    s = min(s, max(cap, 2));
+    return max(1, s);
+}
+
+template <bool W8>
+static int launch_mt(const GemmSkinnyParams& p, int grid, hipStream_t stream) {
+    const int mt = (p.M + 15) / 16;
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 1>), dim3(grid), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 2>), dim3(grid), dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 3>), dim3(grid), dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 4>), dim3(grid), dim3(256), 0, stream, p); break;
+    }
+    return 0;
+}
+
+int launch_gemm_skinny(const GemmSkinnyParams& p, hipStream_t stream) {
+    WM_REQUIRE(p.M >= 1 && p.M <= 64, "gemm_skinny: M=%d out of range [1,64]", p.M);
+    const int KT = p.w8 ? 64 : 32;
+    WM_REQUIRE(p.K % KT == 0, "gemm_skinny: K=%d must be a multiple of %d", p.K, KT);
+    WM_REQUIRE(p.lda % 8 == 0, "gemm_skinny: lda=%d must be a multiple of 8", p.lda);
+    WM_REQUIRE(p.ksplit >= 1, "gemm_skinny: ksplit must be >= 1");
+    WM_REQUIRE(p.out == nullptr || p.ksplit == 1, "gemm_skinny: direct output needs ksplit == 1");
+    WM_REQUIRE(p.out != nullptr || p.part != nullptr, "gemm_skinny: no output buffer");
+    const int grid = ((p.n_blocks + 3) / 4) * p.ksplit;
+    if (p.w8) launch_mt<true>(p, grid, stream); else launch_mt<false>(p, grid, stream);
+    WM_LAUNCH_CHECK(stream, "gemm_skinny");
+    return 0;
+}
+
+}  // namespace wm

@@ -1,0 +1,143 @@
+// Device-side greedy step: Whisper's logit filters + argmax + log-prob bookkeeping + token append
+// in ONE kernel, so that a decode step never returns to the host.
+//
+// Restates for the device what the reference does in Python on every token (host loops,
+// .tolist() and a stream sync per step -- W/decoding.py:785-821):
+//   SuppressBlank (W/decoding.py:202-209), SuppressTokens (:212-217, list from :394-421),
+//   ApplyTimestampRules (:134-199), GreedyDecoder.update (:274-300).
+// One workgroup per utterance; two passes over the vocabulary row (51 865 fp16 logits = 104 KB,
+// L2-resident right after the logits GEMM):
+//   pass 1: masked running (max, sum-exp) separately for text tokens (< timestamp_begin) and
+//           timestamp tokens, plus the arg-max of each class;
+//   decide: timestamps win if logsumexp(timestamps) > max(text)  (:191-199; the common log Z
+//           cancels), then the next token, its log-probability under the final mask, EOT
+//           stickiness and the append.
+#include "common.h"
+#include "kernels.h"
+
+namespace wm {
+
+struct MS { float m, s; };                       // running max and sum of exp(x - m)
+__device__ __forceinline__ MS ms_add(MS a, float x) {
+    if (x == -INFINITY) return a;
+    if (x > a.m) { a.s = a.s * __expf(a.m - x) + 1.f; a.m = x; }
+    else a.s += __expf(x - a.m);
+    return a;
+}
+__device__ __forceinline__ MS ms_merge(MS a, MS b) {
+    if (b.m == -INFINITY) return a;
+    if (a.m == -INFINITY) return b;
+    const float m = fmaxf(a.m, b.m);
+    return MS{m, a.s * __expf(a.m - m) + b.s * __expf(b.m - m)};
+}
+struct AM { float v; int i; };                   // arg-max with first-index tie break
+__device__ __forceinline__ AM am_merge(AM a, AM b) {
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+
+template <typename T, typename F>
+__device__ __forceinline__ T block_reduce(T v, F merge, T* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T other;
+        // shuffle the struct field-wise (two 32-bit words)
+        static_assert(sizeof(T) == 8, "pair types only");
+        unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+        unsigned lo = __shfl_xor((unsigned)bits, o), hi = __shfl_xor((unsigned)(bits >> 32), o);
+        other = __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+        v = merge(v, other);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    T r = scratch[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = merge(r, scratch[w]);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void greedy_kernel(GreedyParams p) {
+    __shared__ MS s_ms[4];
+    __shared__ AM s_am[4];
+    __shared__ int s_info[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const h16* lg = p.logits + (size_t)b * p.ld_row;
+    int32_t* toks = p.tokens + (size_t)b * p.ld_tok;
+    const int tb = p.timestamp_begin;
+
+    // ---- token-history facts (thread 0): last / penultimate sampled token, last timestamp ----------
+    if (tid == 0) {
+        int last_ts = 0, pen_ts = 0, ts_last = -1;
+        if (p.apply_rules) {
+            const int n = p.cur_len - p.sample_begin;
+            last_ts = (n >= 1 && toks[p.cur_len - 1] >= tb) ? 1 : 0;
+            pen_ts = (n < 2 || toks[p.cur_len - 2] >= tb) ? 1 : 0;
+            for (int j = p.cur_len - 1; j >= p.sample_begin; --j)
+                if (toks[j] >= tb) { ts_last = toks[j]; break; }
+            if (ts_last >= 0 && !(last_ts && !pen_ts)) ts_last += 1;
+        }
+        s_info[0] = last_ts; s_info[1] = pen_ts; s_info[2] = ts_last;
+    }
+    __syncthreads();
+    const bool last_ts = s_info[0], pen_ts = s_info[1];
+    const int ts_last = s_info[2];
+    const bool first = p.apply_rules && (p.cur_len == p.sample_begin);
+
+    auto masked = [&](int n) -> bool {
+        if (!p.apply_rules) return false;
+        if (p.suppress_mask[n]) return true;
+        if (first) {
+            if (n < tb) return true;
+            if (p.max_initial_ts >= 0 && n > tb + p.max_initial_ts) return true;
+        }
+        if (last_ts) {
+            if (pen_ts) { if (n >= tb) return true; }
+            else if (n < p.eot) return true;
+        }
+        if (ts_last >= 0 && n >= tb && n < ts_last) return true;
+        return false;
+    };
+
+    MS txt{-INFINITY, 0.f}, tsm{-INFINITY, 0.f};
+    AM atxt{-INFINITY, 0x7fffffff}, ats{-INFINITY, 0x7fffffff};
+    for (int n = tid; n < p.V; n += 256) {
+        float x = (float)lg[n];
+        if (masked(n)) x = -INFINITY;
+        if (first) for (int k = 0; k < p.n_blank; ++k) if (p.blank[k] == n) x = -INFINITY;
+        if (!p.apply_rules || n < tb) { txt = ms_add(txt, x); if (x > atxt.v) atxt = AM{x, n}; }
+        else { tsm = ms_add(tsm, x); if (x > ats.v) ats = AM{x, n}; }
+    }
+    txt = block_reduce(txt, ms_merge, s_ms);
+    tsm = block_reduce(tsm, ms_merge, s_ms);
+    atxt = block_reduce(atxt, am_merge, s_am);
+    ats = block_reduce(ats, am_merge, s_am);
+
+    if (tid == 0) {
+        bool ts_only = false;
+        if (p.apply_rules) {
+            const float lse_ts = (tsm.m == -INFINITY) ? -INFINITY : tsm.m + __logf(tsm.s);
+            ts_only = lse_ts > txt.m;      // logsumexp(ts logprobs) > max(text logprobs)
+        }
+        AM best = ts_only ? ats : am_merge(atxt, ats);
+        MS z = ts_only ? tsm : ms_merge(txt, tsm);
+        const float logz = z.m + logf(z.s);
+        const float lp = best.v - logz;
+        const int prev = toks[p.cur_len - 1];
+        const bool alive = (prev != p.eot);
+        if (alive) p.sum_logprobs[b] += lp;
+        const int next = alive ? best.i : p.eot;
+        toks[p.cur_len] = next;
+        if (next == p.eot && p.n_done) atomicAdd(p.n_done, 1);
+    }
+}
+
+int launch_greedy(const GreedyParams& p, hipStream_t stream) {
+    WM_REQUIRE(p.cur_len >= 1 && p.cur_len < p.ld_tok, "greedy: cur_len=%d does not fit ld_tok=%d", p.cur_len, p.ld_tok);
+    WM_REQUIRE(!p.apply_rules || p.suppress_mask != nullptr, "greedy: rules need a suppress mask");
+    hipLaunchKernelGGL(greedy_kernel, dim3(p.B), dim3(256), 0, stream, p);
+    WM_LAUNCH_CHECK(stream, "greedy");
+    return 0;
+}
+
+}  // namespace wm

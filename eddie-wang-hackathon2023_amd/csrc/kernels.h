@@ -1,0 +1,124 @@
+// Internal launch interfaces of the gfx950 kernels (C++ side of the C-ABI in include/whisper_mi355.h).
+#pragma once
+#include "common.h"
+
+namespace wm {
+
+// ---------------------------------------------------------------- gemm_big.hip
+struct GemmBigParams {
+    const h16* A; int lda; int M; int K;
+    const void* W; int N; int w8;            // W [N][K] row-major fp16, or int8 when w8
+    const h16* scale; const h16* bias;       // per output channel (scale only with w8); may be null
+    h16* C; int ldc;
+    const h16* residual; int ldr; int res_mod;   // v += residual[row % res_mod (or row)][col]
+    int act;                                 // 0 none, 1 exact-erf GELU, 2 tanh GELU
+    int colscale_n; float colscale;          // columns < colscale_n are multiplied by colscale
+    int out_mode;                            // 0 row-major, 1 head-split [B,2,H,T,64]
+    int hs_T, hs_H, hs_kv;                   // hs_kv < 0: N = 2*H*64, kv = col / (H*64)
+    // batched strided views (convolutions as GEMMs over a zero-padded token-major buffer):
+    // row m lives at A + (m / a_rows) * a_bstride + (m % a_rows) * lda   (a_rows == 0: plain)
+    int a_rows; long a_bstride;
+    int c_rows; long c_bstride;              // same for C (out_mode 0 only)
+};
+int launch_gemm_big(const GemmBigParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------- gemm_skinny.hip
+// Weight-streaming GEMM for M <= 64 rows (decode step M = B, prefill M = 3B):
+//   out = A[M,K] x Wt     with Wt stored tile-linear (see weight layout in DESIGN.md)
+struct GemmSkinnyParams {
+    const h16* A; int lda; int M; int K;
+    const void* Wt; int n_blocks; int w8;    // n_blocks = padded N / 16
+    const h16* scale;                        // [n_blocks*16] (w8 only)
+    int ksplit;                              // number of K slices
+    float* part;                             // [ksplit][..][n_blocks*16] fp32 partial sums (scaled)
+    long part_sstride;                       // elements between K-slice slabs (0: M * n_blocks * 16)
+    h16* out; int ldc; int n_valid;          // direct fp16 output instead of partials (ksplit == 1)
+};
+int launch_gemm_skinny(const GemmSkinnyParams& p, hipStream_t stream);
+int skinny_default_ksplit(int M, int K, int n_blocks, int w8);
+
+// ---------------------------------------------------------------- rowops.hip
+struct RowFinishParams {
+    // y = sum_s part[s][m][:] + bias ; y16 = fp16(y)
+    const float* part; int ksplit; int M; int N; int ldp;   // ldp = padded N of the partial slabs
+    long part_sstride;                                      // elements between slabs (0: M * ldp)
+    const h16* bias;
+    // mode 0: x = fp16(x + y16) (in place, residual stream), then xn = LayerNorm(x) * g + b
+    // mode 1: h = fp16(gelu(y16))                      (MLP hidden)
+    // mode 2: xn = LayerNorm(x) * g + b only           (no partials; first block / encoder)
+    // mode 3: x = fp16(x + y16) only
+    int mode; int gelu_kind;
+    h16* x; int ldx;
+    const h16* ln_g; const h16* ln_b;
+    h16* out; int ldo;
+};
+int launch_row_finish(const RowFinishParams& p, hipStream_t stream);
+
+struct EmbedParams {
+    const int32_t* tokens; int tokens_ld;    // token of row m = tokens[(m / L) * tokens_ld + m % L]
+    int M;                                   // M = B*L rows
+    int L;                                   // row m uses pos[m % L]
+    const void* emb_tiles; int C;            // token embedding in fp16 tile-linear layout [V/16][C/32][64][8]
+    const h16* pos;                          // [L][C] (already offset by the caller, decoding.py:604-608)
+    h16* x; int ldx;
+    int n_vocab;
+};
+int launch_embed(const EmbedParams& p, hipStream_t stream);
+
+int launch_mel_transpose_pad(const h16* mel, int B, int n_mels, int T, h16* out /*[B][T+2][n_mels]*/,
+                             hipStream_t stream);
+int launch_zero_pad_rows(h16* buf, int B, int Tpad, int C, hipStream_t stream);
+int launch_layernorm(const h16* x, int ldx, int M, int N, const h16* g, const h16* b, h16* out, int ldo,
+                     hipStream_t stream);
+
+// ---------------------------------------------------------------- attn_encoder.hip
+struct AttnEncParams {
+    const h16* qkv; int ld;                  // [B*T][3C] rows, q | k | v column blocks (q,k pre-scaled by d^-0.25)
+    int B, T, H;                             // head size 64
+    h16* out; int ldo;                       // [B*T][C]
+};
+int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------- attn_decode.hip
+struct AttnSelfParams {
+    const float* part; int ksplit; int ldp;  // qkv partial slabs [ksplit][M][ldp], columns q | k | v
+    long part_sstride;                       // elements between slabs (0: M * ldp)
+    const h16* bias;                         // [3C] = [q bias, 0, v bias] (weight.py:209-215)
+    int B, L, T, H;                          // T cached tokens before this call
+    const void* past; long past_bstride; int past_cap;      // [B][2][H][past_cap][64]
+    void* present; long present_bstride; int present_cap;   // may alias past (in-place append)
+    int int8_kv; float kv_scale;             // t (kv_quant_orig); 1/t formed in fp32
+    float* amax;                             // optional: running max |q|,|k|,|v| (int8-KV calibration)
+    h16* out; int ldo;                       // [M][C]
+};
+int launch_attn_self(const AttnSelfParams& p, hipStream_t stream);
+
+struct AttnCrossParams {
+    const float* part; int ksplit; int ldp;  // q partial slabs [ksplit][M][ldp]
+    long part_sstride;
+    const h16* bias;                         // [C]
+    int B, L, H, Tk;                         // Tk = n_audio_ctx (1500)
+    const h16* kv; long kv_bstride;          // [B][2][H][Tk][64] fp16
+    h16* out; int ldo;                       // [M][C]
+    int nsplit;                              // key-range splits per (b,h)  (1 = single pass)
+    float* ws;                               // [B*H*nsplit][L][66] partial (m, l, o[64]) when nsplit > 1
+};
+int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------- greedy.hip
+struct GreedyParams {
+    const h16* logits; long ld_row;          // row b at logits + b*ld_row (last position of each utterance)
+    int B; int V;
+    int32_t* tokens; int ld_tok; int cur_len;     // [B][ld_tok], cur_len tokens valid; next written at cur_len
+    float* sum_logprobs;                     // [B]
+    const uint8_t* suppress_mask;            // [V] 1 = always suppressed (SuppressTokens + no_timestamps)
+    const int32_t* blank; int n_blank;       // SuppressBlank list (incl. eot)
+    int sample_begin; int eot; int timestamp_begin; int max_initial_ts;   // -1 = no limit
+    int apply_rules;                         // 0 = plain argmax (tests / models without special ids)
+    int32_t* n_done;                         // [1] number of rows whose last token is eot after this step
+};
+int launch_greedy(const GreedyParams& p, hipStream_t stream);
+
+int launch_quantize_i8(const h16* x, int8_t* q, long n, float inv_scale, hipStream_t stream);
+
+}  // namespace wm

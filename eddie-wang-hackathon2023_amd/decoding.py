@@ -1,0 +1,595 @@
+"""WhisperDecoding: decoder + cross-K/V session wrapper and Whisper's greedy decoding rules.
+
+Same classes, constructor, attributes and method names as the reference's
+examples/whisper/decoding.py (W/decoding.py; W = /root/reference/tensorrt_llm_july-release-v1/
+examples/whisper): `DecodingOptions`, `DecodingResult`, `MaximumLikelihoodRanker`,
+`SuppressBlank`, `SuppressTokens`, `ApplyTimestampRules`, `GreedyDecoder`, and
+`WhisperDecoding.{xa2cross_key_value, decode, detect_language, main_loop, post_process,
+torch_detect_language, torch_main_loop}` (W/decoding.py:303-878).
+
+What differs underneath:
+* any batch size and model size (the reference hard-wires batch 1 / large-v2);
+* `main_loop` runs the fast path: KV cache pre-allocated `[B,2,H,n_text_ctx,64]` and appended in
+  place (the reference concatenates a fresh cache per layer per step), logit rules +
+  arg-max + log-prob + token append fused in one device kernel (csrc/greedy.hip), no host
+  synchronisation inside the loop except a completion poll every `poll_every` steps.
+  `main_loop_reference` is the literal per-step loop through `decode()` and the host-side filter
+  classes, kept for parity tests: both must return identical tokens;
+* the cross-attention K/V computed by `detect_language` are re-used by `main_loop` for the same
+  audio features (the reference runs that engine twice per utterance).
+"""
+from __future__ import annotations
+
+import json
+import zlib
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from functools import lru_cache
+from pathlib import Path
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import ctypes as C
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+import native
+from build import get_engine_name
+from session import Session, TensorInfo, str_dtype_to_trt, trt_dtype_to_torch, logger
+from tokenizer import LANGUAGES, TO_LANGUAGE_CODE, Tokenizer
+
+CHUNK_LENGTH = 30
+
+
+@dataclass(frozen=True)
+class DecodingOptions:
+    task: str = "transcribe"            # "transcribe" (X->X) or "translate" (X->English)
+    language: Optional[str] = None      # detected when None
+    temperature: float = 0.0
+    sample_len: Optional[int] = None    # maximum number of tokens to sample
+    best_of: Optional[int] = None
+    beam_size: Optional[int] = None
+    patience: Optional[float] = None
+    length_penalty: Optional[float] = None
+    prompt: Optional[Union[str, List[int]]] = None
+    prefix: Optional[Union[str, List[int]]] = None
+    suppress_tokens: Optional[Union[str, Iterable[int]]] = "-1"
+    suppress_blank: bool = True
+    without_timestamps: bool = False
+    max_initial_timestamp: Optional[float] = 1.0
+    fp16: bool = True
+
+
+@dataclass(frozen=True)
+class DecodingResult:
+    audio_features: Tensor
+    language: str
+    language_probs: Optional[Dict[str, float]] = None
+    tokens: List[int] = field(default_factory=list)
+    text: str = ""
+    avg_logprob: float = np.nan
+    no_speech_prob: float = np.nan
+    temperature: float = np.nan
+    compression_ratio: float = np.nan
+
+
+class MaximumLikelihoodRanker:
+    """Pick the sample with the highest length-normalised log-probability (W/decoding.py:92-115)."""
+
+    def __init__(self, length_penalty: Optional[float]):
+        self.length_penalty = length_penalty
+
+    def rank(self, tokens: List[List[Tensor]], sum_logprobs: List[List[float]]):
+        picks = []
+        for group, lps in zip(tokens, sum_logprobs):
+            scores = []
+            for t, lp in zip(group, lps):
+                n = len(t)
+                penalty = n if self.length_penalty is None else ((5 + n) / 6) ** self.length_penalty
+                scores.append(lp / penalty)
+            picks.append(int(np.argmax(scores)))
+        return picks
+
+
+# ---- host-side logit filters (the reference-faithful loop; vectorised over the batch) -----------
+
+class LogitFilter:
+    def apply(self, logits: Tensor, tokens: Tensor) -> None:
+        raise NotImplementedError
+
+
+class SuppressBlank(LogitFilter):
+    def __init__(self, tokenizer: Tokenizer, sample_begin: int):
+        self.tokenizer, self.sample_begin = tokenizer, sample_begin
+
+    def apply(self, logits: Tensor, tokens: Tensor):
+        if tokens.shape[1] == self.sample_begin:
+            logits[:, list(self.tokenizer.blank_tokens()) + [self.tokenizer.eot]] = -np.inf
+
+
+class SuppressTokens(LogitFilter):
+    def __init__(self, suppress_tokens: Sequence[int]):
+        self.suppress_tokens = list(suppress_tokens)
+
+    def apply(self, logits: Tensor, tokens: Tensor):
+        logits[:, self.suppress_tokens] = -np.inf
+
+
+class ApplyTimestampRules(LogitFilter):
+    """Timestamp pairing / monotonicity / initial-timestamp rules (W/decoding.py:134-199)."""
+
+    def __init__(self, tokenizer: Tokenizer, sample_begin: int, max_initial_timestamp_index: Optional[int]):
+        self.tokenizer, self.sample_begin = tokenizer, sample_begin
+        self.max_initial_timestamp_index = max_initial_timestamp_index
+
+    def apply(self, logits: Tensor, tokens: Tensor):
+        tk = self.tokenizer
+        tb, eot = tk.timestamp_begin, tk.eot
+        V = logits.shape[1]
+        if tk.no_timestamps is not None:
+            logits[:, tk.no_timestamps] = -np.inf
+        sampled = tokens[:, self.sample_begin:]
+        n = sampled.shape[1]
+        is_ts = sampled >= tb
+        col = torch.arange(V, device=logits.device)[None, :]
+        last_ts = is_ts[:, -1] if n >= 1 else torch.zeros(tokens.shape[0], dtype=torch.bool, device=tokens.device)
+        pen_ts = is_ts[:, -2] if n >= 2 else torch.ones(tokens.shape[0], dtype=torch.bool, device=tokens.device)
+        # timestamps come in pairs (except right before EOT)
+        kill = (last_ts & pen_ts)[:, None] & (col >= tb)
+        kill |= (last_ts & ~pen_ts)[:, None] & (col < eot)
+        if n >= 1:
+            # no decreasing timestamps; a closed segment must have non-zero length
+            has_ts = is_ts.any(dim=1)
+            idx = torch.arange(n, device=tokens.device)[None, :].expand_as(is_ts)
+            last_pos = torch.where(is_ts, idx, torch.full_like(idx, -1)).max(dim=1).values.clamp(min=0)
+            last_val = sampled.gather(1, last_pos[:, None])[:, 0]
+            bound = torch.where(last_ts & ~pen_ts, last_val, last_val + 1)
+            kill |= has_ts[:, None] & (col >= tb) & (col < bound[:, None])
+        logits.masked_fill_(kill.to(logits.device), -np.inf)
+        if tokens.shape[1] == self.sample_begin:
+            logits[:, :tb] = -np.inf
+            if self.max_initial_timestamp_index is not None:
+                logits[:, tb + self.max_initial_timestamp_index + 1:] = -np.inf
+        # if the timestamps together outweigh every text token, sample a timestamp
+        logprobs = F.log_softmax(logits.float(), dim=-1)
+        ts_lp = logprobs[:, tb:].logsumexp(dim=-1)
+        text_lp = logprobs[:, :tb].max(dim=-1).values
+        logits[:, :tb] = torch.where((ts_lp > text_lp)[:, None], torch.full_like(logits[:, :tb], -np.inf),
+                                     logits[:, :tb])
+
+
+class GreedyDecoder:
+    def __init__(self, temperature: float, eot: int):
+        self.temperature, self.eot = temperature, eot
+
+    def update(self, tokens: Tensor, logits: Tensor, sum_logprobs: Tensor) -> Tuple[Tensor, bool]:
+        if self.temperature == 0:
+            next_tokens = logits.argmax(dim=-1)
+        else:
+            next_tokens = torch.distributions.Categorical(logits=logits / self.temperature).sample()
+        logprobs = F.log_softmax(logits.float(), dim=-1)
+        current = logprobs[torch.arange(logprobs.shape[0]), next_tokens]
+        alive = tokens[:, -1] != self.eot
+        sum_logprobs += current * alive
+        next_tokens[~alive] = self.eot
+        tokens = torch.cat([tokens, next_tokens[:, None]], dim=-1)
+        return tokens, bool((tokens[:, -1] == self.eot).all())
+
+    def finalize(self, tokens: Tensor, sum_logprobs: Tensor):
+        # make sure each sequence has at least one EOT token at the end
+        return F.pad(tokens, (0, 1), value=self.eot), sum_logprobs.tolist()
+
+
+class WhisperDecoding:
+    def __init__(self, engine_dir, only_torch: bool = False, vocab_path: Optional[str] = None,
+                 options: Optional[DecodingOptions] = None):
+        engine_dir = Path(engine_dir)
+        self.decoder_config = None
+        self.cross_attn_config = None
+        self.get_config(engine_dir)
+        self.only_torch = only_torch
+        if not only_torch:
+            self.decoder_session, self.cross_attn_session = self.get_session(engine_dir)
+        self.vocab_path = vocab_path
+        multilingual = self.decoder_config.get('vocab_size', 51865) >= 51865
+        self.tokenizer = self.get_tokenizer(multilingual, 'en', 'transcribe')
+
+        self.sot_sequence = self.tokenizer.sot_sequence
+        self.initial_tokens = tuple(list(self.sot_sequence))
+        self.initial_token_length = len(self.initial_tokens)
+        self.tokens = torch.tensor([self.initial_tokens]).repeat(self.decoder_config['num_audio'], 1)
+        self.sot_index = self.initial_tokens.index(self.tokenizer.sot)
+        self.options = options or DecodingOptions()
+
+        self.n_group = self.options.beam_size or self.options.best_of or 1
+        self.sample_len: int = self.options.sample_len or self.decoder_config['num_text_ctx'] // 2
+        self.sample_begin: int = len(self.initial_tokens)
+        self.use_int8_kv_cache = self.decoder_config['use_int8_kv_cache']
+
+        pe = np.load(engine_dir / 'positional_embedding.npy')
+        self.positional_embedding = torch.tensor(pe)
+        if not only_torch:
+            self.positional_embedding = self.positional_embedding.to('cuda').type(torch.float16).contiguous()
+
+        self.logit_filters = []
+        self.max_initial_timestamp_index = None
+        if self.options.suppress_blank:
+            self.logit_filters.append(SuppressBlank(self.tokenizer, self.sample_begin))
+        if self.options.suppress_tokens:
+            self.logit_filters.append(SuppressTokens(self._get_suppress_tokens()))
+        if not self.options.without_timestamps:
+            precision = CHUNK_LENGTH / self.decoder_config['num_audio_ctx']  # usually 0.02 seconds
+            if self.options.max_initial_timestamp:
+                self.max_initial_timestamp_index = round(self.options.max_initial_timestamp / precision)
+            self.logit_filters.append(
+                ApplyTimestampRules(self.tokenizer, self.sample_begin, self.max_initial_timestamp_index))
+        self.sequence_ranker = MaximumLikelihoodRanker(self.options.length_penalty)
+        self.decoder = GreedyDecoder(self.options.temperature, self.tokenizer.eot)
+
+        self.kv_cache = {}
+        self.hooks = []
+        self._cross_cache = None          # (key, list of cross K/V) from the last xa2cross_key_value
+        self._state = {}                  # per-batch-size device buffers of the fast path
+        self.poll_every = 8
+
+    # ---- configuration / sessions -----------------------------------------------------------------
+    def get_config(self, engine_dir):
+        for attr, fname in (('decoder_config', 'decoder_config.json'), ('cross_attn_config', 'cross_attn_config.json')):
+            with open(engine_dir / fname, 'r') as f:
+                config = json.load(f)
+            merged = OrderedDict()
+            merged.update(config['plugin_config'])
+            merged.update(config['builder_config'])
+            setattr(self, attr, merged)
+
+    def get_session(self, engine_dir):
+        path = engine_dir / get_engine_name('whisper_decoder', self.decoder_config['precision'],
+                                            self.decoder_config['tensor_parallel'], 0)
+        with open(path, 'rb') as f:
+            decoder_session = Session.from_serialized_engine(f.read())
+        path = engine_dir / get_engine_name('whsiper_crossattn', self.cross_attn_config['precision'],
+                                            self.cross_attn_config['tensor_parallel'], 0)
+        with open(path, 'rb') as f:
+            cross_attn_session = Session.from_serialized_engine(f.read())
+        return decoder_session, cross_attn_session
+
+    def _get_suppress_tokens(self) -> Tuple[int]:
+        suppress_tokens = self.options.suppress_tokens
+        if isinstance(suppress_tokens, str):
+            suppress_tokens = [int(t) for t in suppress_tokens.split(",")]
+        if -1 in suppress_tokens:
+            suppress_tokens = [t for t in suppress_tokens if t >= 0]
+            suppress_tokens.extend(self.tokenizer.non_speech_tokens)
+        elif suppress_tokens is None or len(suppress_tokens) == 0:
+            suppress_tokens = []
+        else:
+            assert isinstance(suppress_tokens, list), "suppress_tokens must be a list"
+        tk = self.tokenizer
+        suppress_tokens.extend([tk.transcribe, tk.translate, tk.sot, tk.sot_prev, tk.sot_lm])
+        if tk.no_speech is not None:
+            suppress_tokens.append(tk.no_speech)       # no-speech probability is collected separately
+        return tuple(sorted(set(suppress_tokens)))
+
+    def get_tokenizer(self, multilingual: bool, language: Optional[str] = None, task: Optional[str] = None) -> Tokenizer:
+        if self.vocab_path:
+            return Tokenizer.from_vocab(self.vocab_path, multilingual, language, task)
+        return Tokenizer.ids_only(multilingual, language, task)
+
+    def _get_initial_tokens(self) -> Tuple[int]:
+        tokens = list(self.sot_sequence)
+        if prefix := self.options.prefix:
+            prefix_tokens = self.tokenizer.encode(" " + prefix.strip()) if isinstance(prefix, str) else prefix
+            if self.sample_len is not None:
+                max_prefix_len = self.decoder_config['num_text_ctx'] // 2 - self.sample_len
+                prefix_tokens = prefix_tokens[-max_prefix_len:]
+            tokens = tokens + prefix_tokens
+        if prompt := self.options.prompt:
+            prompt_tokens = self.tokenizer.encode(" " + prompt.strip()) if isinstance(prompt, str) else prompt
+            tokens = [self.tokenizer.sot_prev] + prompt_tokens[-(self.decoder_config['num_text_ctx'] // 2 - 1):] + tokens
+        return tuple(tokens)
+
+    # ---- engine calls with the reference's by-name protocol ------------------------------------------
+    def xa2cross_key_value(self, xa):
+        key = (xa.data_ptr(), tuple(xa.shape), xa._version)
+        if self._cross_cache is not None and self._cross_cache[0] == key:
+            return self._cross_cache[1]
+        inputs = OrderedDict()
+        xa16 = xa.type(torch.float16).contiguous()
+        inputs.update({'xa': xa16})
+        output_info = self.cross_attn_session.infer_shapes([TensorInfo('xa', str_dtype_to_trt("float16"), xa16.shape)])
+        logger.debug(f'output info {output_info}')
+        outputs = {t.name: torch.empty(tuple(t.shape), dtype=trt_dtype_to_torch(t.dtype), device=xa.device)
+                   for t in output_info}
+        stream = torch.cuda.current_stream()
+        ok = self.cross_attn_session.run(inputs=inputs, outputs=outputs, stream=stream.cuda_stream)
+        assert ok, 'Engine execution failed'
+        stream.synchronize()
+        cross = [outputs['cross_present_key_value_' + str(i)] for i in range(self.cross_attn_config['num_layers'])]
+        self._cross_cache = (key, cross, xa)      # keep xa alive so the pointer key stays valid
+        return cross
+
+    def decode(self, x, cross_past_key_value, past_key_value=None):
+        """One decoder call with the reference's I/O protocol (W/decoding.py:543-659): returns
+        (logits fp16 [B, L, n_vocab], list of present_key_value [B,2,H,T+L,64])."""
+        dev = x.device
+        n_layer = self.decoder_config['num_layers']
+        kv_dtype = 'int8' if self.use_int8_kv_cache else 'float16'
+        inputs = OrderedDict()
+        infos = []
+
+        def add(name, tensor, dtype, shape=None):
+            inputs[name] = tensor
+            infos.append(TensorInfo(name, str_dtype_to_trt(dtype), tuple(shape if shape is not None else tensor.shape)))
+
+        x = x.type(torch.int32).contiguous()
+        input_len = x.shape[-1]
+        add('x', x, 'int32')
+        lens = torch.tensor((input_len,), dtype=torch.int32, device=dev)
+        add('input_lengths', lens, 'int32')
+        add('max_input_length', lens, 'int32')
+        if not self.decoder_config['gpt_attention_plugin']:
+            n_ctx = self.decoder_config['num_text_ctx']
+            mask = torch.full((n_ctx, n_ctx), -50000.0, dtype=torch.float32).triu_(1)[:input_len, :input_len].contiguous().to(dev)
+            add('mask', mask, 'float32')          # causality is applied inside the kernel; kept for I/O parity
+        else:
+            add('masked_tokens', torch.zeros((1, input_len), dtype=torch.int32, device=dev), 'int32')
+            add('cache_indirection', torch.zeros((x.shape[0], 1, input_len), dtype=torch.int32, device=dev), 'int32')
+            add('past_key_value_length', torch.tensor([0, 1], dtype=torch.int32, device=dev), 'int32')
+            add('sequence_length', lens, 'int32')
+        offset = past_key_value[0].shape[3] if past_key_value else 0
+        pos = self.positional_embedding[offset: offset + input_len].type(torch.float16).contiguous()
+        add('positional_embedding', pos, 'float16')
+        n_head = self.decoder_config['num_heads']
+        for i in range(n_layer):
+            if past_key_value is None:
+                dummy = torch.ones((1,), dtype=trt_dtype_to_torch(kv_dtype), device=dev)
+                add('past_key_value_' + str(i), dummy, kv_dtype, (x.shape[0], 2, n_head, 0, 64))
+            else:
+                add('past_key_value_' + str(i), past_key_value[i].contiguous(), kv_dtype)
+        for i in range(n_layer):
+            add('cross_past_key_value_' + str(i), cross_past_key_value[i].contiguous(), 'float16')
+
+        output_info = self.decoder_session.infer_shapes(infos)
+        assert output_info is not None, 'infer_shapes failed'
+        logger.debug(f'output info {output_info}')
+        outputs = {t.name: torch.empty(tuple(t.shape), dtype=trt_dtype_to_torch(t.dtype), device=dev) for t in output_info}
+        stream = torch.cuda.current_stream()
+        ok = self.decoder_session.run(inputs=inputs, outputs=outputs, stream=stream.cuda_stream)
+        assert ok, 'Engine execution failed'
+        stream.synchronize()
+        return outputs['output'], [outputs['present_key_value_' + str(i)] for i in range(n_layer)]
+
+    # ---- language detection ---------------------------------------------------------------------------
+    def _language_from_logits(self, logits, n_audio, single):
+        tk = self.tokenizer
+        mask = torch.ones(logits.shape[-1], dtype=torch.bool)
+        mask[list(tk.all_language_tokens)] = False
+        logits[:, mask] = -np.inf
+        language_tokens = logits.argmax(dim=-1)
+        probs = logits.softmax(dim=-1).cpu()
+        language_probs = [{c: probs[i, j].item() for j, c in zip(tk.all_language_tokens, tk.all_language_codes)}
+                          for i in range(n_audio)]
+        if single:
+            language_tokens, language_probs = language_tokens[0], language_probs[0]
+            languages = [max(language_probs, key=language_probs.get)]
+        else:
+            languages = [max(p, key=p.get) for p in language_probs]
+        return language_tokens, language_probs, languages
+
+    def detect_language(self, audio_features):
+        languages = [self.options.language] * audio_features.shape[0]
+        language_probs = None
+        if self.options.language is None or self.options.task == "lang_id":
+            single = audio_features.ndim == 2
+            if single:
+                audio_features = audio_features.unsqueeze(0)
+            n_audio = audio_features.shape[0]
+            x = torch.tensor([[self.tokenizer.sot]] * n_audio).to(audio_features.device)    # [n_audio, 1]
+            cross = self.xa2cross_key_value(audio_features)
+            logits, _ = self.decode(x, cross)
+            language_tokens, language_probs, languages = self._language_from_logits(logits[:, 0].float(), n_audio, single)
+            if self.options.language is None:
+                self.tokens = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
+                self.tokens[:, self.sot_index + 1] = language_tokens.cpu()        # write language tokens
+        return languages, language_probs
+
+    def torch_detect_language(self, model, audio_features):
+        """PyTorch path (W/decoding.py:661-701): `model.logits(tokens, audio_features)`."""
+        with torch.no_grad():
+            languages = [self.options.language] * audio_features.shape[0]
+            language_probs = None
+            if self.options.language is None or self.options.task == "lang_id":
+                single = audio_features.ndim == 2
+                if single:
+                    audio_features = audio_features.unsqueeze(0)
+                n_audio = audio_features.shape[0]
+                x = torch.tensor([[self.tokenizer.sot]] * n_audio).to(audio_features.device)
+                logits = model.logits(x, audio_features)[:, 0]
+                language_tokens, language_probs, languages = self._language_from_logits(logits, n_audio, single)
+                if self.options.language is None:
+                    self.tokens = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
+                    self.tokens[:, self.sot_index + 1] = language_tokens.cpu()
+        for hook in self.hooks:
+            hook.remove()
+        self.kv_cache, self.hooks = {}, []
+        return languages, language_probs
+
+    # ---- decoding loops ---------------------------------------------------------------------------------
+    def _initial_token_rows(self, n_audio, device):
+        tokens = self.tokens
+        if tokens.shape[0] != n_audio:
+            tokens = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
+        return tokens.repeat_interleave(self.n_group, dim=0).to(device)
+
+    def _host_step(self, i, logits, tokens, sum_logprobs, no_speech_probs):
+        if i == 0 and self.tokenizer.no_speech is not None:       # save no_speech_probs
+            probs_at_sot = logits[:, self.sot_index].float().softmax(dim=-1)
+            no_speech_probs[:] = probs_at_sot[:, self.tokenizer.no_speech].tolist()
+        logits = logits[:, -1]
+        for logit_filter in self.logit_filters:
+            logit_filter.apply(logits, tokens)
+        return self.decoder.update(tokens, logits, sum_logprobs)
+
+    def main_loop_reference(self, audio_features):
+        """The reference's loop verbatim in structure (W/decoding.py:785-821): one `decode()` per token,
+        host-side filters, concat KV."""
+        tokens = self._initial_token_rows(audio_features.shape[0], audio_features.device)
+        n_batch = tokens.shape[0]
+        sum_logprobs: Tensor = torch.zeros(n_batch, device=audio_features.device)
+        no_speech_probs = [np.nan] * n_batch
+        past_key_value = None
+        cross = self.xa2cross_key_value(audio_features)
+        for i in range(self.sample_len):
+            feed = tokens if tokens.shape[-1] <= self.initial_token_length else tokens[:, -1:]
+            logits, past_key_value = self.decode(feed, cross, past_key_value)
+            tokens, completed = self._host_step(i, logits, tokens, sum_logprobs, no_speech_probs)
+            if completed or tokens.shape[-1] > self.decoder_config['num_text_ctx']:
+                break
+        return tokens, sum_logprobs, no_speech_probs
+
+    def torch_main_loop(self, model, audio_features):
+        """PyTorch path (W/decoding.py:743-783): `model.decoder(tokens, xa, kv_cache=)` with hooks."""
+        with torch.no_grad():
+            tokens = self._initial_token_rows(audio_features.shape[0], audio_features.device)
+            n_batch = tokens.shape[0]
+            sum_logprobs: Tensor = torch.zeros(n_batch, device=audio_features.device)
+            no_speech_probs = [np.nan] * n_batch
+            for i in range(self.sample_len):
+                if not self.kv_cache:
+                    self.kv_cache, self.hooks = model.install_kv_cache_hooks()
+                feed = tokens if tokens.shape[-1] <= self.initial_token_length else tokens[:, -1:]
+                logits = model.decoder(feed, audio_features, kv_cache=self.kv_cache)
+                tokens, completed = self._host_step(i, logits, tokens, sum_logprobs, no_speech_probs)
+                if completed or tokens.shape[-1] > self.decoder_config['num_text_ctx']:
+                    break
+        for hook in self.hooks:
+            hook.remove()
+        self.kv_cache, self.hooks = {}, []
+        return tokens, sum_logprobs, no_speech_probs
+
+    # ---- fast path ----------------------------------------------------------------------------------------
+    def _fast_state(self, n_batch, device):
+        st = self._state.get(n_batch)
+        if st is not None:
+            return st
+        cfg = self.decoder_config
+        n_layer, n_head, cap, V = cfg['num_layers'], cfg['num_heads'], cfg['num_text_ctx'], cfg['vocab_size']
+        kv_dtype = torch.int8 if self.use_int8_kv_cache else torch.float16
+        tk = self.tokenizer
+        mask = torch.zeros(V, dtype=torch.uint8)
+        use_rules = not self.options.without_timestamps
+        for f in self.logit_filters:
+            if isinstance(f, SuppressTokens):
+                mask[f.suppress_tokens] = 1
+        if use_rules and tk.no_timestamps is not None:
+            mask[tk.no_timestamps] = 1
+        blank = list(tk.blank_tokens()) + [tk.eot] if self.options.suppress_blank else []
+        st = dict(
+            kv=[torch.zeros((n_batch, 2, n_head, cap, 64), dtype=kv_dtype, device=device) for _ in range(n_layer)],
+            tokens=torch.zeros((n_batch, cap + 1), dtype=torch.int32, device=device),
+            logits=torch.empty((n_batch, self.initial_token_length, V), dtype=torch.float16, device=device),
+            sum_logprobs=torch.zeros(n_batch, dtype=torch.float32, device=device),
+            n_done=torch.zeros(1, dtype=torch.int32, device=device),
+            mask=mask.to(device), blank=torch.tensor(blank or [0], dtype=torch.int32, device=device), n_blank=len(blank),
+        )
+        self._state[n_batch] = st
+        return st
+
+    def _greedy(self, st, logits, row_stride, cur_len, n_batch, stream):
+        tk = self.tokenizer
+        io = native.WmGreedyIO()
+        io.logits, io.row_stride = logits, row_stride
+        io.batch, io.n_vocab = n_batch, self.decoder_config['vocab_size']
+        io.tokens, io.tokens_ld, io.cur_len = st['tokens'].data_ptr(), st['tokens'].shape[1], cur_len
+        io.sum_logprobs = st['sum_logprobs'].data_ptr()
+        io.suppress_mask = st['mask'].data_ptr()
+        io.blank, io.n_blank = st['blank'].data_ptr(), st['n_blank']
+        io.sample_begin, io.eot, io.timestamp_begin = self.sample_begin, tk.eot, tk.timestamp_begin
+        io.max_initial_timestamp_index = -1 if self.max_initial_timestamp_index is None else self.max_initial_timestamp_index
+        io.apply_rules = 1          # main_loop routes without_timestamps to the reference loop
+        io.n_done = st['n_done'].data_ptr()
+        native.check(native.load_library().wm_greedy_step(C.byref(io), stream), "wm_greedy_step")
+
+    def main_loop(self, audio_features, ignore_eot: bool = False):
+        """Greedy decoding, fast path.  Same return values as the reference's main_loop
+        (tokens int64 [n, <=n_text_ctx+1], sum_logprobs fp32 [n], no_speech_probs list).
+        `ignore_eot` (benchmarks with random weights) decodes `sample_len` tokens regardless."""
+        if self.options.temperature != 0 or self.n_group != 1 or self.options.without_timestamps:
+            return self.main_loop_reference(audio_features)
+        dev = audio_features.device
+        tokens0 = self._initial_token_rows(audio_features.shape[0], dev)
+        n_batch, L0 = tokens0.shape
+        cfg = self.decoder_config
+        V, cap = cfg['vocab_size'], cfg['num_text_ctx']
+        cross = self.xa2cross_key_value(audio_features)
+        st = self._fast_state(n_batch, dev)
+        st['tokens'].zero_()
+        st['tokens'][:, :L0] = tokens0.to(torch.int32)
+        st['sum_logprobs'].zero_()
+        st['n_done'].zero_()
+        stream = torch.cuda.current_stream().cuda_stream
+        sess, kv, pos = self.decoder_session, st['kv'], self.positional_embedding
+        no_speech_probs = [np.nan] * n_batch
+        cur = L0
+        steps_done = 0
+        for i in range(self.sample_len):
+            if i == 0:
+                sess.decoder_step(st['tokens'][:, :L0], pos[0:L0], cross, None, cap, kv, cap, st['logits'], 0, stream)
+                if self.tokenizer.no_speech is not None:
+                    probs_at_sot = st['logits'][:, self.sot_index].float().softmax(dim=-1)
+                    nsp_dev = probs_at_sot[:, self.tokenizer.no_speech]
+                self._greedy(st, st['logits'].data_ptr() + (L0 - 1) * V * 2, L0 * V, cur, n_batch, stream)
+            else:
+                sess.decoder_step(st['tokens'][:, cur - 1:cur], pos[cur - 1:cur], cross, kv, cap, kv, cap, st['logits'],
+                                  cur - 1, stream)
+                self._greedy(st, st['logits'].data_ptr(), V, cur, n_batch, stream)
+            cur += 1
+            steps_done += 1
+            if cur > cap:
+                break
+            if not ignore_eot and (steps_done % self.poll_every == 0):
+                # rows keep emitting EOT once finished, so "all rows EOT in the newest column" is
+                # monotone; poll it now and then instead of synchronising every step
+                if bool((st['tokens'][:, cur - 1] == self.tokenizer.eot).all()):
+                    break
+        tokens = st['tokens'][:, :cur].to(torch.int64)
+        if not ignore_eot:
+            # cut at the first column where every row is EOT: where the per-step check would have stopped
+            all_eot = (tokens[:, L0:] == self.tokenizer.eot).all(dim=0)
+            if bool(all_eot.any()):
+                tokens = tokens[:, :L0 + int(all_eot.float().argmax()) + 1]
+        if self.tokenizer.no_speech is not None:
+            no_speech_probs = nsp_dev.tolist()
+        return tokens, st['sum_logprobs'].clone(), no_speech_probs
+
+    # ---- post-processing -------------------------------------------------------------------------------
+    def compression_ratio(self, text) -> float:
+        text_bytes = text.encode("utf-8")
+        return len(text_bytes) / len(zlib.compress(text_bytes))
+
+    def post_process(self, tokens, sum_logprobs, no_speech_probs, audio_features, languages):
+        """Slice, rank, detokenise (W/decoding.py:827-878); n_audio comes from the batch, not the config."""
+        audio_features = audio_features[:: self.n_group]
+        no_speech_probs = no_speech_probs[:: self.n_group]
+        n_audio = audio_features.shape[0]
+        assert n_audio == len(no_speech_probs)
+        tokens = tokens.reshape(n_audio, self.n_group, -1)
+        sum_logprobs = sum_logprobs.reshape(n_audio, self.n_group)
+        tokens, sum_logprobs = self.decoder.finalize(tokens, sum_logprobs)
+        eot = self.tokenizer.eot
+        tokens = [[t[self.sample_begin: (t == eot).nonzero()[0, 0]] for t in s] for s in tokens]
+        selected = self.sequence_ranker.rank(tokens, sum_logprobs)
+        tokens = [t[i].tolist() for i, t in zip(selected, tokens)]
+        texts = [self.tokenizer.decode(t).strip() for t in tokens]
+        sum_logprobs = [lp[i] for i, lp in zip(selected, sum_logprobs)]
+        avg_logprobs = [lp / (len(t) + 1) for t, lp in zip(tokens, sum_logprobs)]
+        fields = (texts, languages, tokens, audio_features, avg_logprobs, no_speech_probs)
+        if len(set(map(len, fields))) != 1:
+            raise RuntimeError(f"inconsistent result lengths: {list(map(len, fields))}")
+        return [
+            DecodingResult(audio_features=features, language=language, tokens=toks, text=text, avg_logprob=avg,
+                           no_speech_prob=nsp, temperature=self.options.temperature,
+                           compression_ratio=self.compression_ratio(text))
+            for text, language, toks, features, avg, nsp in zip(*fields)
+        ]

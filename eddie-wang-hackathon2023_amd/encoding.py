@@ -1,0 +1,77 @@
+"""WhisperEncoding: the encoder session wrapper.  Same class, constructor and methods as the
+reference's examples/whisper/encoding.py (W/encoding.py:12-76), over the gfx950 engine.
+
+`get_audio_features(mel)` takes fp16 `[B, n_mels, 2*n_audio_ctx]` on the GPU (the reference is
+hard-wired to `[1, 80, 3000]`; any batch works here) and returns fp16
+`[B, n_audio_ctx, n_audio_state]`.
+"""
+from __future__ import annotations
+
+import json
+from collections import OrderedDict
+
+import torch
+
+from build import get_engine_name
+from session import Session, TensorInfo, str_dtype_to_trt, trt_dtype_to_torch, logger
+
+
+class WhisperEncoding:
+    def __init__(self, engine_dir, only_torch: bool = False):
+        self.dtype = 'float16'
+        if not only_torch:
+            self.session = self.get_session(engine_dir)
+
+    def get_session(self, engine_dir):
+        config_path = engine_dir / 'encoder_config.json'
+        with open(config_path, 'r') as f:
+            config = json.load(f)
+        self.use_gpt_attention_plugin = config['plugin_config']['gpt_attention_plugin']
+        dtype = config['builder_config']['precision']
+        world_size = config['builder_config']['tensor_parallel']
+        self.num_heads = config['builder_config']['num_heads'] // world_size
+        self.hidden_size = config['builder_config']['hidden_size'] // world_size
+        self.num_layers = config['builder_config']['num_layers']
+        self.dtype = dtype
+        serialize_path = engine_dir / get_engine_name('whisper_encoder', self.dtype, world_size, 0)
+        with open(serialize_path, 'rb') as f:
+            session = Session.from_serialized_engine(f.read())
+        return session
+
+    def torch_get_audio_features(self, model, mel):
+        """The PyTorch path (W/encoding.py:43-46): `model` is any module with `.encoder(mel)`."""
+        with torch.no_grad():
+            audio_features = model.encoder(mel)
+        return audio_features
+
+    def get_audio_features(self, mel):
+        inputs = OrderedDict()
+        output_list = []
+        mel = mel.type(torch.float16).contiguous()
+        inputs.update({'x': mel})
+        output_list.append(TensorInfo('x', str_dtype_to_trt("float16"), mel.shape))
+        # the two length tensors are dummies in the reference too (W/encoding.py:55-61)
+        input_lengths = torch.ones((1,), dtype=torch.int32, device=mel.device)
+        inputs.update({'input_lengths': input_lengths})
+        output_list.append(TensorInfo('input_lengths', str_dtype_to_trt("int32"), input_lengths.shape))
+        inputs.update({'max_input_length': input_lengths})
+        output_list.append(TensorInfo('max_input_length', str_dtype_to_trt("int32"), input_lengths.shape))
+
+        output_info = self.session.infer_shapes(output_list)
+        logger.debug(f'output info {output_info}')
+        outputs = {t.name: torch.empty(tuple(t.shape), dtype=trt_dtype_to_torch(t.dtype), device=mel.device)
+                   for t in output_info}
+        stream = torch.cuda.current_stream()
+        ok = self.session.run(inputs=inputs, outputs=outputs, stream=stream.cuda_stream)
+        assert ok, 'Engine execution failed'
+        stream.synchronize()
+        return outputs['output']
+
+    def get_audio_features_async(self, mel, out=None):
+        """Fast path: no dictionaries, no synchronisation; enqueued on the current stream."""
+        mel = mel.type(torch.float16).contiguous()
+        d = self.session.dims
+        if out is None:
+            out = torch.empty((mel.shape[0], d['n_audio_ctx'], d['n_audio_state']), dtype=torch.float16, device=mel.device)
+        self.session.encoder_forward(mel, out, torch.cuda.current_stream().cuda_stream)
+        return out

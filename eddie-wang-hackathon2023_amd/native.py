@@ -1,0 +1,157 @@
+"""ctypes binding of libwhisper_mi355.so (include/whisper_mi355.h).
+
+The counterpart of the reference's plugin loader (R/tensorrt_llm/plugin/plugin.py:10-22:
+`ctypes.CDLL(libnvinfer_plugin_tensorrt_llm.so)` + `initLibNvInferPlugins`).  There is NO
+fallback: if the HIP library is missing or fails to load, importing the engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwhisper_mi355.so")
+
+EXPORTS = (
+    "wm_version", "wm_last_error", "wm_device_count", "wm_engine_create", "wm_engine_destroy",
+    "wm_engine_info", "wm_engine_weight_bytes", "wm_encoder_workspace_bytes", "wm_encoder_forward",
+    "wm_cross_kv_workspace_bytes", "wm_cross_kv", "wm_decoder_workspace_bytes", "wm_decoder_step",
+    "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
+    "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
+)
+
+
+class WmError(RuntimeError):
+    pass
+
+
+class WmDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
+
+    def to_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class WmDecoderIO(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("n_new", C.c_int32), ("n_past", C.c_int32),
+        ("tokens", C.c_void_p), ("tokens_ld", C.c_int32), ("positional_embedding", C.c_void_p),
+        ("past", C.POINTER(C.c_void_p)), ("past_capacity", C.c_int32),
+        ("present", C.POINTER(C.c_void_p)), ("present_capacity", C.c_int32),
+        ("cross", C.POINTER(C.c_void_p)),
+        ("logits", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("qkv_amax", C.c_void_p),
+    ]
+
+
+class WmGreedyIO(C.Structure):
+    _fields_ = [
+        ("logits", C.c_void_p), ("row_stride", C.c_int64),
+        ("batch", C.c_int32), ("n_vocab", C.c_int32),
+        ("tokens", C.c_void_p), ("tokens_ld", C.c_int32), ("cur_len", C.c_int32),
+        ("sum_logprobs", C.c_void_p),
+        ("suppress_mask", C.c_void_p),
+        ("blank", C.c_void_p), ("n_blank", C.c_int32),
+        ("sample_begin", C.c_int32), ("eot", C.c_int32), ("timestamp_begin", C.c_int32),
+        ("max_initial_timestamp_index", C.c_int32),
+        ("apply_rules", C.c_int32),
+        ("n_done", C.c_void_p),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """Load the HIP library, declare prototypes.  Raises WmError when it is absent: the product
+    path has no CPU or PyTorch fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise WmError(f"{path} not found: build it with `python __graft_entry__.py` "
+                      f"(hipcc --offload-arch=gfx950); there is no fallback path")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise WmError(f"{path} does not export {name}")
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.wm_version.restype = i32
+    lib.wm_last_error.restype = C.c_char_p
+    lib.wm_device_count.argtypes = [C.POINTER(i32)]
+    lib.wm_engine_create.argtypes = [vp, sz, i32, C.POINTER(vp)]
+    lib.wm_engine_destroy.argtypes = [vp]
+    lib.wm_engine_destroy.restype = None
+    lib.wm_engine_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(WmDims)]
+    lib.wm_engine_weight_bytes.argtypes = [vp]
+    lib.wm_engine_weight_bytes.restype = sz
+    lib.wm_encoder_workspace_bytes.argtypes = [vp, i32]
+    lib.wm_encoder_workspace_bytes.restype = sz
+    lib.wm_encoder_forward.argtypes = [vp, vp, i32, vp, vp, sz, vp]
+    lib.wm_cross_kv_workspace_bytes.argtypes = [vp, i32]
+    lib.wm_cross_kv_workspace_bytes.restype = sz
+    lib.wm_cross_kv.argtypes = [vp, vp, i32, C.POINTER(vp), vp, sz, vp]
+    lib.wm_decoder_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.wm_decoder_workspace_bytes.restype = sz
+    lib.wm_decoder_step.argtypes = [vp, C.POINTER(WmDecoderIO), vp]
+    lib.wm_greedy_step.argtypes = [C.POINTER(WmGreedyIO), vp]
+    lib.wm_gemm.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp]
+    lib.wm_gemm_skinny.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
+    lib.wm_gemm_skinny_default_ksplit.argtypes = [i32, i32, i32, i32]
+    lib.wm_layernorm.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp]
+    lib.wm_attn_encoder.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp]
+    lib.wm_attn_decode_cross.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp]
+    lib.wm_attn_decode_self.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, C.c_float, vp, vp]
+    lib.wm_quantize_i8.argtypes = [vp, vp, C.c_int64, C.c_float, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load_library().wm_last_error().decode(errors="replace")
+        raise WmError(f"{what or 'libwhisper_mi355'} failed (rc={rc}): {msg}")
+
+
+def ptr_array(tensors: Sequence) -> "C.Array":
+    """Device pointers of a list of torch tensors (or ints / None) as a void*[]."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else (t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+    return arr
+
+
+class Engine:
+    """Owns one wm_engine (device-resident weights of one *.engine file)."""
+
+    def __init__(self, blob: bytes, device: int = 0):
+        self.lib = load_library()
+        handle = C.c_void_p()
+        if not isinstance(blob, bytes):
+            blob = bytes(blob)
+        # c_char_p points at the bytes object's own buffer: no host copy of a multi-GB blob
+        check(self.lib.wm_engine_create(C.cast(C.c_char_p(blob), C.c_void_p), len(blob), device, C.byref(handle)),
+              "wm_engine_create")
+        self.handle = handle
+        kind, flags, dims = C.c_int32(), C.c_uint32(), WmDims()
+        check(self.lib.wm_engine_info(self.handle, C.byref(kind), C.byref(flags), C.byref(dims)))
+        self.kind, self.flags, self.dims, self.device = kind.value, flags.value, dims.to_dict(), device
+
+    @property
+    def weight_bytes(self) -> int:
+        return int(self.lib.wm_engine_weight_bytes(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.wm_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,211 @@
+"""`Session` / `TensorInfo`: the object the Whisper wrappers hold, re-implemented over the C ABI.
+
+Same surface as R/tensorrt_llm/runtime/session.py:27-31,53-61,116-178 (R = /root/reference/
+tensorrt_llm_july-release-v1): `Session.from_serialized_engine(bytes)`, `infer_shapes(List[
+TensorInfo]) -> List[TensorInfo] | None` (logs and returns None on an unknown name or a wrong
+dtype), `run(inputs, outputs, stream) -> bool` -- asynchronous enqueue on the caller's stream, the
+caller owns and pre-allocates every input and output tensor, and synchronises.
+
+Engine I/O by tensor name is the reference's (whisper/model.py:171-197,
+301-467,543-555), generalised from batch 1 / large-v2 to any batch and model size.  dtypes are
+spelled as strings ("float16", "int32", "int8", "float32"): `str_dtype_to_trt` is the identity
+here, there is no TensorRT enum to map to.
+
+Besides the by-name `run` there are typed fast-path methods (`encoder_forward`, `cross_kv`,
+`decoder_step`) that skip the dictionaries and allow in-place KV-cache append.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+import native
+from native import Engine, WmDecoderIO, check, ptr_array
+
+logger = logging.getLogger("whisper_mi355")
+
+ENGINE_ENCODER, ENGINE_DECODER, ENGINE_CROSS_KV = 0, 1, 2
+FLAG_WEIGHT_ONLY_INT8, FLAG_INT8_KV, FLAG_GELU_TANH = 1, 2, 4
+
+_STR_TO_TORCH = {"float16": torch.float16, "float32": torch.float32, "int32": torch.int32, "int8": torch.int8,
+                 "bfloat16": torch.bfloat16}
+
+
+def str_dtype_to_trt(dtype: str) -> str:
+    """Identity: engine dtypes are plain strings (reference: tensorrt_llm._utils.str_dtype_to_trt)."""
+    if dtype not in _STR_TO_TORCH:
+        raise ValueError(f"unsupported dtype {dtype}")
+    return dtype
+
+
+def str_dtype_to_torch(dtype: str) -> torch.dtype:
+    return _STR_TO_TORCH[dtype]
+
+
+def trt_dtype_to_torch(dtype: str) -> torch.dtype:
+    return _STR_TO_TORCH[dtype]
+
+
+@dataclass
+class TensorInfo:
+    name: str
+    dtype: str
+    shape: tuple
+
+
+class Session(object):
+    def __init__(self, **kwargs):
+        # use Session.from_serialized_engine to create a session
+        pass
+
+    def _init(self, engine_buffer, device: Optional[int] = None):
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self._engine = Engine(engine_buffer, device)
+        self._device = device
+        self._workspaces: Dict[tuple, torch.Tensor] = {}
+        self._shapes: Dict[str, tuple] = {}
+        return self
+
+    @staticmethod
+    def from_serialized_engine(engine, device: Optional[int] = None) -> "Session":
+        """Create a session from the bytes of one *.engine file (session.py:53-61)."""
+        return Session()._init(engine, device)
+
+    # -- properties ----------------------------------------------------------------------------
+    @property
+    def engine(self) -> Engine:
+        return self._engine
+
+    @property
+    def kind(self) -> int:
+        return self._engine.kind
+
+    @property
+    def dims(self) -> dict:
+        return self._engine.dims
+
+    @property
+    def kv_dtype(self) -> str:
+        return "int8" if self._engine.flags & FLAG_INT8_KV else "float16"
+
+    def _workspace(self, key: tuple, nbytes: int) -> torch.Tensor:
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=f"cuda:{self._device}")
+            self._workspaces[key] = ws
+        return ws
+
+    # -- by-name interface -----------------------------------------------------------------------
+    def _input_spec(self) -> Dict[str, Optional[str]]:
+        """name -> dtype of every input this engine accepts (None = any: ignored dummies)."""
+        d = self.dims
+        if self.kind == ENGINE_ENCODER:
+            return {"x": "float16", "input_lengths": "int32", "max_input_length": "int32"}
+        if self.kind == ENGINE_CROSS_KV:
+            return {"xa": "float16"}
+        spec = {"x": "int32", "input_lengths": "int32", "max_input_length": "int32",
+                "positional_embedding": "float16", "mask": "float32", "masked_tokens": "int32",
+                "cache_indirection": "int32", "past_key_value_length": "int32", "sequence_length": "int32"}
+        for i in range(d["n_text_layer"]):
+            spec[f"past_key_value_{i}"] = self.kv_dtype
+            spec[f"cross_past_key_value_{i}"] = "float16"
+        return spec
+
+    def infer_shapes(self, inputs: List[TensorInfo], context=None) -> Optional[List[TensorInfo]]:
+        """Record the input shapes and return the output TensorInfos (session.py:116-146)."""
+        spec = self._input_spec()
+        for i in inputs:
+            if i.name not in spec:
+                logger.error(f"Tensor:{i.name} is not an input tensor")
+                return None
+            if spec[i.name] is not None and spec[i.name] != i.dtype:
+                logger.error(f"Tensor:{i.name} has wrong dtype")
+                return None
+            self._shapes[i.name] = tuple(int(s) for s in i.shape)
+        d = self.dims
+        if self.kind == ENGINE_ENCODER:
+            b = self._shapes["x"][0]
+            return [TensorInfo("output", "float16", (b, d["n_audio_ctx"], d["n_audio_state"]))]
+        if self.kind == ENGINE_CROSS_KV:
+            b = self._shapes["xa"][0]
+            shape = (b, 2, d["n_text_head"], d["n_audio_ctx"], d["n_text_state"] // d["n_text_head"])
+            return [TensorInfo(f"cross_present_key_value_{i}", "float16", shape) for i in range(d["n_text_layer"])]
+        b, l = self._shapes["x"]
+        t = self._shapes.get("past_key_value_0", (b, 2, d["n_text_head"], 0, 64))[3]
+        outs = [TensorInfo("output", "float16", (b, l, d["n_vocab"]))]
+        outs += [TensorInfo(f"present_key_value_{i}", self.kv_dtype, (b, 2, d["n_text_head"], t + l, 64))
+                 for i in range(d["n_text_layer"])]
+        return outs
+
+    def run(self, inputs: Dict[str, Any], outputs: Dict[str, Any], stream, context=None) -> bool:
+        """Enqueue the engine on `stream` (session.py:148-178).  Returns False (and logs) on failure,
+        like execute_async_v3 would."""
+        try:
+            if self.kind == ENGINE_ENCODER:
+                mel = inputs["x"]
+                self.encoder_forward(mel, outputs["output"], stream)
+            elif self.kind == ENGINE_CROSS_KV:
+                n = self.dims["n_text_layer"]
+                self.cross_kv(inputs["xa"], [outputs[f"cross_present_key_value_{i}"] for i in range(n)], stream)
+            else:
+                n = self.dims["n_text_layer"]
+                x = inputs["x"]
+                b, l = x.shape
+                t = self._shapes.get("past_key_value_0", (0, 0, 0, 0, 0))[3]
+                past = [inputs[f"past_key_value_{i}"] for i in range(n)] if t > 0 else None
+                self.decoder_step(x, inputs["positional_embedding"],
+                                  [inputs[f"cross_past_key_value_{i}"] for i in range(n)],
+                                  past, t, [outputs[f"present_key_value_{i}"] for i in range(n)], t + l,
+                                  outputs["output"], t, stream)
+            return True
+        except (native.WmError, KeyError) as e:
+            logger.error(f"Engine execution failed: {e}")
+            return False
+
+    # -- typed fast path ---------------------------------------------------------------------------
+    def encoder_forward(self, mel: torch.Tensor, out: torch.Tensor, stream: int):
+        lib = self._engine.lib
+        b = mel.shape[0]
+        nbytes = lib.wm_encoder_workspace_bytes(self._engine.handle, b)
+        ws = self._workspace(("enc", b), nbytes)
+        check(lib.wm_encoder_forward(self._engine.handle, mel.data_ptr(), b, out.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), stream), "wm_encoder_forward")
+
+    def cross_kv(self, xa: torch.Tensor, outs: Sequence[torch.Tensor], stream: int):
+        lib = self._engine.lib
+        b = xa.shape[0]
+        ws = self._workspace(("ckv", b), lib.wm_cross_kv_workspace_bytes(self._engine.handle, b))
+        check(lib.wm_cross_kv(self._engine.handle, xa.data_ptr(), b, ptr_array(outs), ws.data_ptr(), ws.numel(),
+                              stream), "wm_cross_kv")
+
+    def decoder_step(self, tokens: torch.Tensor, pos: torch.Tensor, cross: Sequence[torch.Tensor],
+                     past: Optional[Sequence[torch.Tensor]], past_capacity: int,
+                     present: Sequence[torch.Tensor], present_capacity: int, logits: torch.Tensor,
+                     n_past: int, stream: int, qkv_amax: Optional[torch.Tensor] = None):
+        """tokens int32 [B, L] (any row stride: a column window of a wider buffer works);
+        past/present per layer [B,2,H,capacity,64]; present may be the same tensors as past
+        (in-place append)."""
+        lib = self._engine.lib
+        b, l = tokens.shape
+        assert tokens.dtype == torch.int32 and tokens.stride(1) == 1
+        ws = self._workspace(("dec", b, l), lib.wm_decoder_workspace_bytes(self._engine.handle, b, l))
+        io = WmDecoderIO()
+        io.batch, io.n_new, io.n_past = b, l, n_past
+        io.tokens, io.positional_embedding = tokens.data_ptr(), pos.data_ptr()
+        io.tokens_ld = tokens.stride(0) if b > 1 else l
+        past_arr = ptr_array(past) if past is not None else None
+        present_arr, cross_arr = ptr_array(present), ptr_array(cross)
+        io.past = C.cast(past_arr, C.POINTER(C.c_void_p)) if past_arr is not None else None
+        io.past_capacity = past_capacity
+        io.present = C.cast(present_arr, C.POINTER(C.c_void_p))
+        io.present_capacity = present_capacity
+        io.cross = C.cast(cross_arr, C.POINTER(C.c_void_p))
+        io.logits = logits.data_ptr()
+        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+        io.qkv_amax = qkv_amax.data_ptr() if qkv_amax is not None else None
+        check(lib.wm_decoder_step(self._engine.handle, C.byref(io), stream), "wm_decoder_step")

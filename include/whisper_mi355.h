@@ -1,0 +1,151 @@
+/* whisper_mi355.h -- C ABI of libwhisper_mi355.so, the MI355X (gfx950) Whisper engine.
+ *
+ * This library is the drop-in for what sits under the reference's `Session` object
+ * (R/tensorrt_llm/runtime/session.py:53-61,116-178; R = tensorrt_llm_july-release-v1): a
+ * deserialised TensorRT engine plus the plugin library loaded by
+ * `ctypes.CDLL(libnvinfer_plugin_tensorrt_llm.so); initLibNvInferPlugins(...)`
+ * (R/tensorrt_llm/plugin/plugin.py:10-22, R/cpp/tensorrt_llm/plugins/api/InferPlugin.cpp:147-170).
+ * TensorRT's IPluginV2DynamicExt vtable ABI is not reproducible without TensorRT, so the boundary
+ * sits one level up: the three engines of examples/whisper (encoder, cross-attention K/V,
+ * decoder; W/build.py:26-31) as three stateless entry points, with the same contract `Session.run`
+ * has: asynchronous enqueue on the caller's stream, the CALLER owns every buffer (inputs, outputs
+ * and workspace are raw device pointers), no hidden allocation, no hidden synchronisation.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; `wm_last_error()` then returns a
+ *     thread-local message.  Nothing throws, nothing aborts (the reference's plugins are
+ *     `noexcept` and report through caughtError, weightOnlyQuantMatmulPlugin.cpp:332-342).
+ *   - all device pointers must belong to the device the engine was created on.
+ *   - fp16 = IEEE binary16.  Tensors are dense row-major unless a leading dimension is given.
+ *   - re-entrant for distinct (engine, stream, workspace); one host thread per GPU in the
+ *     data-parallel design.  The only global state is the error string and WM_SYNC_CHECK.
+ */
+#ifndef WHISPER_MI355_H
+#define WHISPER_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wm_engine wm_engine;
+typedef void* wm_stream_t; /* hipStream_t */
+
+enum { WM_ENGINE_ENCODER = 0, WM_ENGINE_DECODER = 1, WM_ENGINE_CROSS_KV = 2 };
+enum { WM_FLAG_WEIGHT_ONLY_INT8 = 1, WM_FLAG_INT8_KV = 2, WM_FLAG_GELU_TANH = 4 };
+
+/* Same ten fields, same order, as the OpenAI checkpoint `dims` (W/build.py:146-154). */
+typedef struct wm_dims {
+    int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} wm_dims;
+
+int wm_version(void);
+const char* wm_last_error(void);
+int wm_device_count(int* out);
+
+/* ---- engines ------------------------------------------------------------------------------
+ * `blob` is the content of one *.engine file written by build.py (our packed-weight format, see
+ * DESIGN.md "engine blob").  Replaces Session.from_serialized_engine (session.py:53-61).
+ * The library copies the weights to `device` and keeps only that copy. */
+int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** out);
+void wm_engine_destroy(wm_engine* e);
+int wm_engine_info(const wm_engine* e, int32_t* kind, uint32_t* flags, wm_dims* dims);
+/* bytes of device memory holding this engine's weights */
+size_t wm_engine_weight_bytes(const wm_engine* e);
+
+/* ---- encoder engine: W/encoding.py:48-76 -> WhisperEncoder.forward (whisper/model.py:149-172) ---
+ * mel  : fp16 [batch, n_mels, 2*n_audio_ctx]    ("x")
+ * out  : fp16 [batch, n_audio_ctx, n_audio_state] ("output")                                      */
+size_t wm_encoder_workspace_bytes(const wm_engine* e, int batch);
+int wm_encoder_forward(const wm_engine* e, const void* mel, int batch, void* out,
+                       void* workspace, size_t workspace_bytes, wm_stream_t stream);
+
+/* ---- cross-attention K/V engine: W/decoding.py:515-541 -> CrossAttn_KV.forward (model.py:469-540)
+ * xa          : fp16 [batch, n_audio_ctx, n_text_state]
+ * out_layers  : n_text_layer device pointers, each fp16 [batch, 2, n_head, n_audio_ctx, 64]
+ *               ("cross_present_key_value_{i}", dim 1: 0 = K, 1 = V)                              */
+size_t wm_cross_kv_workspace_bytes(const wm_engine* e, int batch);
+int wm_cross_kv(const wm_engine* e, const void* xa, int batch, void* const* out_layers,
+                void* workspace, size_t workspace_bytes, wm_stream_t stream);
+
+/* ---- decoder engine: W/decoding.py:543-659 -> WhisperDecoder.forward (model.py:241-299) ---------
+ * One call = L new tokens for each of `batch` utterances on top of T cached tokens.               */
+typedef struct wm_decoder_io {
+    int32_t batch, n_new /* L: 1 for a decode step, len(sot_sequence) for the prefill */, n_past /* T */;
+    const int32_t* tokens;            /* int32 [batch, L]                               "x" */
+    int32_t tokens_ld;                /* elements between utterances in `tokens` (0 = L); lets a
+                                         step read column cur-1 of a [batch, capacity] buffer   */
+    const void* positional_embedding; /* fp16 [L, n_text_state], rows T..T+L of the table
+                                         (the caller slices: decoding.py:604-608)            */
+    /* self-attention KV cache, per layer [batch, 2, n_head, capacity, 64], int8 when the engine
+     * has WM_FLAG_INT8_KV, else fp16.  past[i] may be NULL when n_past == 0.
+     * present[i] == past[i] with equal capacities = in-place append (the fast path);
+     * otherwise the T cached rows are copied and the L new ones appended (the reference's
+     * concat semantics, attention.py:296-306, "present_key_value_{i}" of shape [.., T+L, 64]). */
+    const void* const* past;  int32_t past_capacity;
+    void* const* present;     int32_t present_capacity;
+    const void* const* cross; /* per layer fp16 [batch, 2, n_head, n_audio_ctx, 64]          */
+    void* logits;             /* fp16 [batch, L, n_vocab]                            "output" */
+    void* workspace; size_t workspace_bytes;
+    /* optional calibration hook (NULL in production): fp32 [n_text_layer], running
+     * max(|q|,|k|,|v|) of each layer's self-attention projections, the statistic the reference's
+     * int8-KV calibration collects with forward hooks (W/smoothquant.py:117-175,
+     * W/torch_whisper_convert.py:145-167).  The caller zeroes it before the first call. */
+    float* qkv_amax;
+} wm_decoder_io;
+size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new);
+int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream);
+
+/* ---- fused greedy step (device-side restatement of W/decoding.py:134-217,274-300) ----------------
+ * Applies SuppressBlank / SuppressTokens / ApplyTimestampRules to the last-position logits of each
+ * utterance, picks the arg-max, accumulates its log-probability, keeps finished rows at EOT and
+ * appends the token at tokens[b][cur_len].  n_done (device int32, caller zeroes it) counts rows
+ * whose new token is EOT.                                                                          */
+typedef struct wm_greedy_io {
+    const void* logits; int64_t row_stride; /* fp16; row b starts at logits + b*row_stride elements */
+    int32_t batch, n_vocab;
+    int32_t* tokens; int32_t tokens_ld; int32_t cur_len;
+    float* sum_logprobs;
+    const uint8_t* suppress_mask; /* [n_vocab], 1 = suppressed on every step */
+    const int32_t* blank; int32_t n_blank; /* suppressed on the first sampled step only */
+    int32_t sample_begin, eot, timestamp_begin, max_initial_timestamp_index /* -1: none */;
+    int32_t apply_rules; /* 0: plain arg-max */
+    int32_t* n_done;
+} wm_greedy_io;
+int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream);
+
+/* ---- kernel-level entry points (parity tests, micro-benchmarks, roofline measurement) -----------*/
+/* C[M,N] = act(A[M,K] x W[N,K]^T * scale + bias) (+ residual); W fp16 or int8 (w8) row-major [N][K].
+ * act: 0 none, 1 erf-GELU, 2 tanh-GELU.  Replaces CutlassFpAIntBGemmRunner::gemm /
+ * the TRT MatMul (fpA_intB_gemm_template.h:47-140).                                                */
+int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, const void* scale,
+            const void* bias, const void* residual, int ldr, int act, void* C, int ldc,
+            wm_stream_t stream);
+/* Weight-streaming GEMM, M <= 64, W in tile-linear layout (weight.py: tile_linear_*).  `part` must
+ * hold ksplit*M*n_blocks*16 floats; result[m][n] = sum_s part[s][m][n].  Replaces
+ * weight_only_gemv_launcher (weightOnlyMatrixVectorMultiplication.cu:371-378).                     */
+int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_blocks, int w8,
+                   const void* scale, int ksplit, float* part, wm_stream_t stream);
+int wm_gemm_skinny_default_ksplit(int M, int K, int n_blocks, int w8);
+/* fp16 LayerNorm rows, fp32 statistics, eps 1e-5 (layernormKernels.cu:62-188). */
+int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta,
+                 void* out, int ldo, wm_stream_t stream);
+/* qkv fp16 [B*T, 3*H*64] with q and k pre-multiplied by 64^-0.25; out fp16 [B*T, H*64]. */
+int wm_attn_encoder(const void* qkv, int ld, int B, int T, int H, void* out, int ldo, wm_stream_t stream);
+/* Decode cross-attention: q fp32 [B*L, H*64] (un-scaled, bias included), kv fp16 [B,2,H,Tk,64]. */
+int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void* kv, void* out,
+                         int nsplit, float* ws, wm_stream_t stream);
+/* Decode self-attention with append: qkv fp32 [B*L, 3*H*64] (bias included); cache [B,2,H,cap,64]. */
+int wm_attn_decode_self(const float* qkv, int B, int L, int T, int H, const void* past, int past_cap,
+                        void* present, int present_cap, int int8_kv, float kv_scale, void* out,
+                        wm_stream_t stream);
+/* q = sat_s8(rne(x * inv_scale)) (quantizeTensorPlugin / attention.py:340-348). */
+int wm_quantize_i8(const void* x, void* q, int64_t n, float inv_scale, wm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPER_MI355_H */

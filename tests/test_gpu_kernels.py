@@ -1,0 +1,295 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel, called through the C ABI, against a
+plain fp32 restatement of the same op (and the reference's own tolerances where it has a test).
+
+Tolerances (stated per test): outputs are fp16, so the floor is half an fp16 ulp of the output
+magnitude; the reference accepts atol 2e-3 for attention layers (R/tests/test_layer.py:764-768),
+5e-3 for the attention plugin incl. int8 KV (R/tests/attention/test_gpt_attention.py:684-693),
+2e-2 for fp16 LayerNorm (test_layer_norm.py:74-78), 1.5*colmax/128 per column for weight-only
+matmul (R/tests/quantization/_utils.py:66-88) and exact equality for int8 quantise
+(test_functional.py:46-50).  We hold the kernels to tighter bounds than those.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import native  # noqa: E402
+import weight as W  # noqa: E402
+from oracle import decoding_rules as DR  # noqa: E402
+from oracle.whisper_oracle import (OracleConfig, OracleModel, Dims, symmetric_quantize_int8, kv_quantize,
+                                   kv_dequantize, woq_reference_matmul, woq_colwise_atol)  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return native.load_library()
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rng(seed):
+    return np.random.Generator(np.random.Philox(seed))
+
+
+# ------------------------------------------------------------------------------------------ big GEMM
+@pytest.mark.parametrize("M,N,K,w8,act,resid", [
+    (200, 256, 192, 0, 0, False), (128, 128, 64, 0, 1, True), (300, 384, 256, 1, 0, False),
+    (77, 128, 128, 1, 1, True), (1500, 1280, 1280, 1, 0, True), (1500, 3840, 1280, 0, 0, False),
+])
+def test_gemm_big(lib, M, N, K, w8, act, resid):
+    r = rng(M + N + K)
+    A = (r.standard_normal((M, K)) * 0.5).astype(np.float16)
+    Wf = (r.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    bias = (r.standard_normal(N) * 0.1).astype(np.float16)
+    res = (r.standard_normal((M, N)) * 0.5).astype(np.float16) if resid else None
+    if w8:
+        q, s = symmetric_quantize_int8(Wf)
+        w_dev, s_dev = dev(q), dev(s)
+        ref = (A.astype(np.float32) @ q.astype(np.float32).T) * s.astype(np.float32)[None, :]
+    else:
+        w_dev, s_dev = dev(Wf), None
+        ref = A.astype(np.float32) @ Wf.astype(np.float32).T
+    ref = (ref + bias.astype(np.float32)).astype(np.float16).astype(np.float32)
+    if act == 1:
+        ref = torch.nn.functional.gelu(torch.from_numpy(ref)).half().float().numpy()
+    if resid:
+        ref = (ref + res.astype(np.float32)).astype(np.float16).astype(np.float32)
+    a_dev, b_dev = dev(A), dev(bias)
+    r_dev = dev(res) if resid else None
+    out = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+    native.check(lib.wm_gemm(a_dev.data_ptr(), K, M, K, w_dev.data_ptr(), N, w8,
+                             s_dev.data_ptr() if s_dev is not None else None, b_dev.data_ptr(),
+                             r_dev.data_ptr() if resid else None, N, act, out.data_ptr(), N, stream()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    # one fp16 ulp of the output magnitude (fp32 accumulation order is the only other difference)
+    tol = 2.0 ** -10 * max(1.0, np.abs(ref).max())
+    assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), tol)
+
+
+# --------------------------------------------------------------------------------------- skinny GEMM
+def _run_skinny(lib, A, Wmat, w8, ksplit):
+    M, K = A.shape
+    N = Wmat.shape[0]
+    if w8:
+        q, s = symmetric_quantize_int8(Wmat)
+        tiles = W.tile_linear(q)
+        npad = tiles.shape[0] * 16
+        s_pad = np.concatenate([s, np.zeros(npad - N, dtype=np.float16)])
+        s_dev = dev(s_pad)
+        ref = (A.astype(np.float32) @ q.astype(np.float32).T) * s.astype(np.float32)[None, :]
+    else:
+        tiles = W.tile_linear(Wmat)
+        npad = tiles.shape[0] * 16
+        s_dev = None
+        ref = A.astype(np.float32) @ Wmat.astype(np.float32).T
+    t_dev = dev(tiles.view(np.uint8) if not w8 else tiles.view(np.uint8))
+    a_dev = dev(A)
+    part = torch.full((ksplit, M, npad), float("nan"), dtype=torch.float32, device="cuda")
+    native.check(lib.wm_gemm_skinny(a_dev.data_ptr(), K, M, K, t_dev.data_ptr(), npad // 16, w8,
+                                    s_dev.data_ptr() if s_dev is not None else None, ksplit, part.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    got = part.sum(dim=0).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got[:, N:]).max(initial=0.0) == 0.0           # padded channels stay zero
+    return got[:, :N], ref
+
+
+@pytest.mark.parametrize("M,N,K,w8,ksplit", [
+    (1, 272, 320, 1, 1), (3, 272, 320, 1, 3), (17, 128, 1280, 1, 5), (64, 1280, 1280, 1, 4),
+    (1, 272, 320, 0, 1), (5, 200, 256, 0, 2), (33, 128, 1280, 0, 7), (64, 5120, 1280, 0, 3),
+    (48, 1280, 5120, 1, 10),
+])
+def test_gemm_skinny(lib, M, N, K, w8, ksplit):
+    r = rng(M * 7 + N + K + w8)
+    A = (r.standard_normal((M, K)) * 0.5).astype(np.float16)
+    Wf = (r.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    got, ref = _run_skinny(lib, A, Wf, w8, ksplit)
+    # fp32 accumulation on both sides: only the summation order differs
+    assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1024, 4096), (64, 1536, 4096)])
+def test_weight_only_matmul_reference_spec(lib, M, N, K):
+    """The reference's own known-answer test (test_weight_only_quant_matmul.py:94-119): uniform
+    weights, activations * 200, oracle = fp32 (x @ q) * scale -> fp16, tolerance 1.5*colmax/128."""
+    g = torch.Generator().manual_seed(0)
+    x = ((torch.rand((M, K), generator=g) * 2 - 1) * 200.0).half().numpy()
+    w = (torch.rand((K, N), generator=g) * 2 - 1).half().numpy()          # [K, N] like the reference
+    got, _ = _run_skinny(lib, x, np.ascontiguousarray(w.T), 1, lib.wm_gemm_skinny_default_ksplit(M, K, N // 16, 1))
+    q, s = symmetric_quantize_int8(np.ascontiguousarray(w.T))
+    ref = woq_reference_matmul(x, q.T, s).astype(np.float32)
+    atol = woq_colwise_atol(ref)
+    assert (np.abs(got.astype(np.float16).astype(np.float32) - ref) <= atol[None, :] + 1e-2).all()
+    # and far tighter than the reference's bound: we only differ by the fp16 store
+    assert np.abs(got - ref).max() <= 2.0 ** -10 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,N", [(4, 128), (7, 384), (33, 1280), (3, 5120)])
+def test_layernorm(lib, M, N):
+    r = rng(N)
+    x = (r.standard_normal((M, N)) * 3 + 1).astype(np.float16)
+    g = r.uniform(0.5, 1.5, N).astype(np.float16)
+    b = r.uniform(-0.5, 0.5, N).astype(np.float16)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x).float(), (N,), torch.from_numpy(g).float(),
+                                         torch.from_numpy(b).float(), 1e-5).numpy()
+    xd, gd, bd = dev(x), dev(g), dev(b)
+    out = torch.empty((M, N), dtype=torch.float16, device="cuda")
+    native.check(lib.wm_layernorm(xd.data_ptr(), N, M, N, gd.data_ptr(), bd.data_ptr(), out.data_ptr(), N, stream()))
+    torch.cuda.synchronize()
+    # reference accepts 2e-2 for fp16 (test_layer_norm.py:74-78); we are at one fp16 ulp
+    assert np.abs(out.float().cpu().numpy() - ref).max() <= 2.0 ** -10 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------ encoder attention
+@pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 150, 2), (1, 1500, 3), (3, 300, 2)])
+def test_attn_encoder(lib, B, T, H):
+    r = rng(T + H)
+    C_ = H * 64
+    q = (r.standard_normal((B, T, C_))).astype(np.float16)
+    k = (r.standard_normal((B, T, C_))).astype(np.float16)
+    v = (r.standard_normal((B, T, C_))).astype(np.float16)
+    m = OracleModel(Dims(80, T, C_, H, 0, 8, 4, C_, H, 0), {}, OracleConfig(act="float16"))
+    ref = m._attend(torch.from_numpy(q).float(), torch.from_numpy(k).float(), torch.from_numpy(v).float(), H).numpy()
+    scale = 64 ** -0.25
+    qs = (q.astype(np.float32) * scale).astype(np.float16)        # what the QKV GEMM epilogue hands over
+    ks = (k.astype(np.float32) * scale).astype(np.float16)
+    qkv = dev(np.concatenate([qs, ks, v], axis=2).reshape(B * T, 3 * C_))
+    out = torch.zeros((B * T, C_), dtype=torch.float16, device="cuda")
+    native.check(lib.wm_attn_encoder(qkv.data_ptr(), 3 * C_, B, T, H, out.data_ptr(), C_, stream()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy().reshape(B, T, C_)
+    # online softmax with fp16 probabilities vs the oracle's normalised fp16 probabilities:
+    # both carry 2^-11 relative rounding per probability -> 2e-3 absolute on O(1) outputs
+    assert np.abs(got - ref).max() <= 2e-3, np.abs(got - ref).max()
+
+
+# -------------------------------------------------------------------------------- decode cross-attention
+@pytest.mark.parametrize("B,L,H,Tk,nsplit", [(2, 1, 2, 100, 1), (2, 3, 2, 100, 1), (1, 1, 20, 1500, 1),
+                                             (3, 1, 2, 1500, 4), (2, 3, 3, 333, 3), (1, 2, 1, 8, 1)])
+def test_attn_decode_cross(lib, B, L, H, Tk, nsplit):
+    r = rng(B + L + H + Tk)
+    C_ = H * 64
+    q = r.standard_normal((B * L, C_)).astype(np.float16).astype(np.float32)
+    kv = r.standard_normal((B, 2, H, Tk, 64)).astype(np.float16)
+    m = OracleModel(Dims(80, Tk, C_, H, 0, 8, 4, C_, H, 0), {}, OracleConfig(act="float16"))
+    kk = torch.from_numpy(kv[:, 0]).float().permute(0, 2, 1, 3).reshape(B, Tk, C_)
+    vv = torch.from_numpy(kv[:, 1]).float().permute(0, 2, 1, 3).reshape(B, Tk, C_)
+    ref = m._attend(torch.from_numpy(q).reshape(B, L, C_), kk, vv, H).numpy().reshape(B * L, C_)
+    qd, kvd = dev(q), dev(kv)
+    out = torch.zeros((B * L, C_), dtype=torch.float16, device="cuda")
+    ws = torch.zeros(B * H * nsplit * L * 66, dtype=torch.float32, device="cuda")
+    native.check(lib.wm_attn_decode_cross(qd.data_ptr(), B, L, H, Tk, kvd.data_ptr(), out.data_ptr(), nsplit,
+                                          ws.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    tol = 1e-3 if nsplit == 1 else 2e-3        # single pass rounds exactly where the oracle does
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+
+
+# --------------------------------------------------------------------------------- decode self-attention
+@pytest.mark.parametrize("int8_kv", [0, 1])
+@pytest.mark.parametrize("B,L,T,H,inplace", [(2, 3, 0, 2, True), (2, 1, 5, 2, True), (1, 1, 130, 3, False),
+                                             (3, 1, 447, 2, True), (2, 3, 7, 1, False)])
+def test_attn_decode_self(lib, B, L, T, H, inplace, int8_kv):
+    r = rng(B + L + T + H + int8_kv)
+    C_ = H * 64
+    cap = 448 if inplace else T + L
+    t_scale = 0.031
+    qkv = r.standard_normal((B * L, 3 * C_)).astype(np.float16).astype(np.float32)
+    past_f = (r.standard_normal((B, 2, H, T, 64)) * 1.2).astype(np.float16)
+    m = OracleModel(Dims(80, 8, C_, H, 0, 8, 512, C_, H, 0), {}, OracleConfig(act="float16"))
+    qkv_t = torch.from_numpy(qkv).reshape(B, L, 3, H, 64)
+    new = qkv_t[:, :, 1:].permute(0, 2, 3, 1, 4)                       # [B, 2, H, L, 64]
+    if int8_kv:
+        past_q = kv_quantize(torch.from_numpy(past_f).float(), t_scale)
+        full = torch.cat([kv_dequantize(past_q, t_scale, "float16"), new], dim=3)
+        want_present = torch.cat([past_q, kv_quantize(new, t_scale)], dim=3)
+        past_store = past_q
+    else:
+        full = torch.cat([torch.from_numpy(past_f).float(), new], dim=3)
+        want_present = full.half()
+        past_store = torch.from_numpy(past_f)
+    mask = torch.zeros(L, T + L)
+    mask[:, T:] = torch.full((L, L), float("-inf")).triu_(1)
+    k_all = full[:, 0].permute(0, 2, 1, 3).reshape(B, T + L, C_)
+    v_all = full[:, 1].permute(0, 2, 1, 3).reshape(B, T + L, C_)
+    ref = m._attend(qkv_t[:, :, 0].reshape(B, L, C_), k_all, v_all, H, mask).numpy().reshape(B * L, C_)
+
+    dt = torch.int8 if int8_kv else torch.float16
+    present = torch.zeros((B, 2, H, cap, 64), dtype=dt, device="cuda")
+    if inplace:
+        present[:, :, :, :T] = past_store.cuda()
+        past, past_cap = present, cap
+    else:
+        past, past_cap = (past_store.cuda().contiguous() if T > 0 else None), T
+    out = torch.zeros((B * L, C_), dtype=torch.float16, device="cuda")
+    qd = dev(qkv)
+    native.check(lib.wm_attn_decode_self(qd.data_ptr(), B, L, T, H, past.data_ptr() if past is not None else None,
+                                         past_cap, present.data_ptr(), cap, int8_kv, t_scale, out.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    # reference accepts 5e-3 with int8 KV (test_gpt_attention.py:684-693)
+    assert np.abs(got - ref).max() <= 1.5e-3, np.abs(got - ref).max()
+    got_present = present[:, :, :, :T + L].cpu()
+    if int8_kv:
+        assert torch.equal(got_present, want_present)                  # integer work: bit-exact
+    else:
+        assert torch.equal(got_present, want_present)
+
+
+def test_quantize_i8_exact(lib):
+    x = torch.randn(100003, generator=torch.Generator().manual_seed(0)).half()
+    x[:6] = torch.tensor([0.5, 1.5, 2.5, -0.5, 1000.0, -1000.0]).half()
+    for inv in (1.0, 2.5, 1.0 / 0.4, 33.3):
+        q = torch.zeros(x.numel(), dtype=torch.int8, device="cuda")
+        xd = x.cuda()
+        native.check(lib.wm_quantize_i8(xd.data_ptr(), q.data_ptr(), x.numel(), inv, stream()))
+        torch.cuda.synchronize()
+        want = torch.clamp(torch.round(x.float() * float(np.float32(inv))), -128, 127).to(torch.int8)
+        assert torch.equal(q.cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------- greedy step
+def test_greedy_step_matches_reference_rules(lib, golden_dir):
+    fixr = np.load(os.path.join(golden_dir, "decoding_rules.npz"))
+    ids = DR.MULTILINGUAL
+    V = ids.n_vocab
+    mask = np.zeros(V, dtype=np.uint8)
+    mask[fixr["suppress"]] = 1
+    mask[ids.no_timestamps] = 1
+    mask_d, blank_d = dev(mask), dev(fixr["blank"].astype(np.int32))
+    for c, (toks, logits) in enumerate(DR.golden_rule_cases()):
+        cur = len(toks)
+        tok_buf = torch.zeros((1, 64), dtype=torch.int32, device="cuda")
+        tok_buf[0, :cur] = torch.from_numpy(toks).int().cuda()
+        lg = dev(logits.astype(np.float16))
+        s = torch.zeros(1, dtype=torch.float32, device="cuda")
+        n_done = torch.zeros(1, dtype=torch.int32, device="cuda")
+        io = native.WmGreedyIO()
+        io.logits, io.row_stride, io.batch, io.n_vocab = lg.data_ptr(), V, 1, V
+        io.tokens, io.tokens_ld, io.cur_len = tok_buf.data_ptr(), 64, cur
+        io.sum_logprobs, io.suppress_mask = s.data_ptr(), mask_d.data_ptr()
+        io.blank, io.n_blank = blank_d.data_ptr(), len(fixr["blank"])
+        io.sample_begin, io.eot, io.timestamp_begin = 3, ids.eot, ids.timestamp_begin
+        io.max_initial_timestamp_index, io.apply_rules, io.n_done = 50, 1, n_done.data_ptr()
+        native.check(lib.wm_greedy_step(C.byref(io), stream()))
+        torch.cuda.synchronize()
+        assert int(tok_buf[0, cur]) == int(fixr[f"c{c}_next"]), f"case {c}"
+        assert abs(float(s[0]) - float(fixr[f"c{c}_sumlp"])) < 2e-4, f"case {c}"
+        assert bool(int(n_done[0])) == bool(fixr[f"c{c}_done"]), f"case {c}"

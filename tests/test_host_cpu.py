@@ -1,0 +1,259 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every declared symbol,
+weight preparation (quantiser, tile layouts, blob), tokenizer, synthetic checkpoints, build.py
+artefacts, the host-side logit filters.  No kernel is launched here (no GPU in this container)."""
+import ctypes as C
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import build as B
+import native
+import synthetic
+import tokenizer as T
+import weight as W
+from oracle import decoding_rules as DR
+from oracle import whisper_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ----------------------------------------------------------------------------------------
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = native.load_library()
+    header = open(os.path.join(ROOT, "include", "whisper_mi355.h")).read()
+    declared = set(re.findall(r"\b(wm_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/whisper_mi355.h but not exported"
+    assert declared == set(native.EXPORTS)
+    assert lib.wm_version() == 1
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors vs the C compiler's view of include/whisper_mi355.h (plain C, gcc)."""
+    import subprocess
+    fields = {"wm_dims": [n for n, _ in native.WmDims._fields_],
+              "wm_decoder_io": [n for n, _ in native.WmDecoderIO._fields_],
+              "wm_greedy_io": [n for n, _ in native.WmGreedyIO._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "whisper_mi355.h"', 'int main(void){']
+    for s, fs in fields.items():
+        src.append(f'printf("{s} %zu\\n", sizeof({s}));')
+        src += [f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));' for f in fs]
+    src.append('return 0;}')
+    (tmp_path / "l.c").write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(tmp_path / "l.c"), "-o", str(tmp_path / "l")])
+    got = dict(line.split() for line in subprocess.check_output([str(tmp_path / "l")]).decode().splitlines())
+    for s, cls in (("wm_dims", native.WmDims), ("wm_decoder_io", native.WmDecoderIO), ("wm_greedy_io", native.WmGreedyIO)):
+        assert int(got[s]) == C.sizeof(cls), s
+        for f in fields[s]:
+            assert int(got[f"{s}.{f}"]) == getattr(cls, f).offset, f"{s}.{f}"
+
+
+def test_engine_create_fails_loudly_on_garbage():
+    with pytest.raises(native.WmError, match="bad magic|too small"):
+        native.Engine(b"not an engine" * 20, 0)
+
+
+def test_missing_library_is_an_error_not_a_fallback(tmp_path, monkeypatch):
+    monkeypatch.setattr(native, "_lib", None)
+    with pytest.raises(native.WmError, match="no fallback"):
+        native.load_library(str(tmp_path / "nope.so"))
+
+
+# ---- weights ----------------------------------------------------------------------------------------
+def test_quantizer_is_bit_identical_to_oracle():
+    rng = np.random.Generator(np.random.Philox(1))
+    w = (rng.standard_normal((96, 320)) * 0.07).astype(np.float16)
+    w[3] = 0
+    q0, s0 = O.symmetric_quantize_int8(w)
+    q1, s1 = W.symmetric_quantize(w)
+    assert np.array_equal(q0, q1) and np.array_equal(s0, s1)
+
+
+@pytest.mark.parametrize("dtype,kt,per", [(np.int8, 64, 16), (np.float16, 32, 8)])
+def test_tile_linear_layout(dtype, kt, per):
+    n, k = 40, 4 * kt                       # n not a multiple of 16: padded with zero channels
+    w = (np.arange(n * k).reshape(n, k) % 251 - 125).astype(dtype)
+    t = W.tile_linear(w)
+    assert t.shape == (3, 4, 64, per)
+    for (nb, tile, lane) in [(0, 0, 0), (1, 2, 37), (2, 3, 63), (2, 1, 8)]:
+        ch, g = nb * 16 + (lane & 15), lane >> 4
+        want = w[ch, tile * kt + g * per: tile * kt + (g + 1) * per] if ch < n else np.zeros(per, dtype)
+        assert np.array_equal(t[nb, tile, lane], want)
+    assert np.array_equal(W.untile_linear(t, n), w)
+
+
+def _parse_blob(blob):
+    hdr = struct.unpack_from("<8sIIII10iQQ", blob, 0)
+    assert hdr[0] == b"WM355ENG" and hdr[1] == 1
+    n, data_off = hdr[3], hdr[15]
+    out, off = {}, struct.calcsize("<8sIIII10iQQ")
+    for _ in range(n):
+        e = struct.unpack_from("<64sII4QQQ", blob, off)
+        off += struct.calcsize("<64sII4QQQ")
+        out[e[0].rstrip(b"\0").decode()] = dict(dtype=e[1], shape=e[3:3 + e[2]], offset=e[7], nbytes=e[8])
+    return dict(kind=hdr[2], flags=hdr[4], dims=hdr[5:15], data_off=data_off, tensors=out)
+
+
+def test_build_writes_reference_artefacts(tmp_path):
+    out = tmp_path / "eng"
+    qdir = tmp_path / "quantize" / "1-gpu"
+    os.makedirs(qdir)
+    for i in range(2):
+        np.array([0.01 * (i + 1)], dtype=np.float32).tofile(
+            qdir / f"model.decoder.blocks.{i}.attn.query_key_value.scale_y_quant_orig.bin")
+    args = B.parse_arguments(["--output_dir", str(out), "--use_gpt_attention_plugin", "--use_gemm_plugin",
+                              "--use_layernorm_plugin", "--int8_kv_cache", "--use_weight_only",
+                              "--quantize_dir", str(qdir), "--log_level", "error"])
+    B.build_from_checkpoint(synthetic.synthetic_checkpoint("micro", 0), args)
+    names = sorted(os.listdir(out))
+    assert names == sorted(["whisper_encoder_float16_tp1_rank0.engine", "whisper_decoder_float16_tp1_rank0.engine",
+                            "whsiper_crossattn_float16_tp1_rank0.engine", "encoder_config.json",
+                            "decoder_config.json", "cross_attn_config.json", "positional_embedding.npy"])
+    dec = json.load(open(out / "decoder_config.json"))
+    for k in ("precision", "tensor_parallel", "num_layers", "num_heads", "num_audio", "num_audio_ctx",
+              "num_text_ctx", "hidden_size", "vocab_size", "use_int8_kv_cache"):
+        assert k in dec["builder_config"], k
+    assert dec["builder_config"]["use_int8_kv_cache"] is True
+    assert dec["plugin_config"]["gpt_attention_plugin"] == "float16"
+    assert dec["plugin_config"]["weight_only_quant_matmul_plugin"] == "float16"
+    enc = json.load(open(out / "encoder_config.json"))
+    assert enc["builder_config"]["hidden_size"] == 128 and enc["builder_config"]["num_heads"] == 2
+    pe = np.load(out / "positional_embedding.npy")
+    assert pe.shape == (32, 128) and pe.dtype == np.float16
+    blob = open(out / "whisper_decoder_float16_tp1_rank0.engine", "rb").read()
+    p = _parse_blob(blob)
+    assert p["kind"] == W.ENGINE_DECODER and p["flags"] == (W.FLAG_WEIGHT_ONLY_INT8 | W.FLAG_INT8_KV)
+    assert p["dims"] == tuple(synthetic.DIMS["micro"].values())
+    t = p["tensors"]
+    assert t["blocks.0.qkv.t"]["dtype"] == 1 and tuple(t["blocks.0.qkv.t"]["shape"]) == (24, 2, 64, 16)
+    assert t["emb.t"]["dtype"] == 0 and tuple(t["emb.t"]["shape"]) == (64, 4, 64, 8)       # never quantised
+    off = p["data_off"] + t["blocks.1.kv_scale"]["offset"]
+    assert abs(struct.unpack_from("<f", blob, off)[0] - 0.02) < 1e-9
+    assert all(v["offset"] % 256 == 0 for v in t.values())
+    encp = _parse_blob(open(out / "whisper_encoder_float16_tp1_rank0.engine", "rb").read())
+    assert encp["tensors"]["conv1.w"]["dtype"] == 0 and tuple(encp["tensors"]["conv1.w"]["shape"]) == (128, 256)
+    assert encp["tensors"]["blocks.0.mlp1.w"]["dtype"] == 1
+    crs = _parse_blob(open(out / "whsiper_crossattn_float16_tp1_rank0.engine", "rb").read())
+    assert tuple(crs["tensors"]["blocks.1.kv.w"]["shape"]) == (256, 128)
+
+
+def test_int8_kv_build_needs_calibration_files(tmp_path):
+    args = B.parse_arguments(["--output_dir", str(tmp_path / "e"), "--int8_kv_cache", "--quantize_dir",
+                              str(tmp_path / "missing"), "--log_level", "error"])
+    with pytest.raises(FileNotFoundError):
+        B.build_from_checkpoint(synthetic.synthetic_checkpoint("micro", 0), args)
+
+
+def test_fused_weights_follow_reference_fusion():
+    ck = synthetic.synthetic_checkpoint("micro", 4)
+    sd = ck["model_state_dict"]
+    t = W.load_encoder_weight(ck["dims"], sd, 2)
+    qkv = t["blocks.0.qkv.w"]
+    assert np.array_equal(qkv[:128], sd["encoder.blocks.0.attn.query.weight"].numpy())
+    assert np.array_equal(qkv[128:256], sd["encoder.blocks.0.attn.key.weight"].numpy())
+    b = t["blocks.0.qkv.b"]
+    assert np.array_equal(b[:128], sd["encoder.blocks.0.attn.query.bias"].numpy()) and not b[128:256].any()
+    assert np.array_equal(b[256:], sd["encoder.blocks.0.attn.value.bias"].numpy())
+    # conv weights: K index = tap * C_in + c_in, conv1 padded to a multiple of 64
+    c1 = sd["encoder.conv1.weight"].numpy()
+    assert np.array_equal(t["conv1.w"][:, 80:160], c1[:, :, 1]) and not t["conv1.w"][:, 240:].any()
+    c = W.load_crossattn_linear_weight(sd, 2)
+    assert np.array_equal(c["blocks.1.kv.w"][128:], sd["decoder.blocks.1.cross_attn.value.weight"].numpy())
+    # the V bias is loaded (reference bug F3 is not reproduced)
+    assert np.array_equal(c["blocks.1.kv.b"][128:], sd["decoder.blocks.1.cross_attn.value.bias"].numpy())
+    assert not c["blocks.1.kv.b"][:128].any()
+
+
+# ---- synthetic / tokenizer ------------------------------------------------------------------------------
+def test_synthetic_checkpoint_equals_oracle_copy():
+    a = synthetic.synthetic_state_dict(synthetic.DIMS["micro"], 7)
+    b = O.synthetic_state_dict(O.MICRO, 7)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(synthetic.synthetic_mel(2, 128, 80, 9), O.synthetic_mel(2, 128, 80, 9))
+
+
+def test_tokenizer_ids_only_matches_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tokenizer.npz"))
+    tk = T.Tokenizer.ids_only(True, "en", "transcribe")
+    assert list(tk.non_speech_tokens) == g["multilingual_non_speech"].tolist()
+    assert list(tk.blank_tokens()) == g["multilingual_blank"].tolist()
+    assert list(tk.sot_sequence) == g["multilingual_sot_sequence"].tolist()
+    assert [tk.eot, tk.sot, tk.translate, tk.transcribe, tk.sot_lm, tk.sot_prev, tk.no_speech, tk.no_timestamps,
+            tk.timestamp_begin, tk.n_vocab] == g["multilingual_specials"].tolist()
+    en = T.Tokenizer.ids_only(False)
+    assert list(en.non_speech_tokens) == g["gpt2_non_speech"].tolist()
+    assert en.sot_sequence == (50257,) and en.n_vocab == 51864
+    assert len(tk.all_language_tokens) == 99 and tk.all_language_tokens[0] == 50259
+    assert tk.decode_with_timestamps([50258, 50259, 50359, 50364]) == "<|startoftranscript|><|en|><|transcribe|><|0.00|>"
+    with pytest.raises(RuntimeError):
+        tk.encode("hello")
+
+
+def test_bpe_on_a_toy_vocabulary(tmp_path):
+    """Vocabulary mode without the real vocabulary file (it does not travel): 256 byte tokens plus a
+    few merges, tiktoken file format."""
+    import base64
+    toks = [bytes([i]) for i in range(256)] + [b"he", b"ll", b"hell", b"hello", b" w", b" wo"]
+    path = tmp_path / "toy.tiktoken"
+    with open(path, "w") as f:
+        for r, t in enumerate(toks):
+            f.write(f"{base64.b64encode(t).decode()} {r}\n")
+    tk = T.Tokenizer.from_vocab(str(path), multilingual=True)
+    ids = tk.encode("hello world")
+    assert ids[0] == 259 and ids[1] == 261 and tk.decode(ids) == "hello world"
+    assert tk.eot == 262 and tk.timestamp_begin == 262 + 107
+
+
+# ---- host-side logit filters vs the reference-generated golden ----------------------------------------------
+def test_host_filters_match_reference_golden(golden_dir):
+    import decoding as D
+    fixr = np.load(os.path.join(golden_dir, "decoding_rules.npz"))
+    tk = T.Tokenizer.ids_only(True, "en", "transcribe")
+    filters = [D.SuppressBlank(tk, 3), D.SuppressTokens(fixr["suppress"].tolist()), D.ApplyTimestampRules(tk, 3, 50)]
+    greedy = D.GreedyDecoder(0.0, tk.eot)
+    cases = DR.golden_rule_cases()
+    # batched: every history length separately (rows of one batch share cur_len)
+    for c, (toks, logits) in enumerate(cases):
+        lt = torch.from_numpy(logits.copy())[None]
+        tt = torch.from_numpy(toks)[None]
+        for f in filters:
+            f.apply(lt, tt)
+        isinf = np.unpackbits(fixr[f"c{c}_filtered_isinf"])[:lt.shape[1]].astype(bool)
+        assert np.array_equal(torch.isinf(lt[0]).numpy(), isinf), c
+        s = torch.zeros(1)
+        new_tokens, done = greedy.update(tt, lt, s)
+        assert int(new_tokens[0, -1]) == int(fixr[f"c{c}_next"]), c
+        assert abs(float(s[0]) - float(fixr[f"c{c}_sumlp"])) < 1e-4
+        assert done == bool(fixr[f"c{c}_done"])
+    # a real batch: three rows with the same length but different histories
+    same_len = [i for i, (t, _) in enumerate(cases) if len(t) == 6][:3]
+    lt = torch.from_numpy(np.stack([cases[i][1] for i in same_len]))
+    tt = torch.from_numpy(np.stack([cases[i][0] for i in same_len]))
+    for f in filters:
+        f.apply(lt, tt)
+    for r, i in enumerate(same_len):
+        isinf = np.unpackbits(fixr[f"c{i}_filtered_isinf"])[:lt.shape[1]].astype(bool)
+        assert np.array_equal(torch.isinf(lt[r]).numpy(), isinf)
+
+
+def test_decoding_wrapper_host_only(tmp_path):
+    """only_torch=True constructs the wrapper without a GPU, like the reference's calibration path."""
+    import decoding as D
+    args = B.parse_arguments(["--output_dir", str(tmp_path / "e"), "--log_level", "error"])
+    B.build_from_checkpoint(synthetic.synthetic_checkpoint("micro-fullvocab", 0), args)
+    dec = D.WhisperDecoding(tmp_path / "e", only_torch=True)
+    assert dec.sample_len == 224 and dec.sample_begin == 3 and dec.n_group == 1
+    assert dec.initial_tokens == (50258, 50259, 50359)
+    sup = dec._get_suppress_tokens()
+    assert 50362 in sup and 50358 in sup and 220 not in sup and len(sup) == 82 + 6
+    assert dec.max_initial_timestamp_index == round(1.0 / (30 / 64))     # precision = 30 s / n_audio_ctx (decoding.py:343-348)
+    assert not dec.use_int8_kv_cache
