@@ -142,7 +142,8 @@ def build_encoder(model, args):
 def build_decoder(model, args):
     md, params = model['dims'], model['model_state_dict']
     positional_embedding = params['decoder.positional_embedding']
-    positional_embedding = positional_embedding.numpy() if hasattr(positional_embedding, 'numpy') else positional_embedding
+    if hasattr(positional_embedding, 'numpy'):
+        positional_embedding = positional_embedding.detach().cpu().numpy()
     np.save(os.path.join(args.output_dir, 'positional_embedding.npy'), positional_embedding)
     builder_config = OrderedDict(
         name=MODEL_DECODER_NAME, precision=args.dtype, tensor_parallel=1, num_layers=md['n_text_layer'],

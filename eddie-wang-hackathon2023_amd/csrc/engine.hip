@@ -377,6 +377,23 @@ int wm_cross_kv(const wm_engine* e, const void* xa, int B, void* const* out_laye
 
 // ================================================================================================ decoder
 namespace {
+// ---- in-situ kernel timing for the roofline report (bench.py): HIP event pairs around sampled
+// launches of the decode cross-attention kernel, on the stream it is launched on ------------------
+struct Profiler {
+    bool enabled = false; int layer_stride = 1;
+    std::vector<hipEvent_t> start, stop; size_t used = 0;
+} g_prof;
+
+int prof_begin(int layer, hipStream_t s) {
+    if (!g_prof.enabled || layer % g_prof.layer_stride != 0 || g_prof.used >= g_prof.start.size()) return -1;
+    const int slot = (int)g_prof.used++;
+    (void)hipEventRecord(g_prof.start[slot], s);
+    return slot;
+}
+void prof_end(int slot, hipStream_t s) {
+    if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], s);
+}
+
 struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total; };
 
 int cross_nsplit(int B, int H) {
@@ -489,7 +506,9 @@ int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t str
             WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
             p.kv = (const h16*)io->cross[i]; p.kv_bstride = (long)2 * H * d.n_audio_ctx * 64;
             p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
+            const int slot = prof_begin(i, s);
             if (launch_attn_cross(p, s)) return 2;
+            prof_end(slot, s);
         }
         if (skinny_all(Lr.cout, w.ctx, C, M, w.part, &ks, s)) return 2;
         if (finish(Lr.cout, ks, 0, Lr.ln2g, Lr.ln2b, w.xn, C, C)) return 2;
@@ -508,6 +527,36 @@ int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t str
         p.out = (h16*)io->logits + (size_t)r0 * d.n_vocab; p.ldc = d.n_vocab; p.n_valid = d.n_vocab;
         if (launch_gemm_skinny(p, s)) return 2;
     }
+    return 0;
+}
+
+// ================================================================================================ profiling
+int wm_profile_configure(int enabled, int layer_stride, int max_samples) {
+    WM_REQUIRE(layer_stride >= 1 && max_samples >= 0, "wm_profile_configure: bad arguments");
+    g_prof.enabled = false;
+    for (size_t i = 0; i < g_prof.start.size(); ++i) { (void)hipEventDestroy(g_prof.start[i]); (void)hipEventDestroy(g_prof.stop[i]); }
+    g_prof.start.clear(); g_prof.stop.clear(); g_prof.used = 0; g_prof.layer_stride = layer_stride;
+    if (!enabled) return 0;
+    g_prof.start.resize(max_samples); g_prof.stop.resize(max_samples);
+    for (int i = 0; i < max_samples; ++i) {
+        WM_CHECK_HIP(hipEventCreate(&g_prof.start[i]));
+        WM_CHECK_HIP(hipEventCreate(&g_prof.stop[i]));
+    }
+    g_prof.enabled = true;
+    return 0;
+}
+
+int wm_profile_read(double* total_ms, int64_t* count, int reset) {
+    WM_REQUIRE(total_ms && count, "wm_profile_read: null argument");
+    double sum = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        WM_CHECK_HIP(hipEventSynchronize(g_prof.stop[i]));
+        WM_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]));
+        sum += ms;
+    }
+    *total_ms = sum; *count = (int64_t)g_prof.used;
+    if (reset) g_prof.used = 0;
     return 0;
 }
 

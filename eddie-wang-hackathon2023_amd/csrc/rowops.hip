@@ -13,7 +13,6 @@
 namespace wm {
 
 constexpr int ROW_THREADS = 256;
-constexpr int MAX_PER_THREAD = 24;     // rows up to 256 * 24 = 6144 columns (MLP hidden 5120)
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -27,80 +26,78 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+constexpr int ROW_MAX_N = 6144;        // MLP hidden of large-v2 is 5120
+
+__device__ __forceinline__ float4 ld_h4(const h16* p) {
+    const half4v v = *(const half4v*)p;
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st_h4(h16* p, float4 v) {
+    half4v o = {(h16)v.x, (h16)v.y, (h16)v.z, (h16)v.w};
+    *(half4v*)p = o;
+}
+
+// One workgroup per row; the row lives in LDS as fp32 between the passes (no per-thread arrays:
+// a runtime-indexed register array would be demoted to scratch).  4 elements per thread per trip,
+// 16-byte loads of the fp32 slabs, 8-byte loads/stores of fp16 data.
 __global__ __launch_bounds__(ROW_THREADS) void row_finish_kernel(RowFinishParams p) {
     __shared__ float red[ROW_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) float row[ROW_MAX_N];
     const int m = blockIdx.x, tid = threadIdx.x;
-    float v[MAX_PER_THREAD];
-    const int per = (p.N + ROW_THREADS - 1) / ROW_THREADS;
     const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.M * p.ldp;
-    // ---- gather: y = sum_s part + bias, fp16; then residual / gelu ----------------------------
-#pragma unroll
-    for (int i = 0; i < MAX_PER_THREAD; ++i) {
-        if (i >= per) break;
-        const int n = tid + i * ROW_THREADS;
-        float x = 0.f;
-        if (n < p.N) {
-            if (p.mode != 2) {
-                float y = 0.f;
-                for (int s = 0; s < p.ksplit; ++s) y += p.part[(size_t)s * sstride + (size_t)m * p.ldp + n];
-                if (p.bias) y += (float)p.bias[n];
-                y = r16(y);
-                if (p.mode == 1) {
-                    x = r16(p.gelu_kind == 2 ? gelu_tanh(y) : gelu_erf(y));
-                } else {
-                    x = r16((float)p.x[(size_t)m * p.ldx + n] + y);
-                }
-            } else {
-                x = (float)p.x[(size_t)m * p.ldx + n];
+    const int n4 = p.N >> 2;
+    float sum = 0.f;
+    for (int c = tid; c < n4; c += ROW_THREADS) {
+        const int n = c * 4;
+        float4 x;
+        if (p.mode != 2) {
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* src = p.part + (size_t)m * p.ldp + n;
+            for (int s = 0; s < p.ksplit; ++s) {
+                const float4 t = *(const float4*)(src + (size_t)s * sstride);
+                y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
             }
+            if (p.bias) { const float4 bb = ld_h4(p.bias + n); y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w; }
+            y.x = r16(y.x); y.y = r16(y.y); y.z = r16(y.z); y.w = r16(y.w);        // the Linear's fp16 output
+            if (p.mode == 1) {
+                if (p.gelu_kind == 2) x = make_float4(gelu_tanh(y.x), gelu_tanh(y.y), gelu_tanh(y.z), gelu_tanh(y.w));
+                else x = make_float4(gelu_erf(y.x), gelu_erf(y.y), gelu_erf(y.z), gelu_erf(y.w));
+                st_h4(p.out + (size_t)m * p.ldo + n, x);
+                continue;
+            }
+            const float4 xr = ld_h4(p.x + (size_t)m * p.ldx + n);
+            x = make_float4(r16(xr.x + y.x), r16(xr.y + y.y), r16(xr.z + y.z), r16(xr.w + y.w));
+            st_h4(p.x + (size_t)m * p.ldx + n, x);                                  // residual stream, in place
+        } else {
+            x = ld_h4(p.x + (size_t)m * p.ldx + n);
         }
-        v[i] = x;
+        *(float4*)&row[n] = x;
+        sum += (x.x + x.y) + (x.z + x.w);
     }
-    if (p.mode == 1) {
-#pragma unroll
-        for (int i = 0; i < MAX_PER_THREAD; ++i) {
-            if (i >= per) break;
-            const int n = tid + i * ROW_THREADS;
-            if (n < p.N) p.out[(size_t)m * p.ldo + n] = (h16)v[i];
-        }
-        return;
-    }
-    if (p.mode == 0 || p.mode == 3) {
-#pragma unroll
-        for (int i = 0; i < MAX_PER_THREAD; ++i) {
-            if (i >= per) break;
-            const int n = tid + i * ROW_THREADS;
-            if (n < p.N) p.x[(size_t)m * p.ldx + n] = (h16)v[i];
-        }
-        if (p.mode == 3) return;
-    }
-    // ---- LayerNorm -------------------------------------------------------------------------
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAX_PER_THREAD; ++i) {
-        if (i >= per) break;
-        if (tid + i * ROW_THREADS < p.N) s += v[i];
-    }
-    const float mean = block_sum(s, red) / (float)p.N;
+    if (p.mode == 1 || p.mode == 3) return;
+    // ---- LayerNorm: two-pass statistics in fp32 (torch_model.py:25-27) --------------------------
+    const float mean = block_sum(sum, red) / (float)p.N;
     float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAX_PER_THREAD; ++i) {
-        if (i >= per) break;
-        if (tid + i * ROW_THREADS < p.N) { const float d = v[i] - mean; q += d * d; }
+    for (int c = tid; c < n4; c += ROW_THREADS) {           // each thread re-reads what it wrote
+        const float4 x = *(const float4*)&row[c * 4];
+        const float a = x.x - mean, b = x.y - mean, cc = x.z - mean, d = x.w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
     }
     const float rstd = rsqrtf(block_sum(q, red) / (float)p.N + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < MAX_PER_THREAD; ++i) {
-        if (i >= per) break;
-        const int n = tid + i * ROW_THREADS;
-        if (n < p.N)
-            p.out[(size_t)m * p.ldo + n] = (h16)((v[i] - mean) * rstd * (float)p.ln_g[n] + (float)p.ln_b[n]);
+    for (int c = tid; c < n4; c += ROW_THREADS) {
+        const int n = c * 4;
+        const float4 x = *(const float4*)&row[n];
+        const float4 g = ld_h4(p.ln_g + n), bt = ld_h4(p.ln_b + n);
+        st_h4(p.out + (size_t)m * p.ldo + n,
+              make_float4((x.x - mean) * rstd * g.x + bt.x, (x.y - mean) * rstd * g.y + bt.y,
+                          (x.z - mean) * rstd * g.z + bt.z, (x.w - mean) * rstd * g.w + bt.w));
     }
 }
 
 int launch_row_finish(const RowFinishParams& p, hipStream_t stream) {
-    WM_REQUIRE(p.N <= ROW_THREADS * MAX_PER_THREAD, "row_finish: N=%d too wide", p.N);
+    WM_REQUIRE(p.N <= ROW_MAX_N && p.N % 4 == 0, "row_finish: N=%d must be a multiple of 4, <= %d", p.N, ROW_MAX_N);
     WM_REQUIRE(p.M > 0, "row_finish: empty M");
+    WM_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0 && p.ldp % 4 == 0, "row_finish: leading dimensions must be multiples of 4");
     hipLaunchKernelGGL(row_finish_kernel, dim3(p.M), dim3(ROW_THREADS), 0, stream, p);
     WM_LAUNCH_CHECK(stream, "row_finish");
     return 0;

@@ -69,6 +69,7 @@ class Session(object):
         self._device = device
         self._workspaces: Dict[tuple, torch.Tensor] = {}
         self._shapes: Dict[str, tuple] = {}
+        self.qkv_amax: Optional[torch.Tensor] = None
         return self
 
     @staticmethod
@@ -207,5 +208,7 @@ class Session(object):
         io.cross = C.cast(cross_arr, C.POINTER(C.c_void_p))
         io.logits = logits.data_ptr()
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+        if qkv_amax is None:
+            qkv_amax = self.qkv_amax          # calibration hook set by torch_whisper_convert.py
         io.qkv_amax = qkv_amax.data_ptr() if qkv_amax is not None else None
         check(lib.wm_decoder_step(self._engine.handle, C.byref(io), stream), "wm_decoder_step")

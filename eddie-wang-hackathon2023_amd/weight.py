@@ -33,6 +33,7 @@ from collections import OrderedDict
 from typing import Dict, Optional, Tuple
 
 import numpy as np
+import torch
 
 ENGINE_ENCODER, ENGINE_DECODER, ENGINE_CROSS_KV = 0, 1, 2
 FLAG_WEIGHT_ONLY_INT8, FLAG_INT8_KV, FLAG_GELU_TANH = 1, 2, 4
@@ -49,42 +50,58 @@ def _np(t) -> np.ndarray:
     return np.asarray(t)
 
 
+def _prep_device() -> torch.device:
+    """Weight preparation (quantise, tile) runs as torch ops: on the GPU when there is one (large-v2 is
+    1.5e9 weights; seconds instead of minutes), else multi-threaded on the host.  Same arithmetic
+    either way: IEEE fp32 divide, floor, compare -- tests/test_gpu_kernels.py checks bit equality."""
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def _t(x, device=None) -> torch.Tensor:
+    if not torch.is_tensor(x):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    return x.detach().to(device or _prep_device())
+
+
 def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.ndarray:
     """Encoder positional table, recomputed like W/weight.py:24-30,50 and stored fp16."""
     assert channels % 2 == 0
     inc = np.log(max_timescale) / (channels // 2 - 1)
-    inv = np.exp(-inc * np.arange(channels // 2, dtype=np.float32)).astype(np.float32)
-    t = np.arange(length, dtype=np.float32)[:, None] * inv[None, :]
-    return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float16)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    t = torch.arange(length)[:, None] * inv[None, :]
+    return torch.cat([torch.sin(t), torch.cos(t)], dim=1).half().numpy()
 
 
 # ---------------------------------------------------------------------------------------------
 # weight-only int8
 # ---------------------------------------------------------------------------------------------
 
-def symmetric_quantize(w_out_in: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+def _symmetric_quantize_t(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    w = w.float()
+    absmax = w.abs().amax(dim=1)
+    scale = absmax * (1.0 / 128.0)
+    safe = torch.where(scale > 0, scale, torch.ones_like(scale))
+    r = w / safe[:, None]
+    q = torch.trunc(r + torch.copysign(torch.full_like(r, 0.5), r))     # C round(): half away from zero
+    q = q.clamp_(-128, 127).to(torch.int8)
+    q[scale == 0] = 0
+    return q, scale.half()
+
+
+def symmetric_quantize(w_out_in) -> Tuple[np.ndarray, np.ndarray]:
     """Per-output-channel symmetric int8 (cutlass_preprocessors.cpp:641-686):
     scale = absmax / 128 in fp32, q = clip(round_half_away(w / scale), -128, 127), stored scale =
     fp16(scale).  Input [out, in] (the reference quantises the transposed [in, out] matrix per
-    column, which is the same thing).  Returns (int8 [out, in], fp16 [out])."""
-    w = np.asarray(w_out_in, dtype=np.float32)
-    absmax = np.abs(w).max(axis=1)
-    scale = (absmax * np.float32(1.0 / 128.0)).astype(np.float32)
-    safe = np.where(scale > 0, scale, np.float32(1.0))
-    r = w / safe[:, None]
-    q = np.sign(r) * np.floor(np.abs(r) + np.float32(0.5))
-    q = np.clip(q, -128, 127).astype(np.int8)
-    q[scale == 0] = 0
-    return q, scale.astype(np.float16)
+    column, which is the same thing).  Returns (int8 [out, in], fp16 [out]) as numpy arrays."""
+    q, s = _symmetric_quantize_t(_t(w_out_in))
+    return q.cpu().numpy(), s.cpu().numpy()
 
 
-def tile_linear(w: np.ndarray) -> np.ndarray:
-    """[N, K] int8 or fp16 -> tile-linear [N/16, K/KT, 64, 16 bytes] (N padded to 16 with zeros)."""
-    w = np.ascontiguousarray(w)
+def _tile_linear_t(w: torch.Tensor) -> torch.Tensor:
     n, k = w.shape
-    if w.dtype == np.int8:
+    if w.dtype == torch.int8:
         kt, per = 64, 16
-    elif w.dtype == np.float16:
+    elif w.dtype == torch.float16:
         kt, per = 32, 8
     else:
         raise TypeError(f"tile_linear: unsupported dtype {w.dtype}")
@@ -92,10 +109,15 @@ def tile_linear(w: np.ndarray) -> np.ndarray:
         raise ValueError(f"tile_linear: K={k} must be a multiple of {kt}")
     npad = (n + 15) // 16 * 16
     if npad != n:
-        w = np.concatenate([w, np.zeros((npad - n, k), dtype=w.dtype)], axis=0)
-    t = w.reshape(npad // 16, 16, k // kt, 4, per)         # (nb, n, kt, g, j)
-    t = t.transpose(0, 2, 3, 1, 4)                         # (nb, kt, g, n, j): lane = g * 16 + n
-    return np.ascontiguousarray(t).reshape(npad // 16, k // kt, 64, per)
+        w = torch.cat([w, torch.zeros((npad - n, k), dtype=w.dtype, device=w.device)], dim=0)
+    t = w.reshape(npad // 16, 16, k // kt, 4, per)          # (nb, n, kt, g, j)
+    t = t.permute(0, 2, 3, 1, 4)                            # (nb, kt, g, n, j): lane = g * 16 + n
+    return t.contiguous().reshape(npad // 16, k // kt, 64, per)
+
+
+def tile_linear(w) -> np.ndarray:
+    """[N, K] int8 or fp16 -> tile-linear [N/16, K/KT, 64, 16 bytes] (N padded to 16 with zeros)."""
+    return _tile_linear_t(_t(w)).cpu().numpy()
 
 
 def untile_linear(t: np.ndarray, n: int) -> np.ndarray:
@@ -109,20 +131,20 @@ def untile_linear(t: np.ndarray, n: int) -> np.ndarray:
 # tensor collections per engine
 # ---------------------------------------------------------------------------------------------
 
-def _linear(out: Dict[str, np.ndarray], name: str, w: np.ndarray, b: Optional[np.ndarray],
-            use_weight_only: bool, tiled: bool):
+def _linear(out: Dict[str, np.ndarray], name: str, w, b, use_weight_only: bool, tiled: bool):
     """Add one Linear: weight `[out, in]` fp16, optional bias."""
-    w = _np(w).astype(np.float16)
+    w = _t(w).half()
     n = w.shape[0]
     if use_weight_only:
-        q, s = symmetric_quantize(w)
+        q, s = _symmetric_quantize_t(w)
         if tiled:
             npad = (n + 15) // 16 * 16
-            s = np.concatenate([s, np.zeros(npad - n, dtype=np.float16)])
-        out[name + (".t" if tiled else ".w")] = tile_linear(q) if tiled else q
-        out[name + ".s"] = s
+            s = torch.cat([s, torch.zeros(npad - n, dtype=torch.float16, device=s.device)])
+            q = _tile_linear_t(q)
+        out[name + (".t" if tiled else ".w")] = q.cpu().numpy()
+        out[name + ".s"] = s.cpu().numpy()
     else:
-        out[name + (".t" if tiled else ".w")] = tile_linear(w) if tiled else w
+        out[name + (".t" if tiled else ".w")] = (_tile_linear_t(w) if tiled else w).cpu().numpy()
     if b is not None:
         out[name + ".b"] = _np(b).astype(np.float16)
 
@@ -134,8 +156,8 @@ def _ln(out, name, params, key):
 
 def _qkv(params, prefix):
     """Fused qkv weight [3C, C] and bias [q, 0, v] (W/weight.py:64-95,196-215)."""
-    w = np.concatenate([_np(params[prefix + ".query.weight"]), _np(params[prefix + ".key.weight"]),
-                        _np(params[prefix + ".value.weight"])], axis=0)
+    w = torch.cat([_t(params[prefix + ".query.weight"]), _t(params[prefix + ".key.weight"]),
+                   _t(params[prefix + ".value.weight"])], dim=0)
     qb = _np(params[prefix + ".query.bias"])
     b = np.concatenate([qb, np.zeros_like(qb), _np(params[prefix + ".value.bias"])], axis=0)
     return w, b
@@ -187,7 +209,7 @@ def load_decoder_weight(model_params: dict, n_layer: int, quantize_dir: Optional
     embedding is stored once (fp16 tile-linear) and serves both the gather and the logits GEMM
     (the reference stores it twice: whisper/model.py:212,231)."""
     t: "OrderedDict[str, np.ndarray]" = OrderedDict()
-    t["emb.t"] = tile_linear(_np(model_params["decoder.token_embedding.weight"]).astype(np.float16))
+    t["emb.t"] = _tile_linear_t(_t(model_params["decoder.token_embedding.weight"]).half()).cpu().numpy()
     for i in range(n_layer):
         p, o = f"decoder.blocks.{i}", f"blocks.{i}"
         _ln(t, o + ".attn_ln", model_params, p + ".attn_ln")
@@ -215,9 +237,9 @@ def load_crossattn_linear_weight(model_params: dict, n_layer: int, use_weight_on
     t: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for i in range(n_layer):
         p = f"decoder.blocks.{i}.cross_attn"
-        wk, wv = _np(model_params[p + ".key.weight"]), _np(model_params[p + ".value.weight"])
+        wk, wv = _t(model_params[p + ".key.weight"]), _t(model_params[p + ".value.weight"])
         vb = _np(model_params[p + ".value.bias"])
-        _linear(t, f"blocks.{i}.kv", np.concatenate([wk, wv], axis=0),
+        _linear(t, f"blocks.{i}.kv", torch.cat([wk, wv], dim=0),
                 np.concatenate([np.zeros_like(vb), vb], axis=0), use_weight_only, False)
     return t
 

@@ -145,6 +145,14 @@ int wm_attn_decode_self(const float* qkv, int B, int L, int T, int H, const void
 /* q = sat_s8(rne(x * inv_scale)) (quantizeTensorPlugin / attention.py:340-348). */
 int wm_quantize_i8(const void* x, void* q, int64_t n, float inv_scale, wm_stream_t stream);
 
+/* ---- in-situ timing of the dominant decode kernel (cross-attention), for the roofline report ------
+ * When enabled, wm_decoder_step brackets the cross-attention launch of every `layer_stride`-th layer
+ * with a HIP event pair on the launch stream, up to `max_samples` pairs.  wm_profile_read waits for
+ * the recorded events and returns the summed duration and the number of samples.  Process-global,
+ * off by default, not thread-safe (one host thread per GPU).                                        */
+int wm_profile_configure(int enabled, int layer_stride, int max_samples);
+int wm_profile_read(double* total_ms, int64_t* count, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,8 +90,9 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> tor
 
 def synthetic_state_dict(dims: Dims, seed: int = 0, gain: float = 2.0, logit_std: float = 1.5,
                          ln_jitter: float = 0.1) -> Dict[str, torch.Tensor]:
-    """OpenAI-checkpoint-shaped state dict with fp16 tensors, from a numpy Philox stream
-    (bit-stable across numpy/torch versions and across the CPU and GPU boxes).
+    """OpenAI-checkpoint-shaped state dict with fp16 tensors.  Tensor number i (in creation order)
+    is drawn from its own numpy PCG64 stream seeded with [seed, i]: bit-stable across boxes and
+    independent of how many threads the product-side generator uses.
 
     Key set = the keys W/weight.py reads (SURVEY.md section 8b "Checkpoint keys consumed").
     Linear weights are N(0, (gain / sqrt(fan_in))^2) so that every block contributes O(1) to the
@@ -101,42 +102,51 @@ def synthetic_state_dict(dims: Dims, seed: int = 0, gain: float = 2.0, logit_std
     model's.  LayerNorm gains are 1 + U(-j, j) and biases U(-j, j) so that a kernel that drops
     gamma or beta cannot pass; Linear biases are N(0, 0.1^2).
     """
-    rng = np.random.Generator(np.random.Philox(seed))
     sd: Dict[str, torch.Tensor] = {}
+    counter = [0]
 
-    def normal(*shape, s=None):
+    def stream():
+        rng = np.random.Generator(np.random.PCG64([seed, counter[0]]))
+        counter[0] += 1
+        return rng
+
+    def normal(name, *shape, s=None):
         if s is None:      # weight [out, in]: fan-in scaling; bias [out]: 0.1
             s = gain / math.sqrt(shape[-1]) if len(shape) == 2 else 0.1
-        return torch.from_numpy((rng.standard_normal(shape) * s).astype(np.float16))
+        x = stream().standard_normal(shape, dtype=np.float32) * np.float32(s)
+        sd[name] = torch.from_numpy(x.astype(np.float16))
+
+    def uniform(name, n, centre):
+        x = stream().random((n,), dtype=np.float32) * np.float32(2 * ln_jitter) + np.float32(centre - ln_jitter)
+        sd[name] = torch.from_numpy(x.astype(np.float16))
 
     def ln(prefix, n):
-        sd[prefix + ".weight"] = torch.from_numpy(
-            (1.0 + rng.uniform(-ln_jitter, ln_jitter, n)).astype(np.float16))
-        sd[prefix + ".bias"] = torch.from_numpy(
-            rng.uniform(-ln_jitter, ln_jitter, n).astype(np.float16))
+        uniform(prefix + ".weight", n, 1.0)
+        uniform(prefix + ".bias", n, 0.0)
 
     def attn(prefix, n):
-        sd[prefix + ".query.weight"] = normal(n, n)
-        sd[prefix + ".query.bias"] = normal(n)
-        sd[prefix + ".key.weight"] = normal(n, n)
-        sd[prefix + ".value.weight"] = normal(n, n)
-        sd[prefix + ".value.bias"] = normal(n)
-        sd[prefix + ".out.weight"] = normal(n, n)
-        sd[prefix + ".out.bias"] = normal(n)
+        normal(prefix + ".query.weight", n, n)
+        normal(prefix + ".query.bias", n)
+        normal(prefix + ".key.weight", n, n)
+        normal(prefix + ".value.weight", n, n)
+        normal(prefix + ".value.bias", n)
+        normal(prefix + ".out.weight", n, n)
+        normal(prefix + ".out.bias", n)
 
     def mlp(prefix, n):
-        sd[prefix + ".0.weight"] = normal(4 * n, n)
-        sd[prefix + ".0.bias"] = normal(4 * n)
-        sd[prefix + ".2.weight"] = normal(n, 4 * n)
-        sd[prefix + ".2.bias"] = normal(n)
+        normal(prefix + ".0.weight", 4 * n, n)
+        normal(prefix + ".0.bias", 4 * n)
+        normal(prefix + ".2.weight", n, 4 * n)
+        normal(prefix + ".2.bias", n)
 
     na, nt = dims.n_audio_state, dims.n_text_state
     # conv weights scaled so that activations entering the blocks are O(1)
-    sd["encoder.conv1.weight"] = normal(na, dims.n_mels, 3, s=1.0 / math.sqrt(3 * dims.n_mels))
-    sd["encoder.conv1.bias"] = normal(na)
-    sd["encoder.conv2.weight"] = normal(na, na, 3, s=1.0 / math.sqrt(3 * na))
-    sd["encoder.conv2.bias"] = normal(na)
+    normal("encoder.conv1.weight", na, dims.n_mels, 3, s=1.0 / math.sqrt(3 * dims.n_mels))
+    normal("encoder.conv1.bias", na)
+    normal("encoder.conv2.weight", na, na, 3, s=1.0 / math.sqrt(3 * na))
+    normal("encoder.conv2.bias", na)
     sd["encoder.positional_embedding"] = sinusoids(dims.n_audio_ctx, na).half()
+    counter[0] += 1
     for i in range(dims.n_audio_layer):
         p = f"encoder.blocks.{i}"
         ln(p + ".attn_ln", na)
@@ -145,8 +155,8 @@ def synthetic_state_dict(dims: Dims, seed: int = 0, gain: float = 2.0, logit_std
         mlp(p + ".mlp", na)
     ln("encoder.ln_post", na)
 
-    sd["decoder.token_embedding.weight"] = normal(dims.n_vocab, nt, s=logit_std / math.sqrt(nt))
-    sd["decoder.positional_embedding"] = normal(dims.n_text_ctx, nt, s=logit_std / math.sqrt(nt))
+    normal("decoder.token_embedding.weight", dims.n_vocab, nt, s=logit_std / math.sqrt(nt))
+    normal("decoder.positional_embedding", dims.n_text_ctx, nt, s=logit_std / math.sqrt(nt))
     for i in range(dims.n_text_layer):
         p = f"decoder.blocks.{i}"
         ln(p + ".attn_ln", nt)
@@ -167,8 +177,8 @@ def synthetic_checkpoint(dims: Dims, seed: int = 0) -> dict:
 def synthetic_mel(batch: int, n_frames: int = 3000, n_mels: int = 80, seed: int = 1234) -> torch.Tensor:
     """Synthetic log-mel: N(0, 0.5) clipped to [-0.5, 1.5], the width-2 range the reference's
     normalisation produces (W/whisper_utils.py:143-145).  fp16, [B, n_mels, n_frames]."""
-    rng = np.random.Generator(np.random.Philox(seed))
-    x = np.clip(rng.standard_normal((batch, n_mels, n_frames)) * 0.5, -0.5, 1.5)
+    rng = np.random.Generator(np.random.PCG64([seed, batch]))
+    x = np.clip(rng.standard_normal((batch, n_mels, n_frames), dtype=np.float32) * np.float32(0.5), -0.5, 1.5)
     return torch.from_numpy(x.astype(np.float16))
 
 
