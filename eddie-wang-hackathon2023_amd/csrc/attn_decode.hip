@@ -38,7 +38,7 @@ template <bool I8>
 __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     constexpr int MAXT = 512;
     __shared__ float s_p[MAXT];
-    __shared__ h16 s_q[64], s_knew[MAX_L][64], s_vnew[MAX_L][64];
+    __shared__ h16 s_qall[MAX_L][64], s_knew[MAX_L][64], s_vnew[MAX_L][64];
 
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int C = p.H * 64;
@@ -51,9 +51,21 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     for (int i = 0; i < p.L; ++i) {
         const int m = b * p.L + i;
         float q = 0.f, k = 0.f, v = 0.f;
-        for (int s = 0; s < p.ksplit; ++s) {
-            const float* row = p.part + (size_t)s * sstride + (size_t)m * p.ldp + h * 64 + lane;
-            q += row[0]; k += row[C]; v += row[2 * C];
+        {
+            const float* row = p.part + (size_t)m * p.ldp + h * 64 + lane;
+            int s = 0;
+            for (; s + 4 <= p.ksplit; s += 4) {        // 12 independent loads in flight (L2-latency bound)
+                const float* r0 = row + (size_t)s * sstride;
+                const float* r1 = r0 + sstride; const float* r2 = r1 + sstride; const float* r3 = r2 + sstride;
+                const float q0 = r0[0], q1 = r1[0], q2 = r2[0], q3 = r3[0];
+                const float k0 = r0[C], k1 = r1[C], k2 = r2[C], k3 = r3[C];
+                const float v0 = r0[2 * C], v1 = r1[2 * C], v2 = r2[2 * C], v3 = r3[2 * C];
+                q += (q0 + q1) + (q2 + q3); k += (k0 + k1) + (k2 + k3); v += (v0 + v1) + (v2 + v3);
+            }
+            for (; s < p.ksplit; ++s) {
+                const float* r0 = row + (size_t)s * sstride;
+                q += r0[0]; k += r0[C]; v += r0[2 * C];
+            }
         }
         q = r16(q + (p.bias ? (float)p.bias[h * 64 + lane] : 0.f));
         k = r16(k + (p.bias ? (float)p.bias[C + h * 64 + lane] : 0.f));
@@ -75,8 +87,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
             ((h16*)p.present)[off_v] = (h16)v;
         }
         // stash q rows in registers via LDS later; keep q of token i in s_q when processed
-        if (i == 0) s_q[lane] = (h16)r16(q * ATTN_SCALE);
-        // queries beyond the first are recomputed below (L is tiny: 1 or 3)
+        s_qall[i][lane] = (h16)r16(q * ATTN_SCALE);
     }
     // copy-forward: when present is a different buffer than past (the reference's concat
     // semantics, attention.py:296-306), move the T cached rows of this head
@@ -96,15 +107,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     const unsigned char* pastV = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(1 * p.H + h) * p.past_cap * 64) * (I8 ? 1 : 2);
 
     for (int i = 0; i < p.L; ++i) {
-        if (i > 0) {    // recompute q of token i (cheap) into s_q
-            const int m = b * p.L + i;
-            float q = 0.f;
-            for (int s = 0; s < p.ksplit; ++s) q += p.part[(size_t)s * sstride + (size_t)m * p.ldp + h * 64 + lane];
-            q = r16(q + (p.bias ? (float)p.bias[h * 64 + lane] : 0.f));
-            __syncthreads();
-            s_q[lane] = (h16)r16(q * ATTN_SCALE);
-            __syncthreads();
-        }
+        const h16* s_q = s_qall[i];
         const int nk = p.T + i + 1;                 // causal: past + new tokens 0..i
         // ---- scores: lane-per-key -------------------------------------------------------------
         float mx = -INFINITY;
@@ -164,9 +167,25 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
         float o = 0.f;
         int j = 0;
         if (I8) {
-            for (; j < p.T; ++j) o += s_p[j] * r16((float)((const int8_t*)pastV)[(size_t)j * 64 + lane] * t_dq);
+            const int8_t* pv = (const int8_t*)pastV + lane;
+            for (; j + 8 <= p.T; j += 8) {          // 8 loads in flight per lane
+                int8_t vq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vq[u] = pv[(size_t)(j + u) * 64];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o += s_p[j + u] * r16((float)vq[u] * t_dq);
+            }
+            for (; j < p.T; ++j) o += s_p[j] * r16((float)pv[(size_t)j * 64] * t_dq);
         } else {
-            for (; j < p.T; ++j) o += s_p[j] * (float)((const h16*)pastV)[(size_t)j * 64 + lane];
+            const h16* pv = (const h16*)pastV + lane;
+            for (; j + 8 <= p.T; j += 8) {
+                h16 vh[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vh[u] = pv[(size_t)(j + u) * 64];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o += s_p[j + u] * (float)vh[u];
+            }
+            for (; j < p.T; ++j) o += s_p[j] * (float)pv[(size_t)j * 64];
         }
         for (; j < nk; ++j) o += s_p[j] * (float)s_vnew[j - p.T][lane];
         p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)o;
@@ -223,12 +242,25 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const int m = b * L + i;
+        const int col0 = h * 64 + sub * 8;
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+        const float* row = p.part + (size_t)m * p.ldp + col0;
+        int s = 0;
+        for (; s + 2 <= p.ksplit; s += 2) {            // 4 independent 16-byte loads in flight
+            const float4 a0 = *(const float4*)(row + (size_t)s * sstride), b0 = *(const float4*)(row + (size_t)s * sstride + 4);
+            const float4 a1 = *(const float4*)(row + (size_t)(s + 1) * sstride), b1 = *(const float4*)(row + (size_t)(s + 1) * sstride + 4);
+            qa.x += a0.x + a1.x; qa.y += a0.y + a1.y; qa.z += a0.z + a1.z; qa.w += a0.w + a1.w;
+            qb.x += b0.x + b1.x; qb.y += b0.y + b1.y; qb.z += b0.z + b1.z; qb.w += b0.w + b1.w;
+        }
+        for (; s < p.ksplit; ++s) {
+            const float4 a0 = *(const float4*)(row + (size_t)s * sstride), b0 = *(const float4*)(row + (size_t)s * sstride + 4);
+            qa.x += a0.x; qa.y += a0.y; qa.z += a0.z; qa.w += a0.w;
+            qb.x += b0.x; qb.y += b0.y; qb.z += b0.z; qb.w += b0.w;
+        }
+        const float qs[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int col = h * 64 + sub * 8 + e;
-            float q = 0.f;
-            for (int s = 0; s < p.ksplit; ++s) q += p.part[(size_t)s * sstride + (size_t)m * p.ldp + col];
-            q = r16(q + (p.bias ? (float)p.bias[col] : 0.f));
+            const float q = r16(qs[e] + (p.bias ? (float)p.bias[col0 + e] : 0.f));
             qf[i][e] = r16(q * ATTN_SCALE);
         }
     }

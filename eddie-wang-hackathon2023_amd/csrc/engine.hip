@@ -81,6 +81,7 @@ using namespace wm;
 struct wm_engine {
     int kind = 0; uint32_t flags = 0; wm_dims dims{}; int device = 0;
     unsigned char* dev = nullptr; size_t dev_bytes = 0;
+    std::vector<void*> expanded;               // fp16 expansions of int8 row-major weights (big-M GEMMs)
     std::map<std::string, Tensor> t;
     std::map<std::string, float> scalars;      // host copies of 4-byte fp32 tensors (kv scales)
     // encoder
@@ -190,6 +191,27 @@ int resolve(wm_engine* e) {
     return 0;
 }
 
+// Weight-only engines: the M >> 16 stages are MFMA-bound, so their int8 [N][K] matrices are expanded
+// once to fp16(fp16(q) * scale) (the reference kernels' per-element dequantisation) and the fp16
+// GEMM serves both precisions.  Costs N*K*2 bytes of the 288 GB; the blob on disk stays int8.
+int expand_lin(wm_engine* e, Lin* l) {
+    if (!l->s) return 0;
+    void* buf = nullptr;
+    WM_CHECK_HIP(hipMalloc(&buf, (size_t)l->N * l->K * sizeof(h16)));
+    e->expanded.push_back(buf);
+    if (launch_dequant_w8((const int8_t*)l->w, l->s, (h16*)buf, l->N, l->K, 0)) return 2;
+    l->w = buf; l->s = nullptr;
+    return 0;
+}
+int expand_row_major_int8(wm_engine* e) {
+    for (auto& L : e->enc)
+        if (expand_lin(e, &L.qkv) || expand_lin(e, &L.out) || expand_lin(e, &L.mlp1) || expand_lin(e, &L.mlp2)) return 2;
+    for (auto& l : e->ckv)
+        if (expand_lin(e, &l)) return 2;
+    WM_CHECK_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct Carver {            // bump allocator over the caller's workspace
@@ -227,7 +249,7 @@ int big(const Lin& l, const wm_engine* e, const h16* A, int lda, int M, h16* Cou
     p.A = A; p.lda = lda; p.M = M; p.K = l.K; p.W = l.w; p.N = l.N; p.w8 = l.s != nullptr;
     p.scale = l.s; p.bias = l.b; p.C = Cout; p.ldc = ldc; p.act = act;
     if (!custom) { p.residual = residual; p.ldr = ldr; }
-    return launch_gemm_big(p, s);
+    return p.w8 ? launch_gemm_big(p, s) : launch_gemm_f16(p, s);
 }
 
 }  // namespace
@@ -279,7 +301,7 @@ int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** ou
             e->scalars[nm] = v;
         }
     }
-    if (resolve(e)) { (void)hipFree(e->dev); delete e; return 1; }
+    if (resolve(e) || expand_row_major_int8(e)) { (void)hipFree(e->dev); for (void* x : e->expanded) (void)hipFree(x); delete e; return 1; }
     *out = e;
     return 0;
 }
@@ -287,6 +309,7 @@ int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** ou
 void wm_engine_destroy(wm_engine* e) {
     if (!e) return;
     if (e->dev) { (void)hipSetDevice(e->device); (void)hipFree(e->dev); }
+    for (void* x : e->expanded) (void)hipFree(x);
     delete e;
 }
 
@@ -564,9 +587,9 @@ int wm_profile_read(double* total_ms, int64_t* count, int reset) {
 int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream) {
     WM_REQUIRE(io && io->logits && io->tokens && io->sum_logprobs, "wm_greedy_step: null argument");
     GreedyParams p{};
-    p.logits = (const h16*)io->logits; p.ld_row = io->row_stride; p.B = io->batch; p.V = io->n_vocab;
+    p.logits = (h16*)io->logits; p.ld_row = io->row_stride; p.B = io->batch; p.V = io->n_vocab;
     p.tokens = io->tokens; p.ld_tok = io->tokens_ld; p.cur_len = io->cur_len; p.sum_logprobs = io->sum_logprobs;
-    p.suppress_mask = io->suppress_mask; p.blank = io->blank; p.n_blank = io->n_blank;
+    p.suppress = io->suppress; p.n_suppress = io->n_suppress; p.blank = io->blank; p.n_blank = io->n_blank;
     p.sample_begin = io->sample_begin; p.eot = io->eot; p.timestamp_begin = io->timestamp_begin;
     p.max_initial_ts = io->max_initial_timestamp_index; p.apply_rules = io->apply_rules; p.n_done = io->n_done;
     return launch_greedy(p, (hipStream_t)stream);
@@ -579,7 +602,7 @@ int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, 
     p.A = (const h16*)A; p.lda = lda; p.M = M; p.K = K; p.W = W; p.N = N; p.w8 = w8;
     p.scale = (const h16*)scale; p.bias = (const h16*)bias; p.C = (h16*)C; p.ldc = ldc;
     p.residual = (const h16*)residual; p.ldr = ldr; p.act = act;
-    return launch_gemm_big(p, (hipStream_t)stream);
+    return w8 ? launch_gemm_big(p, (hipStream_t)stream) : launch_gemm_f16(p, (hipStream_t)stream);
 }
 
 int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_blocks, int w8,

@@ -54,18 +54,29 @@ __device__ __forceinline__ T block_reduce(T v, F merge, T* scratch) {
     __syncthreads();
     T r = scratch[0];
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = merge(r, scratch[w]);
+    __syncthreads();
     return r;
 }
 
-__global__ __launch_bounds__(256) void greedy_kernel(GreedyParams p) {
-    __shared__ MS s_ms[4];
-    __shared__ AM s_am[4];
+constexpr int GREEDY_THREADS = 1024;
+
+__global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) {
+    __shared__ MS s_ms[GREEDY_THREADS / 64];
+    __shared__ AM s_am[GREEDY_THREADS / 64];
     __shared__ int s_info[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const h16* lg = p.logits + (size_t)b * p.ld_row;
+    h16* lg = p.logits + (size_t)b * p.ld_row;
     int32_t* toks = p.tokens + (size_t)b * p.ld_tok;
     const int tb = p.timestamp_begin;
+    const bool first = p.apply_rules && (p.cur_len == p.sample_begin);
 
+    // ---- SuppressTokens (+ no_timestamps) and SuppressBlank: written into the logits row, exactly
+    // like the reference's in-place filters (decoding.py:202-217); the scan below then sees -inf ----
+    if (p.apply_rules) {
+        const h16 ninf = (h16)(-INFINITY);
+        for (int i = tid; i < p.n_suppress; i += GREEDY_THREADS) lg[p.suppress[i]] = ninf;
+        if (first) for (int i = tid; i < p.n_blank; i += GREEDY_THREADS) lg[p.blank[i]] = ninf;
+    }
     // ---- token-history facts (thread 0): last / penultimate sampled token, last timestamp ----------
     if (tid == 0) {
         int last_ts = 0, pen_ts = 0, ts_last = -1;
@@ -79,35 +90,36 @@ __global__ __launch_bounds__(256) void greedy_kernel(GreedyParams p) {
         }
         s_info[0] = last_ts; s_info[1] = pen_ts; s_info[2] = ts_last;
     }
-    __syncthreads();
+    __syncthreads();                       // also orders the -inf stores above before the scan
     const bool last_ts = s_info[0], pen_ts = s_info[1];
     const int ts_last = s_info[2];
-    const bool first = p.apply_rules && (p.cur_len == p.sample_begin);
 
-    auto masked = [&](int n) -> bool {
-        if (!p.apply_rules) return false;
-        if (p.suppress_mask[n]) return true;
-        if (first) {
-            if (n < tb) return true;
-            if (p.max_initial_ts >= 0 && n > tb + p.max_initial_ts) return true;
-        }
-        if (last_ts) {
-            if (pen_ts) { if (n >= tb) return true; }
-            else if (n < p.eot) return true;
-        }
-        if (ts_last >= 0 && n >= tb && n < ts_last) return true;
-        return false;
-    };
+    // allowed = [lo_txt, hi_txt) U [lo_ts, hi_ts): every rule of ApplyTimestampRules is a range
+    int lo_txt = 0, hi_txt = p.apply_rules ? tb : p.V, lo_ts = p.apply_rules ? tb : p.V, hi_ts = p.V;
+    if (p.apply_rules) {
+        if (first) { hi_txt = 0; if (p.max_initial_ts >= 0) hi_ts = min(hi_ts, tb + p.max_initial_ts + 1); }
+        if (last_ts) { if (pen_ts) lo_ts = p.V; else lo_txt = max(lo_txt, p.eot); }
+        if (ts_last >= 0) lo_ts = max(lo_ts, ts_last);
+    }
 
     MS txt{-INFINITY, 0.f}, tsm{-INFINITY, 0.f};
     AM atxt{-INFINITY, 0x7fffffff}, ats{-INFINITY, 0x7fffffff};
-    for (int n = tid; n < p.V; n += 256) {
-        float x = (float)lg[n];
-        if (masked(n)) x = -INFINITY;
-        if (first) for (int k = 0; k < p.n_blank; ++k) if (p.blank[k] == n) x = -INFINITY;
-        if (!p.apply_rules || n < tb) { txt = ms_add(txt, x); if (x > atxt.v) atxt = AM{x, n}; }
-        else { tsm = ms_add(tsm, x); if (x > ats.v) ats = AM{x, n}; }
+    auto visit = [&](int n, float x) {
+        if (n < hi_txt) { if (n >= lo_txt) { txt = ms_add(txt, x); if (x > atxt.v) atxt = AM{x, n}; } }
+        else if (n >= lo_ts && n < hi_ts) { tsm = ms_add(tsm, x); if (x > ats.v) ats = AM{x, n}; }
+    };
+    // rows are only 2-byte aligned (odd vocabulary): scalar head up to a 16-byte boundary, 8-wide body
+    const int head = min(p.V, (int)(((16 - ((size_t)lg & 15)) & 15) >> 1));
+    for (int n = tid; n < head; n += GREEDY_THREADS) visit(n, (float)lg[n]);
+    const int nvec = (p.V - head) >> 3;
+    for (int c = tid; c < nvec; c += GREEDY_THREADS) {
+        const int n0 = head + c * 8;
+        const half8v v = *(const half8v*)(lg + n0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) visit(n0 + e, (float)v[e]);
     }
+    for (int n = head + nvec * 8 + tid; n < p.V; n += GREEDY_THREADS) visit(n, (float)lg[n]);
+
     txt = block_reduce(txt, ms_merge, s_ms);
     tsm = block_reduce(tsm, ms_merge, s_ms);
     atxt = block_reduce(atxt, am_merge, s_am);
@@ -134,8 +146,8 @@ __global__ __launch_bounds__(256) void greedy_kernel(GreedyParams p) {
 
 int launch_greedy(const GreedyParams& p, hipStream_t stream) {
     WM_REQUIRE(p.cur_len >= 1 && p.cur_len < p.ld_tok, "greedy: cur_len=%d does not fit ld_tok=%d", p.cur_len, p.ld_tok);
-    WM_REQUIRE(!p.apply_rules || p.suppress_mask != nullptr, "greedy: rules need a suppress mask");
-    hipLaunchKernelGGL(greedy_kernel, dim3(p.B), dim3(256), 0, stream, p);
+    WM_REQUIRE(p.n_suppress == 0 || p.suppress != nullptr, "greedy: suppress list is null");
+    hipLaunchKernelGGL(greedy_kernel, dim3(p.B), dim3(GREEDY_THREADS), 0, stream, p);
     WM_LAUNCH_CHECK(stream, "greedy");
     return 0;
 }

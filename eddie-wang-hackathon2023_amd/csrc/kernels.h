@@ -20,7 +20,9 @@ struct GemmBigParams {
     int a_rows; long a_bstride;
     int c_rows; long c_bstride;              // same for C (out_mode 0 only)
 };
-int launch_gemm_big(const GemmBigParams& p, hipStream_t stream);
+int launch_gemm_big(const GemmBigParams& p, hipStream_t stream);      // 128x128 tile, register staged; int8 or fp16 W
+int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // 256x128 tile, LDS-DMA ring; fp16 W (gemm_f16.hip)
+int launch_dequant_w8(const int8_t* q, const h16* scale, h16* out, int N, int K, hipStream_t stream);
 
 // ---------------------------------------------------------------- gemm_skinny.hip
 // Weight-streaming GEMM for M <= 64 rows (decode step M = B, prefill M = 3B):
@@ -107,11 +109,11 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- greedy.hip
 struct GreedyParams {
-    const h16* logits; long ld_row;          // row b at logits + b*ld_row (last position of each utterance)
+    h16* logits; long ld_row;                // row b at logits + b*ld_row; suppressed entries are overwritten with -inf
     int B; int V;
     int32_t* tokens; int ld_tok; int cur_len;     // [B][ld_tok], cur_len tokens valid; next written at cur_len
     float* sum_logprobs;                     // [B]
-    const uint8_t* suppress_mask;            // [V] 1 = always suppressed (SuppressTokens + no_timestamps)
+    const int32_t* suppress; int n_suppress; // token ids suppressed on every step (SuppressTokens + no_timestamps)
     const int32_t* blank; int n_blank;       // SuppressBlank list (incl. eot)
     int sample_begin; int eot; int timestamp_begin; int max_initial_ts;   // -1 = no limit
     int apply_rules;                         // 0 = plain argmax (tests / models without special ids)

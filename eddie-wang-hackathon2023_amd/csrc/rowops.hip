@@ -53,7 +53,16 @@ __global__ __launch_bounds__(ROW_THREADS) void row_finish_kernel(RowFinishParams
         if (p.mode != 2) {
             float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
             const float* src = p.part + (size_t)m * p.ldp + n;
-            for (int s = 0; s < p.ksplit; ++s) {
+            int s = 0;
+            for (; s + 4 <= p.ksplit; s += 4) {       // 4 slabs in flight: the loop is L2-latency bound
+                const float4 t0 = *(const float4*)(src + (size_t)s * sstride);
+                const float4 t1 = *(const float4*)(src + (size_t)(s + 1) * sstride);
+                const float4 t2 = *(const float4*)(src + (size_t)(s + 2) * sstride);
+                const float4 t3 = *(const float4*)(src + (size_t)(s + 3) * sstride);
+                y.x += (t0.x + t1.x) + (t2.x + t3.x); y.y += (t0.y + t1.y) + (t2.y + t3.y);
+                y.z += (t0.z + t1.z) + (t2.z + t3.z); y.w += (t0.w + t1.w) + (t2.w + t3.w);
+            }
+            for (; s < p.ksplit; ++s) {
                 const float4 t = *(const float4*)(src + (size_t)s * sstride);
                 y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
             }

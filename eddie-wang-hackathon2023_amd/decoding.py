@@ -477,13 +477,13 @@ class WhisperDecoding:
         n_layer, n_head, cap, V = cfg['num_layers'], cfg['num_heads'], cfg['num_text_ctx'], cfg['vocab_size']
         kv_dtype = torch.int8 if self.use_int8_kv_cache else torch.float16
         tk = self.tokenizer
-        mask = torch.zeros(V, dtype=torch.uint8)
-        use_rules = not self.options.without_timestamps
+        suppress = []
         for f in self.logit_filters:
             if isinstance(f, SuppressTokens):
-                mask[f.suppress_tokens] = 1
-        if use_rules and tk.no_timestamps is not None:
-            mask[tk.no_timestamps] = 1
+                suppress += list(f.suppress_tokens)
+        if not self.options.without_timestamps and tk.no_timestamps is not None:
+            suppress.append(tk.no_timestamps)
+        suppress = sorted(set(suppress))
         blank = list(tk.blank_tokens()) + [tk.eot] if self.options.suppress_blank else []
         st = dict(
             kv=[torch.zeros((n_batch, 2, n_head, cap, 64), dtype=kv_dtype, device=device) for _ in range(n_layer)],
@@ -491,7 +491,8 @@ class WhisperDecoding:
             logits=torch.empty((n_batch, self.initial_token_length, V), dtype=torch.float16, device=device),
             sum_logprobs=torch.zeros(n_batch, dtype=torch.float32, device=device),
             n_done=torch.zeros(1, dtype=torch.int32, device=device),
-            mask=mask.to(device), blank=torch.tensor(blank or [0], dtype=torch.int32, device=device), n_blank=len(blank),
+            suppress=torch.tensor(suppress or [0], dtype=torch.int32, device=device), n_suppress=len(suppress),
+            blank=torch.tensor(blank or [0], dtype=torch.int32, device=device), n_blank=len(blank),
         )
         self._state[n_batch] = st
         return st
@@ -503,7 +504,7 @@ class WhisperDecoding:
         io.batch, io.n_vocab = n_batch, self.decoder_config['vocab_size']
         io.tokens, io.tokens_ld, io.cur_len = st['tokens'].data_ptr(), st['tokens'].shape[1], cur_len
         io.sum_logprobs = st['sum_logprobs'].data_ptr()
-        io.suppress_mask = st['mask'].data_ptr()
+        io.suppress, io.n_suppress = st['suppress'].data_ptr(), st['n_suppress']
         io.blank, io.n_blank = st['blank'].data_ptr(), st['n_blank']
         io.sample_begin, io.eot, io.timestamp_begin = self.sample_begin, tk.eot, tk.timestamp_begin
         io.max_initial_timestamp_index = -1 if self.max_initial_timestamp_index is None else self.max_initial_timestamp_index

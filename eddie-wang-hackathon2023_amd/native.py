@@ -55,7 +55,7 @@ class WmGreedyIO(C.Structure):
         ("batch", C.c_int32), ("n_vocab", C.c_int32),
         ("tokens", C.c_void_p), ("tokens_ld", C.c_int32), ("cur_len", C.c_int32),
         ("sum_logprobs", C.c_void_p),
-        ("suppress_mask", C.c_void_p),
+        ("suppress", C.c_void_p), ("n_suppress", C.c_int32),
         ("blank", C.c_void_p), ("n_blank", C.c_int32),
         ("sample_begin", C.c_int32), ("eot", C.c_int32), ("timestamp_begin", C.c_int32),
         ("max_initial_timestamp_index", C.c_int32),

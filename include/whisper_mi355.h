@@ -105,11 +105,13 @@ int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t str
  * appends the token at tokens[b][cur_len].  n_done (device int32, caller zeroes it) counts rows
  * whose new token is EOT.                                                                          */
 typedef struct wm_greedy_io {
-    const void* logits; int64_t row_stride; /* fp16; row b starts at logits + b*row_stride elements */
+    void* logits; int64_t row_stride; /* fp16; row b starts at logits + b*row_stride elements;
+                                         suppressed entries are overwritten with -inf in place,
+                                         like the reference's filters do (decoding.py:202-217) */
     int32_t batch, n_vocab;
     int32_t* tokens; int32_t tokens_ld; int32_t cur_len;
     float* sum_logprobs;
-    const uint8_t* suppress_mask; /* [n_vocab], 1 = suppressed on every step */
+    const int32_t* suppress; int32_t n_suppress; /* token ids suppressed on every step */
     const int32_t* blank; int32_t n_blank; /* suppressed on the first sampled step only */
     int32_t sample_begin, eot, timestamp_begin, max_initial_timestamp_index /* -1: none */;
     int32_t apply_rules; /* 0: plain arg-max */

@@ -270,10 +270,8 @@ def test_greedy_step_matches_reference_rules(lib, golden_dir):
     fixr = np.load(os.path.join(golden_dir, "decoding_rules.npz"))
     ids = DR.MULTILINGUAL
     V = ids.n_vocab
-    mask = np.zeros(V, dtype=np.uint8)
-    mask[fixr["suppress"]] = 1
-    mask[ids.no_timestamps] = 1
-    mask_d, blank_d = dev(mask), dev(fixr["blank"].astype(np.int32))
+    sup = sorted(set(fixr["suppress"].tolist() + [ids.no_timestamps]))
+    sup_d, blank_d = dev(np.array(sup, dtype=np.int32)), dev(fixr["blank"].astype(np.int32))
     for c, (toks, logits) in enumerate(DR.golden_rule_cases()):
         cur = len(toks)
         tok_buf = torch.zeros((1, 64), dtype=torch.int32, device="cuda")
@@ -284,7 +282,7 @@ def test_greedy_step_matches_reference_rules(lib, golden_dir):
         io = native.WmGreedyIO()
         io.logits, io.row_stride, io.batch, io.n_vocab = lg.data_ptr(), V, 1, V
         io.tokens, io.tokens_ld, io.cur_len = tok_buf.data_ptr(), 64, cur
-        io.sum_logprobs, io.suppress_mask = s.data_ptr(), mask_d.data_ptr()
+        io.sum_logprobs, io.suppress, io.n_suppress = s.data_ptr(), sup_d.data_ptr(), len(sup)
         io.blank, io.n_blank = blank_d.data_ptr(), len(fixr["blank"])
         io.sample_begin, io.eot, io.timestamp_begin = 3, ids.eot, ids.timestamp_begin
         io.max_initial_timestamp_index, io.apply_rules, io.n_done = 50, 1, n_done.data_ptr()
