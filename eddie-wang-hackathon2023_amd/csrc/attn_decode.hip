@@ -41,6 +41,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     __shared__ h16 s_qall[MAX_L][64], s_knew[MAX_L][64], s_vnew[MAX_L][64];
 
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int T = p.t_dev ? *p.t_dev : p.T;      // device-resident step counter (graph replay) or host value
     const int C = p.H * 64;
     const float t_dq = p.kv_scale;
     const float inv_t = 1.0f / p.kv_scale;
@@ -77,8 +78,8 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
         s_knew[i][lane] = (h16)k;
         s_vnew[i][lane] = (h16)v;
         // append to the cache (present), position T + i
-        const size_t off_k = (size_t)b * p.present_bstride + ((size_t)(0 * p.H + h) * p.present_cap + p.T + i) * 64 + lane;
-        const size_t off_v = (size_t)b * p.present_bstride + ((size_t)(1 * p.H + h) * p.present_cap + p.T + i) * 64 + lane;
+        const size_t off_k = (size_t)b * p.present_bstride + ((size_t)(0 * p.H + h) * p.present_cap + T + i) * 64 + lane;
+        const size_t off_v = (size_t)b * p.present_bstride + ((size_t)(1 * p.H + h) * p.present_cap + T + i) * 64 + lane;
         if (I8) {
             ((int8_t*)p.present)[off_k] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(k * inv_t)));
             ((int8_t*)p.present)[off_v] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(v * inv_t)));
@@ -92,12 +93,12 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     // copy-forward: when present is a different buffer than past (the reference's concat
     // semantics, attention.py:296-306), move the T cached rows of this head
     const bool inplace = (p.past == p.present) && (p.past_cap == p.present_cap) && (p.past_bstride == p.present_bstride);
-    if (!inplace && p.T > 0) {
+    if (!inplace && T > 0) {
         const int es = I8 ? 1 : 2;
         for (int kv = 0; kv < 2; ++kv) {
             const unsigned char* src = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(kv * p.H + h) * p.past_cap * 64) * es;
             unsigned char* dst = (unsigned char*)p.present + ((size_t)b * p.present_bstride + (size_t)(kv * p.H + h) * p.present_cap * 64) * es;
-            const int n16 = p.T * 64 * es / 16;
+            const int n16 = T * 64 * es / 16;
             for (int c = lane; c < n16; c += 64) ((uint4*)dst)[c] = ((const uint4*)src)[c];
         }
     }
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
 
     for (int i = 0; i < p.L; ++i) {
         const h16* s_q = s_qall[i];
-        const int nk = p.T + i + 1;                 // causal: past + new tokens 0..i
+        const int nk = T + i + 1;                 // causal: past + new tokens 0..i
         // ---- scores: lane-per-key -------------------------------------------------------------
         float mx = -INFINITY;
         for (int j0 = 0; j0 < nk; j0 += 64) {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
             float sc = -INFINITY;
             if (j < nk) {
                 float acc = 0.f;
-                if (j < p.T) {
+                if (j < T) {
                     if (I8) {
                         const uint4* kr = (const uint4*)(pastK + (size_t)j * 64);
 #pragma unroll
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
                         }
                     }
                 } else {
-                    const h16* kn = s_knew[j - p.T];
+                    const h16* kn = s_knew[j - T];
 #pragma unroll 8
                     for (int e = 0; e < 64; ++e) acc += (float)s_q[e] * r16((float)kn[e] * ATTN_SCALE);
                 }
@@ -168,26 +169,26 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
         int j = 0;
         if (I8) {
             const int8_t* pv = (const int8_t*)pastV + lane;
-            for (; j + 8 <= p.T; j += 8) {          // 8 loads in flight per lane
+            for (; j + 8 <= T; j += 8) {          // 8 loads in flight per lane
                 int8_t vq[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) vq[u] = pv[(size_t)(j + u) * 64];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) o += s_p[j + u] * r16((float)vq[u] * t_dq);
             }
-            for (; j < p.T; ++j) o += s_p[j] * r16((float)pv[(size_t)j * 64] * t_dq);
+            for (; j < T; ++j) o += s_p[j] * r16((float)pv[(size_t)j * 64] * t_dq);
         } else {
             const h16* pv = (const h16*)pastV + lane;
-            for (; j + 8 <= p.T; j += 8) {
+            for (; j + 8 <= T; j += 8) {
                 h16 vh[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) vh[u] = pv[(size_t)(j + u) * 64];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) o += s_p[j + u] * (float)vh[u];
             }
-            for (; j < p.T; ++j) o += s_p[j] * (float)pv[(size_t)j * 64];
+            for (; j < T; ++j) o += s_p[j] * (float)pv[(size_t)j * 64];
         }
-        for (; j < nk; ++j) o += s_p[j] * (float)s_vnew[j - p.T][lane];
+        for (; j < nk; ++j) o += s_p[j] * (float)s_vnew[j - T][lane];
         p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)o;
         __syncthreads();
     }

@@ -409,6 +409,8 @@ struct Profiler {
 
 int prof_begin(int layer, hipStream_t s) {
     if (!g_prof.enabled || layer % g_prof.layer_stride != 0 || g_prof.used >= g_prof.start.size()) return -1;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;   // eager launches only
     const int slot = (int)g_prof.used++;
     (void)hipEventRecord(g_prof.start[slot], s);
     return slot;
@@ -482,12 +484,13 @@ int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t str
     WM_REQUIRE(B >= 1 && L >= 1 && L <= 4 && T >= 0, "wm_decoder_step: bad batch/n_new/n_past (%d, %d, %d)", B, L, T);
     WM_REQUIRE(T + L <= d.n_text_ctx, "wm_decoder_step: T+L=%d exceeds n_text_ctx=%d", T + L, d.n_text_ctx);
     WM_REQUIRE(T == 0 || io->past, "wm_decoder_step: n_past > 0 needs past buffers");
+    WM_REQUIRE(!io->n_past_dev || (L == 1 && io->past), "wm_decoder_step: a device step counter needs n_new == 1 and past buffers");
     WM_REQUIRE(C == H * 64, "head size must be 64");
     DecWs w = carve_decoder(e, B, L, io->workspace);
     WM_REQUIRE(io->workspace_bytes >= w.total, "decoder workspace too small: %zu < %zu", io->workspace_bytes, w.total);
 
     EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
-                   (const h16*)io->positional_embedding, w.x, C, d.n_vocab};
+                   (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev};
     if (launch_embed(ep, s)) return 2;
 
     auto finish = [&](const Lin& l, int ks, int mode, const h16* g, const h16* bta, h16* out, int ldo, int N) {
@@ -516,6 +519,7 @@ int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t str
             } else { p.past = p.present; p.past_cap = p.present_cap; p.past_bstride = p.present_bstride; }
             p.int8_kv = e->i8kv(); p.kv_scale = Lr.kv_scale; p.out = w.ctx; p.ldo = C;
             p.amax = io->qkv_amax ? io->qkv_amax + i : nullptr;
+            p.t_dev = io->n_past_dev;
             if (launch_attn_self(p, s)) return 2;
         }
         if (skinny_all(Lr.out, w.ctx, C, M, w.part, &ks, s)) return 2;
@@ -592,8 +596,11 @@ int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream) {
     p.suppress = io->suppress; p.n_suppress = io->n_suppress; p.blank = io->blank; p.n_blank = io->n_blank;
     p.sample_begin = io->sample_begin; p.eot = io->eot; p.timestamp_begin = io->timestamp_begin;
     p.max_initial_ts = io->max_initial_timestamp_index; p.apply_rules = io->apply_rules; p.n_done = io->n_done;
+    p.t_dev = io->n_past_dev;
     return launch_greedy(p, (hipStream_t)stream);
 }
+
+int wm_step_advance(int32_t* counter, wm_stream_t stream) { return launch_step_advance(counter, (hipStream_t)stream); }
 
 // ================================================================================================ kernel-level
 int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, const void* scale,

@@ -27,16 +27,16 @@ namespace wm {
 constexpr int KC = 256;                 // activation chunk staged per barrier (inputs)
 constexpr int A_ROW = KC * 2 + 16;      // LDS row stride in bytes
 
-template <bool W8, int MT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyParams p) {
+template <bool W8, int MT, int NW>      // NW waves per workgroup share one staged activation chunk
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p) {
     constexpr int KT = W8 ? 64 : 32;          // inputs per weight tile
     constexpr int TPC = KC / KT;              // tiles per chunk: 4 (int8) / 8 (fp16)
     __shared__ __attribute__((aligned(16))) unsigned char sA[MT * 16 * A_ROW];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nwg_n = (p.n_blocks + 3) >> 2;
+    const int nwg_n = (p.n_blocks + NW - 1) / NW;
     const int bn = blockIdx.x % nwg_n, ks = blockIdx.x / nwg_n;
-    const int nb = bn * 4 + wid;                          // this wave's 16-channel block
+    const int nb = bn * NW + wid;                          // this wave's 16-channel block
     const bool wave_active = nb < p.n_blocks;
 
     const int kt_total = p.K / KT;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyParams p) {
     for (int t0 = t_begin; t0 < t_end; t0 += TPC) {
         // ---- stage A[:, t0*KT .. +KC) into LDS (zero rows >= M, zero columns >= K) ----------
         const int k0 = t0 * KT;
-        for (int c = tid; c < MT * 16 * (KC / 8); c += 256) {
+        for (int c = tid; c < MT * 16 * (KC / 8); c += NW * 64) {
             const int r = c / (KC / 8), cc = c % (KC / 8);
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r < p.M && k0 + cc * 8 < p.K) v = *(const uint4*)(p.A + (size_t)r * p.lda + k0 + cc * 8);
@@ -136,27 +136,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyParams p) {
     }
 }
 
+static inline int skinny_waves(int M) { return M > 32 ? 8 : 4; }   // bigger activation block -> share it wider
+
 int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
     const int kt_total = K / (w8 ? 64 : 32);
-    const int nwg_n = (n_blocks + 3) / 4;
-    int s = (768 + nwg_n - 1) / nwg_n;                 // aim for ~3 workgroups per CU
+    const int nw = skinny_waves(M);
+    const int nwg_n = (n_blocks + nw - 1) / nw;
+    int s = (3072 / nw + nwg_n - 1) / nwg_n;      // aim for ~3000 waves in flight (12 per CU)                 // aim for ~3 workgroups per CU
     const int min_tiles = w8 ? 2 : 4;                  // at least 2 KiB (int8) / 4 KiB (fp16) per wave
     s = min(s, max(1, kt_total / min_tiles));
-    // partial-slab traffic (2 * s * M * N * 4 B) should stay below the weight bytes (N * K * es)
-    const int es = w8 ? 1 : 2;
-    const int cap = max(1, (K * es) / (8 * max(M, 1)));
-    s = min(s, max(cap, 2));
+    // the fp32 slabs (s * M * N * 4 B) are written and re-read through L2 / Infinity Cache: keep them
+    // under ~16 MB so that they stay on-die; below that, more slices = more bytes in flight, which is
+    // what a latency-bound weight stream needs
+    const long slab = (long)max(M, 1) * n_blocks * 16 * 4;
+    const int cap = (int)max(1L, (16L << 20) / slab);
+    s = min(s, cap);
     return max(1, s);
 }
 
 template <bool W8>
-static int launch_mt(const GemmSkinnyParams& p, int grid, hipStream_t stream) {
+static int launch_mt(const GemmSkinnyParams& p, hipStream_t stream) {
     const int mt = (p.M + 15) / 16;
+    const int g4 = ((p.n_blocks + 3) / 4) * p.ksplit, g8 = ((p.n_blocks + 7) / 8) * p.ksplit;
     switch (mt) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 1>), dim3(grid), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 2>), dim3(grid), dim3(256), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 3>), dim3(grid), dim3(256), 0, stream, p); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 4>), dim3(grid), dim3(256), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 1, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 2, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 3, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 4, 8>), dim3(g8), dim3(512), 0, stream, p); break;
     }
     return 0;
 }
@@ -169,8 +175,7 @@ int launch_gemm_skinny(const GemmSkinnyParams& p, hipStream_t stream) {
     WM_REQUIRE(p.ksplit >= 1, "gemm_skinny: ksplit must be >= 1");
     WM_REQUIRE(p.out == nullptr || p.ksplit == 1, "gemm_skinny: direct output needs ksplit == 1");
     WM_REQUIRE(p.out != nullptr || p.part != nullptr, "gemm_skinny: no output buffer");
-    const int grid = ((p.n_blocks + 3) / 4) * p.ksplit;
-    if (p.w8) launch_mt<true>(p, grid, stream); else launch_mt<false>(p, grid, stream);
+    if (p.w8) launch_mt<true>(p, stream); else launch_mt<false>(p, stream);
     WM_LAUNCH_CHECK(stream, "gemm_skinny");
     return 0;
 }

@@ -65,10 +65,11 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
     __shared__ AM s_am[GREEDY_THREADS / 64];
     __shared__ int s_info[4];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int cur_len = p.t_dev ? *p.t_dev + 1 : p.cur_len;     // device step counter holds n_past = cur_len - 1
     h16* lg = p.logits + (size_t)b * p.ld_row;
     int32_t* toks = p.tokens + (size_t)b * p.ld_tok;
     const int tb = p.timestamp_begin;
-    const bool first = p.apply_rules && (p.cur_len == p.sample_begin);
+    const bool first = p.apply_rules && (cur_len == p.sample_begin);
 
     // ---- SuppressTokens (+ no_timestamps) and SuppressBlank: written into the logits row, exactly
     // like the reference's in-place filters (decoding.py:202-217); the scan below then sees -inf ----
@@ -81,10 +82,10 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
     if (tid == 0) {
         int last_ts = 0, pen_ts = 0, ts_last = -1;
         if (p.apply_rules) {
-            const int n = p.cur_len - p.sample_begin;
-            last_ts = (n >= 1 && toks[p.cur_len - 1] >= tb) ? 1 : 0;
-            pen_ts = (n < 2 || toks[p.cur_len - 2] >= tb) ? 1 : 0;
-            for (int j = p.cur_len - 1; j >= p.sample_begin; --j)
+            const int n = cur_len - p.sample_begin;
+            last_ts = (n >= 1 && toks[cur_len - 1] >= tb) ? 1 : 0;
+            pen_ts = (n < 2 || toks[cur_len - 2] >= tb) ? 1 : 0;
+            for (int j = cur_len - 1; j >= p.sample_begin; --j)
                 if (toks[j] >= tb) { ts_last = toks[j]; break; }
             if (ts_last >= 0 && !(last_ts && !pen_ts)) ts_last += 1;
         }
@@ -135,20 +136,29 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
         MS z = ts_only ? tsm : ms_merge(txt, tsm);
         const float logz = z.m + logf(z.s);
         const float lp = best.v - logz;
-        const int prev = toks[p.cur_len - 1];
+        const int prev = toks[cur_len - 1];
         const bool alive = (prev != p.eot);
         if (alive) p.sum_logprobs[b] += lp;
         const int next = alive ? best.i : p.eot;
-        toks[p.cur_len] = next;
+        toks[cur_len] = next;
         if (next == p.eot && p.n_done) atomicAdd(p.n_done, 1);
     }
 }
 
 int launch_greedy(const GreedyParams& p, hipStream_t stream) {
-    WM_REQUIRE(p.cur_len >= 1 && p.cur_len < p.ld_tok, "greedy: cur_len=%d does not fit ld_tok=%d", p.cur_len, p.ld_tok);
+    WM_REQUIRE(p.t_dev || (p.cur_len >= 1 && p.cur_len < p.ld_tok), "greedy: cur_len=%d does not fit ld_tok=%d", p.cur_len, p.ld_tok);
     WM_REQUIRE(p.n_suppress == 0 || p.suppress != nullptr, "greedy: suppress list is null");
     hipLaunchKernelGGL(greedy_kernel, dim3(p.B), dim3(GREEDY_THREADS), 0, stream, p);
     WM_LAUNCH_CHECK(stream, "greedy");
+    return 0;
+}
+
+__global__ void step_advance_kernel(int32_t* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1; }
+
+int launch_step_advance(int32_t* counter, hipStream_t stream) {
+    WM_REQUIRE(counter, "step_advance: null counter");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, stream, counter);
+    WM_LAUNCH_CHECK(stream, "step_advance");
     return 0;
 }
 

@@ -64,6 +64,7 @@ struct EmbedParams {
     const h16* pos;                          // [L][C] (already offset by the caller, decoding.py:604-608)
     h16* x; int ldx;
     int n_vocab;
+    const int32_t* t_dev;                    // optional device counter: token column / position row offset
 };
 int launch_embed(const EmbedParams& p, hipStream_t stream);
 
@@ -91,6 +92,7 @@ struct AttnSelfParams {
     void* present; long present_bstride; int present_cap;   // may alias past (in-place append)
     int int8_kv; float kv_scale;             // t (kv_quant_orig); 1/t formed in fp32
     float* amax;                             // optional: running max |q|,|k|,|v| (int8-KV calibration)
+    const int32_t* t_dev;                    // optional device copy of T (overrides T; hipGraph replay)
     h16* out; int ldo;                       // [M][C]
 };
 int launch_attn_self(const AttnSelfParams& p, hipStream_t stream);
@@ -118,8 +120,10 @@ struct GreedyParams {
     int sample_begin; int eot; int timestamp_begin; int max_initial_ts;   // -1 = no limit
     int apply_rules;                         // 0 = plain argmax (tests / models without special ids)
     int32_t* n_done;                         // [1] number of rows whose last token is eot after this step
+    const int32_t* t_dev;                    // optional device step counter: cur_len = *t_dev + 1
 };
 int launch_greedy(const GreedyParams& p, hipStream_t stream);
+int launch_step_advance(int32_t* counter, hipStream_t stream);
 
 int launch_quantize_i8(const h16* x, int8_t* q, long n, float inv_scale, hipStream_t stream);
 

@@ -126,12 +126,13 @@ int launch_layernorm(const h16* x, int ldx, int M, int N, const h16* g, const h1
 //   ((t / 16) * (C / 32) + kt) * 1024 + ((t & 15) + 16 * g) * 16 bytes.
 __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
     const int m = blockIdx.x;
-    int tok = p.tokens[(size_t)(m / p.L) * p.tokens_ld + m % p.L];
+    const int T = p.t_dev ? *p.t_dev : 0;            // graph replay: column / position offset read on the device
+    int tok = p.tokens[(size_t)(m / p.L) * p.tokens_ld + m % p.L + T];
     if (tok < 0) tok = 0;
     if (tok >= p.n_vocab) tok = p.n_vocab - 1;
     const int kt_total = p.C / 32;
     const unsigned char* base = (const unsigned char*)p.emb_tiles + (size_t)(tok >> 4) * kt_total * 1024 + (tok & 15) * 16;
-    const h16* pos = p.pos + (size_t)(m % p.L) * p.C;
+    const h16* pos = p.pos + (size_t)(m % p.L + T) * p.C;
     for (int piece = threadIdx.x; piece < p.C / 8; piece += blockDim.x) {
         const int kt = piece >> 2, g = piece & 3;
         const half8v e = *(const half8v*)(base + (size_t)kt * 1024 + g * 256);

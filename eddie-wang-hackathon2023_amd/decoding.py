@@ -232,6 +232,9 @@ class WhisperDecoding:
         self._cross_cache = None          # (key, list of cross K/V) from the last xa2cross_key_value
         self._state = {}                  # per-batch-size device buffers of the fast path
         self.poll_every = 8
+        self.micro_batches = 2            # stream-level overlap of independent utterance groups
+        self.use_graphs = True            # replay one captured decode step per token (hipGraph)
+        self._streams = []
 
     # ---- configuration / sessions -----------------------------------------------------------------
     def get_config(self, engine_dir):
@@ -377,7 +380,9 @@ class WhisperDecoding:
             languages = [max(p, key=p.get) for p in language_probs]
         return language_tokens, language_probs, languages
 
-    def detect_language(self, audio_features):
+    def detect_language_reference(self, audio_features):
+        """The reference's language-ID pass literally (W/decoding.py:703-741): cross K/V engine, one
+        `decode()` of the single <|sot|> token through the by-name protocol."""
         languages = [self.options.language] * audio_features.shape[0]
         language_probs = None
         if self.options.language is None or self.options.task == "lang_id":
@@ -389,6 +394,40 @@ class WhisperDecoding:
             cross = self.xa2cross_key_value(audio_features)
             logits, _ = self.decode(x, cross)
             language_tokens, language_probs, languages = self._language_from_logits(logits[:, 0].float(), n_audio, single)
+            if self.options.language is None:
+                self.tokens = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
+                self.tokens[:, self.sot_index + 1] = language_tokens.cpu()        # write language tokens
+        return languages, language_probs
+
+    def detect_language(self, audio_features):
+        """Language-ID pass, fast path: same arithmetic as detect_language_reference, but the cross
+        K/V land in the persistent buffers main_loop re-uses (the reference computes them twice,
+        SURVEY F6) and the one-token decoder call runs per utterance group on its stream."""
+        languages = [self.options.language] * audio_features.shape[0]
+        language_probs = None
+        if self.options.language is None or self.options.task == "lang_id":
+            single = audio_features.ndim == 2
+            if single:
+                audio_features = audio_features.unsqueeze(0)
+            n_audio, dev = audio_features.shape[0], audio_features.device
+            cfg = self.decoder_config
+            st = self._fast_state(n_audio, dev)
+            cross = self._cross_persistent(audio_features, st)
+            if 'lang_logits' not in st:
+                st['lang_logits'] = torch.empty((n_audio, 1, cfg['vocab_size']), dtype=torch.float16, device=dev)
+                st['sot'] = torch.full((n_audio, 1), self.tokenizer.sot, dtype=torch.int32, device=dev)
+            n_micro, bounds = self._groups(n_audio)
+            main = torch.cuda.current_stream()
+            streams = self._group_streams(n_micro, dev)
+            cap = cfg['num_text_ctx']
+            for g, (lo, hi) in enumerate(bounds):
+                streams[g].wait_stream(main)
+                self.decoder_session.decoder_step(st['sot'][lo:hi], self.positional_embedding[0:1],
+                                                  [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
+                                                  st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g)
+                main.wait_stream(streams[g])
+            language_tokens, language_probs, languages = self._language_from_logits(
+                st['lang_logits'][:, 0].float(), n_audio, single)
             if self.options.language is None:
                 self.tokens = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
                 self.tokens[:, self.sot_index + 1] = language_tokens.cpu()        # write language tokens
@@ -487,6 +526,9 @@ class WhisperDecoding:
         blank = list(tk.blank_tokens()) + [tk.eot] if self.options.suppress_blank else []
         st = dict(
             kv=[torch.zeros((n_batch, 2, n_head, cap, 64), dtype=kv_dtype, device=device) for _ in range(n_layer)],
+            cross=[torch.empty((n_batch, 2, n_head, cfg['num_audio_ctx'], 64), dtype=torch.float16, device=device)
+                   for _ in range(n_layer)],
+            cross_key=None, cross_xa=None, graphs={}, counters={},
             tokens=torch.zeros((n_batch, cap + 1), dtype=torch.int32, device=device),
             logits=torch.empty((n_batch, self.initial_token_length, V), dtype=torch.float16, device=device),
             sum_logprobs=torch.zeros(n_batch, dtype=torch.float32, device=device),
@@ -497,25 +539,52 @@ class WhisperDecoding:
         self._state[n_batch] = st
         return st
 
-    def _greedy(self, st, logits, row_stride, cur_len, n_batch, stream):
+    def _group_streams(self, n, dev):
+        """Side streams of the utterance groups (never the legacy default stream: graphs are captured on them)."""
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=dev))
+        return self._streams[:n]
+
+    def _groups(self, n_batch):
+        n_micro = self.micro_batches if n_batch >= 8 * self.micro_batches else 1
+        return n_micro, [(g * n_batch // n_micro, (g + 1) * n_batch // n_micro) for g in range(n_micro)]
+
+    def _cross_persistent(self, xa, st):
+        """Cross K/V of `xa` in the state's persistent buffers (stable addresses: the captured decode
+        graphs point at them).  Computed once per audio-features tensor; `xa` is kept alive so that the
+        (pointer, version) key cannot alias a recycled allocation."""
+        key = (xa.data_ptr(), tuple(xa.shape), xa._version)
+        if st['cross_key'] != key:
+            xa16 = xa.type(torch.float16).contiguous()
+            self.cross_attn_session.cross_kv(xa16, st['cross'], torch.cuda.current_stream().cuda_stream)
+            st['cross_key'], st['cross_xa'] = key, xa
+        return st['cross']
+
+    def _greedy(self, st, lo, hi, logits_ptr, row_stride, cur_len, stream, n_past_dev=None):
+        """Fused logit rules + arg-max + append for utterances [lo, hi) of the batch state `st`."""
         tk = self.tokenizer
         io = native.WmGreedyIO()
-        io.logits, io.row_stride = logits, row_stride
-        io.batch, io.n_vocab = n_batch, self.decoder_config['vocab_size']
-        io.tokens, io.tokens_ld, io.cur_len = st['tokens'].data_ptr(), st['tokens'].shape[1], cur_len
-        io.sum_logprobs = st['sum_logprobs'].data_ptr()
+        io.logits, io.row_stride = logits_ptr, row_stride
+        io.batch, io.n_vocab = hi - lo, self.decoder_config['vocab_size']
+        io.tokens, io.tokens_ld, io.cur_len = st['tokens'][lo:hi].data_ptr(), st['tokens'].shape[1], cur_len
+        io.sum_logprobs = st['sum_logprobs'][lo:hi].data_ptr()
         io.suppress, io.n_suppress = st['suppress'].data_ptr(), st['n_suppress']
         io.blank, io.n_blank = st['blank'].data_ptr(), st['n_blank']
         io.sample_begin, io.eot, io.timestamp_begin = self.sample_begin, tk.eot, tk.timestamp_begin
         io.max_initial_timestamp_index = -1 if self.max_initial_timestamp_index is None else self.max_initial_timestamp_index
         io.apply_rules = 1          # main_loop routes without_timestamps to the reference loop
         io.n_done = st['n_done'].data_ptr()
+        io.n_past_dev = n_past_dev.data_ptr() if n_past_dev is not None else None
         native.check(native.load_library().wm_greedy_step(C.byref(io), stream), "wm_greedy_step")
 
     def main_loop(self, audio_features, ignore_eot: bool = False):
         """Greedy decoding, fast path.  Same return values as the reference's main_loop
         (tokens int64 [n, <=n_text_ctx+1], sum_logprobs fp32 [n], no_speech_probs list).
-        `ignore_eot` (benchmarks with random weights) decodes `sample_len` tokens regardless."""
+        `ignore_eot` (benchmarks with random weights) decodes `sample_len` tokens regardless.
+
+        Utterances are independent, so the batch is cut into `micro_batches` groups that advance in
+        lock-step on separate HIP streams: while one group streams its cross-attention K/V (the
+        HBM-bound part of a step) the other group runs its latency-bound weight-streaming chain."""
         if self.options.temperature != 0 or self.n_group != 1 or self.options.without_timestamps:
             return self.main_loop_reference(audio_features)
         dev = audio_features.device
@@ -523,28 +592,69 @@ class WhisperDecoding:
         n_batch, L0 = tokens0.shape
         cfg = self.decoder_config
         V, cap = cfg['vocab_size'], cfg['num_text_ctx']
-        cross = self.xa2cross_key_value(audio_features)
         st = self._fast_state(n_batch, dev)
+        cross = self._cross_persistent(audio_features, st)
         st['tokens'].zero_()
         st['tokens'][:, :L0] = tokens0.to(torch.int32)
         st['sum_logprobs'].zero_()
         st['n_done'].zero_()
-        stream = torch.cuda.current_stream().cuda_stream
-        sess, kv, pos = self.decoder_session, st['kv'], self.positional_embedding
-        no_speech_probs = [np.nan] * n_batch
+        n_micro, bounds = self._groups(n_batch)
+        main = torch.cuda.current_stream()
+        streams = self._group_streams(n_micro, dev)
+        for s_ in streams:
+            s_.wait_stream(main)
+        sess, pos = self.decoder_session, self.positional_embedding
+        groups = []
+        for g, (lo, hi) in enumerate(bounds):
+            groups.append(dict(lo=lo, hi=hi, stream=streams[g].cuda_stream, slot=g,
+                               kv=[t[lo:hi] for t in st['kv']], cross=[t[lo:hi] for t in cross],
+                               logits=st['logits'][lo:hi], tokens=st['tokens'][lo:hi]))
         cur = L0
         steps_done = 0
+        lib = native.load_library()
+        use_graph = self.use_graphs and self.decoder_session.qkv_amax is None
         for i in range(self.sample_len):
-            if i == 0:
-                sess.decoder_step(st['tokens'][:, :L0], pos[0:L0], cross, None, cap, kv, cap, st['logits'], 0, stream)
-                if self.tokenizer.no_speech is not None:
-                    probs_at_sot = st['logits'][:, self.sot_index].float().softmax(dim=-1)
-                    nsp_dev = probs_at_sot[:, self.tokenizer.no_speech]
-                self._greedy(st, st['logits'].data_ptr() + (L0 - 1) * V * 2, L0 * V, cur, n_batch, stream)
-            else:
-                sess.decoder_step(st['tokens'][:, cur - 1:cur], pos[cur - 1:cur], cross, kv, cap, kv, cap, st['logits'],
-                                  cur - 1, stream)
-                self._greedy(st, st['logits'].data_ptr(), V, cur, n_batch, stream)
+            for gr in groups:
+                lo, hi, sm, slot = gr['lo'], gr['hi'], gr['stream'], gr['slot']
+                gkey = (n_micro, slot)
+                if i == 0:
+                    sess.decoder_step(gr['tokens'][:, :L0], pos[0:L0], gr['cross'], None, cap, gr['kv'], cap,
+                                      gr['logits'], 0, sm, slot=slot)
+                    self._greedy(st, lo, hi, gr['logits'].data_ptr() + (L0 - 1) * V * 2, L0 * V, cur, sm)
+                elif use_graph and gkey in st['graphs']:
+                    if i == 1 or st['counters'][gkey + ('fresh',)]:
+                        # the device step counter holds n_past = cur - 1; (re)seed it on the group's stream
+                        with torch.cuda.stream(streams[slot]):
+                            st['counters'][gkey].fill_(cur - 1)
+                        st['counters'][gkey + ('fresh',)] = False
+                    with torch.cuda.stream(streams[slot]):
+                        st['graphs'][gkey].replay()
+                else:
+                    sess.decoder_step(gr['tokens'][:, cur - 1:cur], pos[cur - 1:cur], gr['cross'], gr['kv'], cap,
+                                      gr['kv'], cap, gr['logits'], cur - 1, sm, slot=slot)
+                    self._greedy(st, lo, hi, gr['logits'].data_ptr(), V, cur, sm)
+                    if use_graph:
+                        # capture ONE decode step (decoder + fused greedy + counter advance) of this group;
+                        # every later token replays it: T is read from a device counter inside the kernels
+                        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+                        streams[slot].synchronize()
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph, stream=streams[slot]):
+                            sess.decoder_step(gr['tokens'], pos, gr['cross'], gr['kv'], cap, gr['kv'], cap,
+                                              gr['logits'], 1, sm, slot=slot, n_past_dev=counter, n_new=1)
+                            self._greedy(st, lo, hi, gr['logits'].data_ptr(), V, 0, sm, n_past_dev=counter)
+                            native.check(lib.wm_step_advance(counter.data_ptr(), sm), "wm_step_advance")
+                        st['graphs'][gkey], st['counters'][gkey] = graph, counter
+                        st['counters'][gkey + ('fresh',)] = True
+            if i == 0 and self.tokenizer.no_speech is not None:
+                # the greedy kernel has already written -inf into the LAST position's row only;
+                # the <|sot|> position (no-speech probability, decoding.py:803-807) is untouched
+                for s_ in streams:
+                    main.wait_stream(s_)
+                probs_at_sot = st['logits'][:, self.sot_index].float().softmax(dim=-1)
+                nsp_dev = probs_at_sot[:, self.tokenizer.no_speech]
+                for s_ in streams:
+                    s_.wait_stream(main)
             cur += 1
             steps_done += 1
             if cur > cap:
@@ -552,14 +662,19 @@ class WhisperDecoding:
             if not ignore_eot and (steps_done % self.poll_every == 0):
                 # rows keep emitting EOT once finished, so "all rows EOT in the newest column" is
                 # monotone; poll it now and then instead of synchronising every step
+                for s_ in streams:
+                    main.wait_stream(s_)
                 if bool((st['tokens'][:, cur - 1] == self.tokenizer.eot).all()):
                     break
+        for s_ in streams:
+            main.wait_stream(s_)
         tokens = st['tokens'][:, :cur].to(torch.int64)
         if not ignore_eot:
             # cut at the first column where every row is EOT: where the per-step check would have stopped
             all_eot = (tokens[:, L0:] == self.tokenizer.eot).all(dim=0)
             if bool(all_eot.any()):
                 tokens = tokens[:, :L0 + int(all_eot.float().argmax()) + 1]
+        no_speech_probs = [np.nan] * n_batch
         if self.tokenizer.no_speech is not None:
             no_speech_probs = nsp_dev.tolist()
         return tokens, st['sum_logprobs'].clone(), no_speech_probs

@@ -19,7 +19,7 @@ EXPORTS = (
     "wm_cross_kv_workspace_bytes", "wm_cross_kv", "wm_decoder_workspace_bytes", "wm_decoder_step",
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
-    "wm_profile_configure", "wm_profile_read",
+    "wm_profile_configure", "wm_profile_read", "wm_step_advance",
 )
 
 
@@ -46,6 +46,7 @@ class WmDecoderIO(C.Structure):
         ("logits", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("qkv_amax", C.c_void_p),
+        ("n_past_dev", C.c_void_p),
     ]
 
 
@@ -61,6 +62,7 @@ class WmGreedyIO(C.Structure):
         ("max_initial_timestamp_index", C.c_int32),
         ("apply_rules", C.c_int32),
         ("n_done", C.c_void_p),
+        ("n_past_dev", C.c_void_p),
     ]
 
 
@@ -108,6 +110,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_attn_decode_cross.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp]
     lib.wm_attn_decode_self.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, C.c_float, vp, vp]
     lib.wm_quantize_i8.argtypes = [vp, vp, C.c_int64, C.c_float, vp]
+    lib.wm_step_advance.argtypes = [vp, vp]
     lib.wm_profile_configure.argtypes = [i32, i32, i32]
     lib.wm_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     _lib = lib

@@ -187,18 +187,21 @@ class Session(object):
     def decoder_step(self, tokens: torch.Tensor, pos: torch.Tensor, cross: Sequence[torch.Tensor],
                      past: Optional[Sequence[torch.Tensor]], past_capacity: int,
                      present: Sequence[torch.Tensor], present_capacity: int, logits: torch.Tensor,
-                     n_past: int, stream: int, qkv_amax: Optional[torch.Tensor] = None):
+                     n_past: int, stream: int, qkv_amax: Optional[torch.Tensor] = None, slot: int = 0,
+                     n_past_dev: Optional[torch.Tensor] = None, n_new: Optional[int] = None):
         """tokens int32 [B, L] (any row stride: a column window of a wider buffer works);
         past/present per layer [B,2,H,capacity,64]; present may be the same tensors as past
         (in-place append)."""
         lib = self._engine.lib
         b, l = tokens.shape
+        if n_new is not None:          # graph capture: `tokens` is the whole [B, capacity] buffer
+            l = n_new
         assert tokens.dtype == torch.int32 and tokens.stride(1) == 1
-        ws = self._workspace(("dec", b, l), lib.wm_decoder_workspace_bytes(self._engine.handle, b, l))
+        ws = self._workspace(("dec", b, l, slot), lib.wm_decoder_workspace_bytes(self._engine.handle, b, l))
         io = WmDecoderIO()
         io.batch, io.n_new, io.n_past = b, l, n_past
         io.tokens, io.positional_embedding = tokens.data_ptr(), pos.data_ptr()
-        io.tokens_ld = tokens.stride(0) if b > 1 else l
+        io.tokens_ld = tokens.stride(0)
         past_arr = ptr_array(past) if past is not None else None
         present_arr, cross_arr = ptr_array(present), ptr_array(cross)
         io.past = C.cast(past_arr, C.POINTER(C.c_void_p)) if past_arr is not None else None
@@ -211,4 +214,5 @@ class Session(object):
         if qkv_amax is None:
             qkv_amax = self.qkv_amax          # calibration hook set by torch_whisper_convert.py
         io.qkv_amax = qkv_amax.data_ptr() if qkv_amax is not None else None
+        io.n_past_dev = n_past_dev.data_ptr() if n_past_dev is not None else None
         check(lib.wm_decoder_step(self._engine.handle, C.byref(io), stream), "wm_decoder_step")

@@ -95,6 +95,12 @@ typedef struct wm_decoder_io {
      * int8-KV calibration collects with forward hooks (W/smoothquant.py:117-175,
      * W/torch_whisper_convert.py:145-167).  The caller zeroes it before the first call. */
     float* qkv_amax;
+    /* optional device-resident step counter (NULL = use n_past): int32 holding T.  With it, one
+     * captured hipGraph of a decode step can be replayed for every token: `tokens` is then the base
+     * of the [batch, tokens_ld] buffer (column T is read), `positional_embedding` the base of the
+     * table (row T is read), `n_past` only an upper bound for validation.  Requires n_new == 1 and
+     * in-place KV append.  wm_step_advance increments the counter on the stream.                   */
+    const int32_t* n_past_dev;
 } wm_decoder_io;
 size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new);
 int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream);
@@ -116,8 +122,10 @@ typedef struct wm_greedy_io {
     int32_t sample_begin, eot, timestamp_begin, max_initial_timestamp_index /* -1: none */;
     int32_t apply_rules; /* 0: plain arg-max */
     int32_t* n_done;
+    const int32_t* n_past_dev; /* optional device step counter: cur_len = *n_past_dev + 1 */
 } wm_greedy_io;
 int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream);
+int wm_step_advance(int32_t* counter, wm_stream_t stream);
 
 /* ---- kernel-level entry points (parity tests, micro-benchmarks, roofline measurement) -----------*/
 /* C[M,N] = act(A[M,K] x W[N,K]^T * scale + bias) (+ residual); W fp16 or int8 (w8) row-major [N][K].

@@ -235,3 +235,64 @@ def test_batch_independence(tmpdir_module):
         xb = xa[b:b + 1].clone()
         lb, _ = dec.decode(prompt[b:b + 1], dec.xa2cross_key_value(xb))
         assert torch.equal(lb[0], lg[b])
+
+
+def test_micro_batched_streams_give_identical_tokens(tmpdir_module):
+    """main_loop splits a large batch into stream-parallel groups; utterances are independent, so
+    the tokens must be exactly those of the single-stream run."""
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    dec.sample_len = 10
+    mel = synthetic_mel(16, 2 * dims.n_audio_ctx, dims.n_mels, 99).cuda()
+    xa = enc.get_audio_features(mel)
+    dec.detect_language(xa)
+    dec.micro_batches = 1
+    t1, lp1, nsp1 = dec.main_loop(xa)
+    dec.micro_batches = 2
+    t2, lp2, nsp2 = dec.main_loop(xa)
+    assert torch.equal(t1.cpu(), t2.cpu())
+    assert torch.allclose(lp1.cpu(), lp2.cpu(), atol=1e-5)
+    assert np.allclose(nsp1, nsp2, atol=1e-6)
+    assert len({tuple(r) for r in t1.cpu().tolist()}) > 1          # rows differ: the test is not vacuous
+
+
+def test_detect_language_fast_equals_reference(tmpdir_module):
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    mel = synthetic_mel(16, 2 * dims.n_audio_ctx, dims.n_mels, 31).cuda()
+    xa = enc.get_audio_features(mel)
+    l_ref, p_ref = dec.detect_language_reference(xa)
+    t_ref = dec.tokens.clone()
+    l_fast, p_fast = dec.detect_language(xa)
+    assert l_ref == l_fast and torch.equal(t_ref, dec.tokens)
+    for a, b in zip(p_ref, p_fast):
+        assert max(abs(a[k] - b[k]) for k in a) < 1e-6
+
+
+def test_graph_replay_gives_identical_tokens(tmpdir_module):
+    """One captured decode step replayed per token (device-resident step counter) against the eager loop,
+    twice in a row (the second call replays from the first token on)."""
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    dec.sample_len = 12
+    mel = synthetic_mel(16, 2 * dims.n_audio_ctx, dims.n_mels, 5).cuda()
+    xa = enc.get_audio_features(mel)
+    dec.detect_language(xa)
+    dec.use_graphs = False
+    t0, lp0, _ = dec.main_loop(xa)
+    dec.use_graphs = True
+    t1, lp1, _ = dec.main_loop(xa)          # captures at step 1, replays from step 2
+    t2, lp2, _ = dec.main_loop(xa)          # replays from step 1
+    assert torch.equal(t0.cpu(), t1.cpu()) and torch.equal(t0.cpu(), t2.cpu())
+    assert torch.allclose(lp0.cpu(), lp1.cpu(), atol=1e-5) and torch.allclose(lp0.cpu(), lp2.cpu(), atol=1e-5)
+    # a different batch of audio through the same (cached) graphs
+    mel_b = synthetic_mel(16, 2 * dims.n_audio_ctx, dims.n_mels, 6).cuda()
+    xb = enc.get_audio_features(mel_b)
+    dec.detect_language(xb)
+    tb1, _, _ = dec.main_loop(xb)
+    dec.use_graphs = False
+    tb0, _, _ = dec.main_loop(xb)
+    assert torch.equal(tb0.cpu(), tb1.cpu()) and not torch.equal(tb0.cpu(), t0.cpu())
