@@ -58,7 +58,15 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float r16(float x) { return (float)(h16)x; }   // round through fp16
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. far below an fp16 ulp of any GELU output
+// that matters) on the hardware exp / rcp: ~12 instructions instead of libm's ~40 in the epilogues.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    return copysignf(1.0f - poly * __expf(-ax * ax), x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_tanh(float x) {
     return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }

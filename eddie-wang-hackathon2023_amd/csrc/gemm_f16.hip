@@ -7,11 +7,16 @@
 // fpA_intB CUTLASS converter) -- because at M >> 16 the GEMM is MFMA-bound, weight bytes are
 // irrelevant, and 288 GB of HBM make the fp16 copy free.
 //
-// gfx950 structure: 256 x 128 x 64 workgroup tile, 8 waves (4 x 2, each 64 x 64 = 4 x 4 MFMA
-// 16x16x32 blocks).  Operand tiles go global -> LDS directly (global_load_lds, 16 B per lane,
-// 1 KiB per wave instruction) through a 3-stage ring; a wave waits only for its own loads of the
-// tile it is about to read (counted s_waitcnt vmcnt(6): the 6 loads of the next tile stay in
-// flight across the barrier) and the workgroup meets at ONE raw s_barrier per K-tile.  LDS rows
+// gfx950 structure: 256 x 256 x 64 workgroup tile (256 x 128 when N is not a multiple of 256),
+// 8 waves (4 x 2, each 64 x 128 = 4 x 8 MFMA 16x16x32 blocks, 128 accumulator VGPRs).  Operand
+// tiles go global -> LDS directly (global_load_lds, 16 B per lane, 1 KiB per wave instruction)
+// into a 2-stage ring: tile k+1 is in flight while tile k is multiplied, the workgroup meets at
+// ONE raw s_barrier per K-tile.  Measured on MI355X (scripts/lab/gemm_lab.hip, random data, M = 48000):
+// 2 stages beat 3 (873 vs 799 TF/s at 256x128) and 256x256 beats 256x128 (1066-1137 vs 863-959
+// TF/s before the epilogue): half the operand bytes per flop through L2 and LDS.  The MFMA operands
+// are SWAPPED (D = W.A^T), so each lane ends up with 4 consecutive output channels of one token
+// row and the epilogue needs no LDS transpose (8-byte vector accesses for bias/residual/store).
+// LDS rows
 // are 128 B; the 16-byte chunk c of row r is stored at position c ^ ((r >> 1) & 7) -- applied on
 // the per-lane SOURCE address, since the DMA writes LDS linearly -- which makes every
 // ds_read_b128 fragment read (16 rows x one chunk) hit 64 distinct banks.
@@ -21,15 +26,17 @@
 namespace wm {
 
 namespace f16gemm {
-constexpr int BM = 256, BN = 128, BK = 64, STAGES = 3;
-constexpr int A_STAGE = BM * BK * 2;            // 32 KiB
-constexpr int B_STAGE = BN * BK * 2;            // 16 KiB
-constexpr int STAGE = A_STAGE + B_STAGE;        // 48 KiB
-constexpr int LOADS = 6;                        // wave-wide 1 KiB loads per wave per K-tile (4 A + 2 B)
+constexpr int BM = 256, BK = 64, STAGES = 2, NWAVE = 8;
 }  // namespace f16gemm
 
+// BN = 256 (N % 256 == 0: every large-v2 shape) or 128.  8 waves as 4 (M) x 2 (N); a wave owns
+// 64 x BN/2 outputs = 4 x TN MFMA blocks.
+template <int BN>
 __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
     using namespace f16gemm;
+    constexpr int A_STAGE = BM * BK * 2, B_STAGE = BN * BK * 2, STAGE = A_STAGE + B_STAGE;
+    constexpr int LOADS = (BM + BN) / 8 / NWAVE;          // wave-wide 1 KiB DMA loads per wave per K-tile
+    constexpr int TN = BN / 2 / 16;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -44,14 +51,14 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
     const int tm = bid / nt_n, tn = bid % nt_n;
     const int row0 = tm * BM, col0 = tn * BN;
 
-    // ---- loader: wave-instruction i covers tile rows 8i .. 8i+7 (A: i < 32, W: i >= 32) ------------
+    // ---- loader: wave-instruction i covers tile rows 8i .. 8i+7 (A: i < BM/8, W: the rest) ----------
     const h16* src[LOADS];
     int dst[LOADS];
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
-        const int i = wid + 8 * j;
-        const bool isA = i < 32;
-        const int r = (isA ? i : i - 32) * 8 + (lane >> 3);       // row inside the tile
+        const int i = wid + NWAVE * j;
+        const bool isA = i < BM / 8;
+        const int r = (isA ? i : i - BM / 8) * 8 + (lane >> 3);   // row inside the tile
         const int c = (lane & 7) ^ ((r >> 1) & 7);                 // source chunk for this LDS slot
         if (isA) {
             int gr = row0 + r;
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
         } else {
             src[j] = (const h16*)p.W + (size_t)(col0 + r) * p.K + c * 8;
         }
-        dst[j] = (isA ? 0 : A_STAGE) + (isA ? i : i - 32) * 1024;
+        dst[j] = (isA ? 0 : A_STAGE) + (isA ? i : i - BM / 8) * 1024;
     }
     auto issue = [&](int kt, int stage) {
 #pragma unroll
@@ -72,106 +79,112 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
                                              16, 0, 0);
     };
 
-    float4v acc[4][4];
+    // acc[i][j] = D block of W_j . A_i^T: rows = 4 output channels (4g + r), col = token row (lane & 15)
+    float4v acc[4][TN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
 
     const int swz = (lane & 15) >> 1, g = lane >> 4;
     const int a_off = (wr * 64 + (lane & 15)) * 128;
-    const int b_off = A_STAGE + (wc * 64 + (lane & 15)) * 128;
+    const int b_off = A_STAGE + (wc * (BN / 2) + (lane & 15)) * 128;
 
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's part of tile kt has landed
+        __builtin_amdgcn_s_barrier();                              // ... everybody's; stage (kt+1)&1 is free
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % STAGES);
-        const unsigned char* st = smem + (kt % STAGES) * STAGE;
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);              // flies during the MFMAs below
+        const unsigned char* st = smem + (kt & 1) * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int pos = ((4 * s + g) ^ swz) * 16;
-            half8v af[4], bf[4];
+            half8v af[4], bf[TN];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 16 * 128 + pos);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *(const half8v*)(st + b_off + j * 16 * 128 + pos);
+            for (int j = 0; j < TN; ++j) bf[j] = *(const half8v*)(st + b_off + j * 16 * 128 + pos);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------
-    // The wave's 64 x 64 fp32 tile goes through LDS (the operand ring is free now) so that each lane
-    // finishes 8 CONTIGUOUS columns of one row: bias / activation / residual on vectors, one 16-byte
-    // store per 8 outputs (8 lanes cover a 128-byte row segment), row addressing computed once per row.
-    __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring
-    constexpr int EP_LD = 68;                           // floats per staged row (64 + 4 pad)
-    float* ep = (float*)smem + wid * (64 * EP_LD);
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    // Operands were swapped, so a lane holds 4 CONSECUTIVE output channels of one token row per block:
+    // bias / activation / q-k scaling are applied on those in registers (fp32 -> the Linear's fp16
+    // output), the fp16 tile of the wave (64 x BN/2) is transposed through LDS (the ring is free), and
+    // the residual add + store then run on whole 16-byte row segments: all residual loads of a lane
+    // are issued before the first store (a store in between would make the counted vmcnt wait for it).
+    __builtin_amdgcn_s_barrier();                                   // every wave is done reading the ring
+    constexpr int WN_COLS = BN / 2;                                 // columns per wave
+    constexpr int EPLD = WN_COLS + 8;                               // halves per staged row (16-byte pad)
+    h16* ep = (h16*)smem + (size_t)wid * 64 * EPLD;
     {
-        const int lc = lane & 15, lr = (lane >> 4) * 4;
+        half4v b4[TN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wc * WN_COLS + j * 16 + g * 4;
+            b4[j] = p.bias ? *(const half4v*)(p.bias + col) : half4v{0, 0, 0, 0};
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(i * 16 + lr + r) * EP_LD + j * 16 + lc] = acc[i][j][r];
+            for (int j = 0; j < TN; ++j) {
+                const int col = col0 + wc * WN_COLS + j * 16 + g * 4;
+                half4v o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = r16(acc[i][j][r] + (float)b4[j][r]);            // the Linear's fp16 output
+                    if (p.act == 1) v = r16(gelu_erf(v));
+                    else if (p.act == 2) v = r16(gelu_tanh(v));
+                    if (col < p.colscale_n) v = r16(v * p.colscale);          // q, k * d^-0.25 (torch_model.py:93-95)
+                    o[r] = (h16)v;
+                }
+                *(half4v*)(ep + (i * 16 + (lane & 15)) * EPLD + j * 16 + g * 4) = o;
+            }
+        }
     }
-    // LDS traffic of one wave only: program order + the compiler's lgkmcnt suffice, no barrier needed
-    const int cseg = (lane & 7) * 8;                    // first of this lane's 8 columns inside the wave tile
-    const int col = col0 + wc * 64 + cseg;
-    float bi[8];
+    // one wave's private LDS region: program order + lgkmcnt are enough, no barrier
+    constexpr int SEG = WN_COLS / 8;                                // 16-byte segments per row (8 or 16)
+    constexpr int RPI = 64 / SEG;                                   // rows covered per wave-instruction (8 or 4)
+    constexpr int NIT = 64 / RPI;                                   // iterations (8 or 16)
+    const int cseg = (lane % SEG) * 8, rsub = lane / SEG;
+    const int colw = col0 + wc * WN_COLS + cseg;
+    half8v res[NIT];
+    if (p.residual) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bi[e] = 0.f;
-    if (p.bias) {
-        const half8v b8 = *(const half8v*)(p.bias + col);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bi[e] = (float)b8[e];
+        for (int it = 0; it < NIT; ++it) {
+            int row = row0 + wr * 64 + it * RPI + rsub;
+            if (row > p.M - 1) row = p.M - 1;
+            res[it] = *(const half8v*)(p.residual + (size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.ldr + colw);
+        }
     }
-    const bool scale_cols = col < p.colscale_n;         // colscale_n is a multiple of 64
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int rl = it * 8 + (lane >> 3);
+    for (int it = 0; it < NIT; ++it) {
+        const int rl = it * RPI + rsub;
         const int row = row0 + wr * 64 + rl;
-        if (row >= p.M) continue;
-        const float4 v0 = *(const float4*)(ep + rl * EP_LD + cseg);
-        const float4 v1 = *(const float4*)(ep + rl * EP_LD + cseg + 4);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = r16(v[e] + bi[e]);                                  // the Linear's fp16 output
-            if (p.act == 1) t = r16(gelu_erf(t));
-            else if (p.act == 2) t = r16(gelu_tanh(t));
-            if (scale_cols) t = r16(t * p.colscale);                      // q, k * d^-0.25 (torch_model.py:93-95)
-            v[e] = t;
-        }
+        half8v o = *(const half8v*)(ep + rl * EPLD + cseg);
         if (p.residual) {
-            const int rr = p.res_mod > 0 ? row % p.res_mod : row;
-            const half8v r8 = *(const half8v*)(p.residual + (size_t)rr * p.ldr + col);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = r16(v[e] + (float)r8[e]);
+            for (int e = 0; e < 8; ++e) o[e] = (h16)((float)o[e] + (float)res[it][e]);
         }
+        if (row >= p.M) continue;
         size_t off;
         if (p.out_mode == 0) {
-            off = p.c_rows > 0 ? (size_t)(row / p.c_rows) * p.c_bstride + (size_t)(row % p.c_rows) * p.ldc + col
-                               : (size_t)row * p.ldc + col;
-        } else {   // head-split [B, 2, H, T, 64] (whisper/model.py:519); 8 columns stay inside one head
+            off = p.c_rows > 0 ? (size_t)(row / p.c_rows) * p.c_bstride + (size_t)(row % p.c_rows) * p.ldc + colw
+                               : (size_t)row * p.ldc + colw;
+        } else {   // head-split [B, 2, H, T, 64] (whisper/model.py:519); 8 channels stay inside one head
             const int HC = p.hs_H * 64;
-            const int kv = p.hs_kv < 0 ? col / HC : p.hs_kv, cc = p.hs_kv < 0 ? col % HC : col;
-            const int b = row / p.hs_T, t = row % p.hs_T, h = cc >> 6, d = cc & 63;
-            off = ((((size_t)b * 2 + kv) * p.hs_H + h) * p.hs_T + t) * 64 + d;
+            const int kv = p.hs_kv < 0 ? colw / HC : p.hs_kv, cc = p.hs_kv < 0 ? colw % HC : colw;
+            const int bb = row / p.hs_T, t = row % p.hs_T, h = cc >> 6, d = cc & 63;
+            off = ((((size_t)bb * 2 + kv) * p.hs_H + h) * p.hs_T + t) * 64 + d;
         }
-        half8v o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (h16)v[e];
         *(half8v*)(p.C + off) = o;
     }
 }
@@ -179,18 +192,27 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
 int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream) {
     using namespace f16gemm;
     WM_REQUIRE(!p.w8, "gemm_f16: int8 weights must be expanded first");
-    WM_REQUIRE(p.N % BN == 0, "gemm_f16: N=%d must be a multiple of %d", p.N, BN);
+    WM_REQUIRE(p.N % 128 == 0, "gemm_f16: N=%d must be a multiple of 128", p.N);
     WM_REQUIRE(p.K % BK == 0, "gemm_f16: K=%d must be a multiple of %d", p.K, BK);
     WM_REQUIRE(p.lda % 8 == 0, "gemm_f16: lda=%d must be a multiple of 8 (16-byte loads)", p.lda);
+    WM_REQUIRE(p.ldc % 8 == 0 && p.ldr % 8 == 0, "gemm_f16: ldc/ldr must be multiples of 8 (16-byte epilogue accesses)");
     WM_REQUIRE(p.M > 0, "gemm_f16: empty M");
-    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-    const size_t lds = (size_t)STAGES * STAGE;
+    const bool wide = (p.N % 256 == 0);
+    const int bn = wide ? 256 : 128;
+    const int grid = ((p.M + BM - 1) / BM) * (p.N / bn);
+    // ring, or the epilogue's per-wave fp16 staging tile (8 waves x 64 rows x (bn/2 + 8) halves), whichever is larger
+    const size_t ring = (size_t)STAGES * (BM + bn) * BK * 2, stage = (size_t)8 * 64 * (bn / 2 + 8) * 2;
+    const size_t lds = ring > stage ? ring : stage;
     static bool attr_set = false;
     if (!attr_set) {
-        WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         8 * 64 * (128 + 8) * 2 > STAGES * (BM + 256) * BK * 2 ? 8 * 64 * (128 + 8) * 2 : STAGES * (BM + 256) * BK * 2));
+        WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         STAGES * (BM + 128) * BK * 2));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_f16_kernel, dim3(grid), dim3(512), lds, stream, p);
+    if (wide) hipLaunchKernelGGL(gemm_f16_kernel<256>, dim3(grid), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL(gemm_f16_kernel<128>, dim3(grid), dim3(512), lds, stream, p);
     WM_LAUNCH_CHECK(stream, "gemm_f16");
     return 0;
 }
