@@ -1,0 +1,114 @@
+"""Audio front-end: PCM loading, pad/trim, log-mel spectrogram.  Mirror of W/whisper_utils.py:17-146
+(`load_audio`, `pad_or_trim`, `mel_filters`, `log_mel_spectrogram`, same constants).
+
+Differences: the reference shells out to ffmpeg (absent here) -- `load_audio` reads 16 kHz mono PCM16
+`.wav` with the standard library and `.npy` waveforms; the 80x201 mel filterbank is regenerated with
+the recipe the reference quotes (`librosa.filters.mel(sr=16000, n_fft=400, n_mels=80)`,
+W/whisper_utils.py:85-90: Slaney scale, Slaney area normalisation) instead of shipping the `.npz`;
+tests/golden/mel.npz (made with the reference's own function and asset) pins both.  The STFT runs
+through torch on whatever device the audio is on; a fused HIP STFT+mel kernel is SURVEY 8f-1 (next).
+"""
+from __future__ import annotations
+
+import wave
+from functools import lru_cache
+from typing import Optional, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SAMPLE_RATE = 16000
+N_FFT = 400
+N_MELS = 80
+HOP_LENGTH = 160
+CHUNK_LENGTH = 30
+N_SAMPLES = CHUNK_LENGTH * SAMPLE_RATE  # 480000 samples in a 30-second chunk
+
+
+def load_audio(file: str, sr: int = SAMPLE_RATE) -> np.ndarray:
+    """Mono float32 waveform in [-1, 1] at `sr` Hz from a PCM16 .wav (or a float .npy)."""
+    if file.endswith(".npy"):
+        return np.load(file).astype(np.float32).flatten()
+    if not file.endswith(".wav"):
+        raise RuntimeError(f"cannot decode {file}: only PCM16 .wav / .npy are supported without ffmpeg "
+                           f"(FLAC/m4a decoding is next-scope, SURVEY 8f-1)")
+    with wave.open(file, "rb") as w:
+        if w.getsampwidth() != 2 or w.getframerate() != sr:
+            raise RuntimeError(f"{file}: need 16-bit PCM at {sr} Hz, got {8 * w.getsampwidth()}-bit at {w.getframerate()} Hz")
+        pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16).reshape(-1, w.getnchannels())
+    return pcm.astype(np.float32).mean(axis=1) / 32768.0
+
+
+def pad_or_trim(array, length: int = N_SAMPLES, *, axis: int = -1):
+    """Pad with zeros or cut to `length` samples along `axis` (W/whisper_utils.py:56-79)."""
+    if torch.is_tensor(array):
+        n = array.shape[axis]
+        if n > length:
+            array = array.narrow(axis, 0, length)
+        elif n < length:
+            pad = [0, 0] * array.ndim
+            pad[2 * (array.ndim - 1 - (axis % array.ndim)) + 1] = length - n
+            array = F.pad(array, pad)
+        return array
+    n = array.shape[axis]
+    if n > length:
+        array = np.take(array, np.arange(length), axis=axis)
+    elif n < length:
+        widths = [(0, 0)] * array.ndim
+        widths[axis] = (0, length - n)
+        array = np.pad(array, widths)
+    return array
+
+
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+@lru_cache(maxsize=None)
+def _mel_filterbank(n_mels: int = N_MELS, n_fft: int = N_FFT, sr: int = SAMPLE_RATE) -> np.ndarray:
+    fft_freqs = np.linspace(0, sr / 2, 1 + n_fft // 2)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(0.0), _hz_to_mel(sr / 2), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fft_freqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    weights = np.maximum(0, np.minimum(lower, upper))
+    weights *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return weights.astype(np.float32)
+
+
+def mel_filters(device, n_mels: int = N_MELS) -> torch.Tensor:
+    assert n_mels == 80, f"Unsupported n_mels: {n_mels}"
+    return torch.from_numpy(_mel_filterbank(n_mels)).to(device)
+
+
+def log_mel_spectrogram(audio: Union[str, np.ndarray, torch.Tensor], n_mels: int = N_MELS, padding: int = 0,
+                        device: Optional[Union[str, torch.device]] = None) -> torch.Tensor:
+    """[80, n_frames] log-mel: Hann STFT (n_fft 400, hop 160), |.|^2, mel projection, log10, clamp to
+    max - 8, (x + 4) / 4  (W/whisper_utils.py:99-146)."""
+    if not torch.is_tensor(audio):
+        if isinstance(audio, str):
+            audio = load_audio(audio)
+        audio = torch.from_numpy(audio)
+    if device is not None:
+        audio = audio.to(device)
+    if padding > 0:
+        audio = F.pad(audio, (0, padding))
+    window = torch.hann_window(N_FFT).to(audio.device)
+    stft = torch.stft(audio, N_FFT, HOP_LENGTH, window=window, return_complex=True)
+    magnitudes = stft[..., :-1].abs() ** 2
+    mel_spec = mel_filters(audio.device, n_mels) @ magnitudes
+    log_spec = torch.clamp(mel_spec, min=1e-10).log10()
+    log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    return (log_spec + 4.0) / 4.0

@@ -1,0 +1,78 @@
+"""The data-parallel layer (dp.py) on CPU: world_size 2 over gloo.  Utterances are sharded with no
+data-path collective; the only exchanges are the mel scatter and the result gather."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import dp
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 8, 9, 100):
+        for world in (1, 2, 3, 8):
+            spans = [dp.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_items, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        feat = (4, 6)
+        mels = torch.arange(n_items * 24, dtype=torch.float32).reshape(n_items, *feat) if rank == 0 else None
+        mine = dp.scatter_utterances(mels, n_items, feat, torch.float32, "cpu")
+        lo, hi = dp.shard_bounds(n_items, rank, world)
+        want = torch.arange(n_items * 24, dtype=torch.float32).reshape(n_items, *feat)[lo:hi]
+        assert torch.equal(mine, want), (rank, mine.shape)
+        # each rank "decodes": token row = utterance id, ragged widths per rank
+        width = 5 + rank
+        toks = (torch.arange(lo, hi)[:, None] * 10 + torch.arange(width)[None, :]).to(torch.int64)
+        lps = torch.arange(lo, hi, dtype=torch.float32) * -1.5
+        out = dp.gather_results(toks, lps, n_items, 8, pad_value=-1)
+        t = dp.max_over_ranks(float(rank + 1), "cpu")
+        assert t == float(world)
+        if rank == 0:
+            all_t, all_lp = out
+            assert all_t.shape == (n_items, 8) and all_lp.shape == (n_items,)
+            for r in range(world):
+                l2, h2 = dp.shard_bounds(n_items, r, world)
+                w = 5 + r
+                assert torch.equal(all_t[l2:h2, :w], (torch.arange(l2, h2)[:, None] * 10 + torch.arange(w)[None, :]))
+                assert (all_t[l2:h2, w:] == -1).all()
+            assert torch.equal(all_lp, torch.arange(n_items, dtype=torch.float32) * -1.5)
+        else:
+            assert out is None
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [7, 8])
+def test_scatter_gather_world2_gloo(n_items):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, n_items, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_single_process_passthrough():
+    mels = torch.randn(3, 2, 5)
+    assert torch.equal(dp.scatter_utterances(mels, 3, (2, 5), torch.float32, "cpu"), mels)
+    toks = torch.tensor([[1, 2, 3], [4, 5, 6]])
+    out, lp = dp.gather_results(toks, torch.tensor([0.5, 1.5]), 2, 5, pad_value=9)
+    assert out.tolist() == [[1, 2, 3, 9, 9], [4, 5, 6, 9, 9]] and lp.tolist() == [0.5, 1.5]
+    assert dp.max_over_ranks(3.25, "cpu") == 3.25

@@ -257,3 +257,30 @@ def test_decoding_wrapper_host_only(tmp_path):
     assert 50362 in sup and 50358 in sup and 220 not in sup and len(sup) == 82 + 6
     assert dec.max_initial_timestamp_index == round(1.0 / (30 / 64))     # precision = 30 s / n_audio_ctx (decoding.py:343-348)
     assert not dec.use_int8_kv_cache
+
+
+def test_log_mel_matches_reference_golden(golden_dir, tmp_path):
+    """whisper_utils against the reference's own log_mel_spectrogram + mel_filters.npz (tests/golden/mel.npz)."""
+    import whisper_utils as wu
+    g = np.load(os.path.join(golden_dir, "mel.npz"))
+    filt = wu.mel_filters("cpu").numpy()
+    assert filt.shape == (80, 201)
+    np.testing.assert_allclose(filt.sum(axis=1), g["filters_rowsum"], rtol=1e-4, atol=1e-6)
+    assert abs(float(np.abs(filt).sum()) - float(g["filters_checksum"])) < 1e-3
+    rng = np.random.Generator(np.random.Philox(int(g["audio_seed"])))
+    audio = (rng.standard_normal(int(g["n_audio"])) * 0.1).astype(np.float32)
+    mel = wu.log_mel_spectrogram(wu.pad_or_trim(audio, int(g["n_padded"])))
+    assert tuple(mel.shape) == g["mel"].shape
+    np.testing.assert_allclose(mel.numpy(), g["mel"], atol=2e-4)
+    # wav round trip + pad_or_trim on tensors
+    import wave
+    pcm = (np.clip(audio, -1, 1) * 32767).astype(np.int16)
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    back = wu.load_audio(str(tmp_path / "a.wav"))
+    assert back.shape == audio.shape and np.abs(back - pcm / 32768.0).max() == 0
+    t = wu.pad_or_trim(torch.ones(2, 10), 14)
+    assert tuple(t.shape) == (2, 14) and float(t[:, 10:].abs().sum()) == 0
+    assert tuple(wu.pad_or_trim(torch.ones(2, 10), 4).shape) == (2, 4)
+    with pytest.raises(RuntimeError):
+        wu.load_audio("clip.flac")
