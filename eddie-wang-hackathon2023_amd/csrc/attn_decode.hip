@@ -169,7 +169,14 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
         int j = 0;
         if (I8) {
             const int8_t* pv = (const int8_t*)pastV + lane;
-            for (; j + 8 <= T; j += 8) {          // 8 loads in flight per lane
+            for (; j + 32 <= T; j += 32) {        // 32 loads in flight per lane: the loop is HBM-latency bound
+                int8_t vq[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) vq[u] = pv[(size_t)(j + u) * 64];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) o += s_p[j + u] * r16((float)vq[u] * t_dq);
+            }
+            for (; j + 8 <= T; j += 8) {
                 int8_t vq[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) vq[u] = pv[(size_t)(j + u) * 64];
@@ -179,6 +186,13 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
             for (; j < T; ++j) o += s_p[j] * r16((float)pv[(size_t)j * 64] * t_dq);
         } else {
             const h16* pv = (const h16*)pastV + lane;
+            for (; j + 32 <= T; j += 32) {
+                h16 vh[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) vh[u] = pv[(size_t)(j + u) * 64];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) o += s_p[j + u] * (float)vh[u];
+            }
             for (; j + 8 <= T; j += 8) {
                 h16 vh[8];
 #pragma unroll

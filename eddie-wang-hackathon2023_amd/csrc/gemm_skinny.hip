@@ -151,6 +151,9 @@ int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
     const long slab = (long)max(M, 1) * n_blocks * 16 * 4;
     const int cap = (int)max(1L, (16L << 20) / slab);
     s = min(s, cap);
+    // every slab is re-read by the row kernel (and its latency chain grows with the slab count);
+    // measured (scripts/bench_skinny.py): 8 slices are already at the latency floor for every decode shape
+    s = min(s, 8);
     return max(1, s);
 }
 

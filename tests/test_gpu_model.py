@@ -296,3 +296,56 @@ def test_graph_replay_gives_identical_tokens(tmpdir_module):
     dec.use_graphs = False
     tb0, _, _ = dec.main_loop(xb)
     assert torch.equal(tb0.cpu(), tb1.cpu()) and not torch.equal(tb0.cpu(), t0.cpu())
+
+
+def _engine_vs_oracle(tmp, dims_dict, name, seed, weight_only, int8_kv, batch, n_steps, tol):
+    """Build an engine of arbitrary dims from the seeded checkpoint, teacher-force it with the oracle's ids."""
+    synthetic.DIMS[name] = dims_dict
+    dims = Dims(**dims_dict)
+    sd = synthetic_state_dict(dims, seed)
+    mel = synthetic_mel(batch, 2 * dims.n_audio_ctx, dims.n_mels, 4242)
+    scales = None
+    if int8_kv:
+        scales = OracleModel(dims, sd, OracleConfig(act="float16", weight_only=weight_only)).calibrate_kv_scales(mel, 3)
+    oracle = OracleModel(dims, sd, OracleConfig(act="float16", weight_only=weight_only, int8_kv=int8_kv, kv_scales=scales))
+    prompt = [dims.n_vocab - 1607, dims.n_vocab - 1606, dims.n_vocab - 1506]      # sot, <|en|>, transcribe of either vocabulary
+    ref = greedy_reference_run(oracle, mel, prompt, n_steps)
+    eng = build_engine(tmp, name, seed, weight_only, int8_kv, scales)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    xa = enc.get_audio_features(mel.cuda())
+    d_xa = float((xa.float().cpu() - ref["xa"]).abs().max())
+    cross = dec.xa2cross_key_value(xa)
+    d_ckv = max(float((c.float().cpu() - r).abs().max()) for c, r in zip(cross, ref["cross_kv"]))
+    logits, kv = dec.decode(torch.tensor([prompt] * batch).cuda(), cross)
+    worst = float((logits.float().cpu() - ref["logits"][0]).abs().max())
+    n_safe = n_ok = 0
+    for s in range(n_steps - 1):
+        logits, kv = dec.decode(ref["ids"][:, s:s + 1].cuda(), cross, kv)
+        worst = max(worst, float((logits[:, 0].float().cpu() - ref["logits"][s + 1][:, 0]).abs().max()))
+        safe = (ref["margins"][:, s + 1] > 2 * tol).numpy()
+        got = logits[:, 0].float().argmax(-1).cpu().numpy()
+        n_safe += int(safe.sum())
+        n_ok += int((got[safe] == ref["ids"][:, s + 1].numpy()[safe]).sum())
+    return d_xa, d_ckv, worst, n_ok, n_safe
+
+
+def test_tiny_en_shape_engine_matches_oracle(tmpdir_module):
+    """BASELINE.json configs[0]: tiny.en dimensions (384 wide, 6 heads, 4+4 layers, gpt2 vocabulary of
+    51 864, 1500 audio positions): exercises the 256x128 GEMM tile, N not a multiple of 256, 24-block GEMVs."""
+    d_xa, d_ckv, worst, n_ok, n_safe = _engine_vs_oracle(
+        tmpdir_module, dict(synthetic.DIMS["tiny.en"]), "tiny.en", 11, weight_only=True, int8_kv=True,
+        batch=2, n_steps=4, tol=LOGIT_TOL_INT8_KV)
+    assert d_xa < 3e-2 and d_ckv < 3e-2 and worst < LOGIT_TOL_INT8_KV, (d_xa, d_ckv, worst)
+    assert n_ok == n_safe
+
+
+def test_large_v2_width_engine_matches_oracle(tmpdir_module):
+    """Full large-v2 WIDTH (1280 wide, 20 heads, 1500 audio positions, 51 865 tokens) with 2 + 2 layers so that
+    the CPU oracle finishes in seconds: every kernel runs at its production shape (256x256 GEMM tiles with an
+    M tail, 80/240/320-block GEMVs, 20-head attention over 1500 keys, split-K slabs of the real widths)."""
+    dims = dict(synthetic.DIMS["large-v2"], n_audio_layer=2, n_text_layer=2)
+    d_xa, d_ckv, worst, n_ok, n_safe = _engine_vs_oracle(
+        tmpdir_module, dims, "large-v2-2layer", 12, weight_only=True, int8_kv=True, batch=3, n_steps=4,
+        tol=LOGIT_TOL_INT8_KV)
+    assert d_xa < 3e-2 and d_ckv < 3e-2 and worst < LOGIT_TOL_INT8_KV, (d_xa, d_ckv, worst)
+    assert n_ok == n_safe and n_safe > 0
