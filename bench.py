@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--engine-cache", type=str, default="/tmp/wm_bench_engines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank (self-test)")
     return ap.parse_args()
 
 
@@ -141,9 +142,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import native
     import dp
@@ -158,7 +162,7 @@ def main():
     if rank == 0 and not (eng_dir / "decoder_config.json").exists():
         eng_dir.parent.mkdir(parents=True, exist_ok=True)
         build_s = build_engines(args, eng_dir)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     enc, dec = WhisperEncoding(eng_dir), WhisperDecoding(eng_dir)
     dec.sample_len = args.decode_steps
@@ -167,7 +171,10 @@ def main():
 
     # ---- inputs: rank 0 draws the global batch, shards it (scatter over RCCL), resident before timing --
     n_total = B * world
-    mels = synthetic.synthetic_mel(n_total, 2 * dims["n_audio_ctx"], dims["n_mels"], 1234) if rank == 0 else None
+    mels = None
+    if rank == 0:     # N(0, 0.5) clipped to [-0.5, 1.5] like synthetic.synthetic_mel, drawn on the GPU (n_total can be 1024 clips)
+        g = torch.Generator(device=dev).manual_seed(1234)
+        mels = (torch.randn((n_total, dims["n_mels"], 2 * dims["n_audio_ctx"]), generator=g, device=dev) * 0.5).clamp_(-0.5, 1.5).half()
     mel = dp.scatter_utterances(mels, n_total, (dims["n_mels"], 2 * dims["n_audio_ctx"]), torch.float16, dev).contiguous()
     del mels
     width = dec.initial_token_length + T
@@ -182,14 +189,14 @@ def main():
         out = step()
     if not args.no_roofline:
         native.check(lib.wm_profile_configure(1, 8, 4096))       # every 8th layer's cross-attention launch
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
 
@@ -239,7 +246,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, T)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -27,7 +27,7 @@ def scatter_utterances(mels: Optional[torch.Tensor], n_items: int, feature_shape
                        dtype: torch.dtype, device) -> torch.Tensor:
     """Rank 0 holds `mels` [n_items, *feature_shape]; every rank returns its own slice on `device`.
     Ragged slices are padded to the widest one for the collective and trimmed afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return mels.to(device)
     rank, world = dist.get_rank(), dist.get_world_size()
     widest = max(shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world))
@@ -49,7 +49,7 @@ def gather_results(tokens: torch.Tensor, sum_logprobs: torch.Tensor, n_items: in
                    ) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
     """All ranks send their [n_local, <=width] token rows and [n_local] log-probs; rank 0 returns
     ([n_items, width] int64, [n_items] fp32) in utterance order, other ranks None."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         out = torch.full((tokens.shape[0], width), pad_value, dtype=torch.int64, device=tokens.device)
         out[:, : tokens.shape[1]] = tokens
         return out, sum_logprobs
@@ -74,7 +74,7 @@ def gather_results(tokens: torch.Tensor, sum_logprobs: torch.Tensor, n_items: in
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
