@@ -24,11 +24,11 @@
 
 namespace wm {
 
-constexpr int KC = 256;                 // activation chunk staged per barrier (inputs)
-constexpr int A_ROW = KC * 2 + 16;      // LDS row stride in bytes
 
 template <bool W8, int MT, int NW>      // NW waves per workgroup share one staged activation chunk
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p) {
+    constexpr int KC = MT > 4 ? 128 : 256;    // activation chunk staged per barrier (inputs); LDS <= 35 KB
+    constexpr int A_ROW = KC * 2 + 16;        // LDS row stride in bytes
     constexpr int KT = W8 ? 64 : 32;          // inputs per weight tile
     constexpr int TPC = KC / KT;              // tiles per chunk: 4 (int8) / 8 (fp16)
     __shared__ __attribute__((aligned(16))) unsigned char sA[MT * 16 * A_ROW];
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
     }
 }
 
-static inline int skinny_waves(int M) { return M > 32 ? 8 : 4; }   // bigger activation block -> share it wider
+static inline int skinny_waves(int M) { return M > 32 ? 8 : 4; }
+constexpr int SKINNY_MAX_M = 128;   // bigger activation block -> share it wider
 
 int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
     const int kt_total = K / (w8 ? 64 : 32);
@@ -165,13 +166,15 @@ static int launch_mt(const GemmSkinnyParams& p, hipStream_t stream) {
         case 1: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 1, 4>), dim3(g4), dim3(256), 0, stream, p); break;
         case 2: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 2, 4>), dim3(g4), dim3(256), 0, stream, p); break;
         case 3: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 3, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 4, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 4, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 6, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 8, 8>), dim3(g8), dim3(512), 0, stream, p); break;
     }
     return 0;
 }
 
 int launch_gemm_skinny(const GemmSkinnyParams& p, hipStream_t stream) {
-    WM_REQUIRE(p.M >= 1 && p.M <= 64, "gemm_skinny: M=%d out of range [1,64]", p.M);
+    WM_REQUIRE(p.M >= 1 && p.M <= SKINNY_MAX_M, "gemm_skinny: M=%d out of range [1,%d]", p.M, SKINNY_MAX_M);
     const int KT = p.w8 ? 64 : 32;
     WM_REQUIRE(p.K % KT == 0, "gemm_skinny: K=%d must be a multiple of %d", p.K, KT);
     WM_REQUIRE(p.lda % 8 == 0, "gemm_skinny: lda=%d must be a multiple of 8", p.lda);

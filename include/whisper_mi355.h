@@ -134,7 +134,7 @@ int wm_step_advance(int32_t* counter, wm_stream_t stream);
 int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, const void* scale,
             const void* bias, const void* residual, int ldr, int act, void* C, int ldc,
             wm_stream_t stream);
-/* Weight-streaming GEMM, M <= 64, W in tile-linear layout (weight.py: tile_linear_*).  `part` must
+/* Weight-streaming GEMM, M <= 128, W in tile-linear layout (weight.py: tile_linear_*).  `part` must
  * hold ksplit*M*n_blocks*16 floats; result[m][n] = sum_s part[s][m][n].  Replaces
  * weight_only_gemv_launcher (weightOnlyMatrixVectorMultiplication.cu:371-378).                     */
 int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_blocks, int w8,

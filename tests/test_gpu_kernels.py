@@ -112,7 +112,7 @@ def _run_skinny(lib, A, Wmat, w8, ksplit):
 @pytest.mark.parametrize("M,N,K,w8,ksplit", [
     (1, 272, 320, 1, 1), (3, 272, 320, 1, 3), (17, 128, 1280, 1, 5), (64, 1280, 1280, 1, 4),
     (1, 272, 320, 0, 1), (5, 200, 256, 0, 2), (33, 128, 1280, 0, 7), (64, 5120, 1280, 0, 3),
-    (48, 1280, 5120, 1, 10),
+    (48, 1280, 5120, 1, 10), (96, 1280, 1280, 1, 4), (128, 3840, 1280, 1, 8), (128, 1280, 5120, 1, 8), (100, 272, 256, 0, 2),
 ])
 def test_gemm_skinny(lib, M, N, K, w8, ksplit):
     r = rng(M * 7 + N + K + w8)
