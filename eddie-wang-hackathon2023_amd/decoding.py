@@ -628,6 +628,8 @@ class WhisperDecoding:
                             st['counters'][gkey].fill_(cur - 1)
                         st['counters'][gkey + ('fresh',)] = False
                     with torch.cuda.stream(streams[slot]):
+                        if i == 2 and slot == 1 and getattr(self, '_phase_sleep_cycles', 0):
+                            torch.cuda._sleep(self._phase_sleep_cycles)     # experiment: de-phase the groups
                         st['graphs'][gkey].replay()
                 else:
                     sess.decoder_step(gr['tokens'][:, cur - 1:cur], pos[cur - 1:cur], gr['cross'], gr['kv'], cap,
