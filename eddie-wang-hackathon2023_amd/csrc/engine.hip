@@ -656,4 +656,14 @@ int wm_quantize_i8(const void* x, void* q, int64_t n, float inv_scale, wm_stream
     return launch_quantize_i8((const h16*)x, (int8_t*)q, (long)n, inv_scale, (hipStream_t)stream);
 }
 
+size_t wm_log_mel_workspace_bytes(int batch, int n_samples, int n_mels) {
+    return log_mel_workspace_bytes(batch, n_samples, n_mels);
+}
+
+int wm_log_mel(const float* audio, int batch, int n_samples, int64_t audio_ld, const float* filters, int n_mels,
+               void* mel_f16, float* mel_f32, void* workspace, size_t workspace_bytes, wm_stream_t stream) {
+    return launch_log_mel(audio, batch, n_samples, (long)audio_ld, filters, n_mels, (h16*)mel_f16, mel_f32, workspace,
+                          workspace_bytes, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -125,6 +125,11 @@ struct GreedyParams {
 int launch_greedy(const GreedyParams& p, hipStream_t stream);
 int launch_step_advance(int32_t* counter, hipStream_t stream);
 
+// ---------------------------------------------------------------- frontend.hip
+size_t log_mel_workspace_bytes(int batch, int n_samples, int n_mels);
+int launch_log_mel(const float* audio, int batch, int n_samples, long audio_ld, const float* filters, int n_mels,
+                   h16* out16, float* out32, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 int launch_quantize_i8(const h16* x, int8_t* q, long n, float inv_scale, hipStream_t stream);
 
 }  // namespace wm

@@ -19,7 +19,7 @@ EXPORTS = (
     "wm_cross_kv_workspace_bytes", "wm_cross_kv", "wm_decoder_workspace_bytes", "wm_decoder_step",
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
-    "wm_profile_configure", "wm_profile_read", "wm_step_advance",
+    "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
 )
 
 
@@ -110,6 +110,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_attn_decode_cross.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp]
     lib.wm_attn_decode_self.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, C.c_float, vp, vp]
     lib.wm_quantize_i8.argtypes = [vp, vp, C.c_int64, C.c_float, vp]
+    lib.wm_log_mel_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.wm_log_mel_workspace_bytes.restype = sz
+    lib.wm_log_mel.argtypes = [vp, i32, i32, C.c_int64, vp, i32, vp, vp, vp, sz, vp]
     lib.wm_step_advance.argtypes = [vp, vp]
     lib.wm_profile_configure.argtypes = [i32, i32, i32]
     lib.wm_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]

@@ -37,8 +37,9 @@ def load_mel(input_file: str) -> torch.Tensor:
     if input_file.endswith('.npy'):
         return torch.from_numpy(np.load(input_file)).float()
     import whisper_utils
-    audio = whisper_utils.load_audio(input_file)
-    return whisper_utils.log_mel_spectrogram(whisper_utils.pad_or_trim(audio))
+    audio = whisper_utils.pad_or_trim(whisper_utils.load_audio(input_file))
+    # STFT + mel projection on the GPU (wm_log_mel); the torch.stft path stays in whisper_utils as the CPU mirror
+    return whisper_utils.log_mel_spectrogram_device(torch.from_numpy(audio).float().cuda(), dtype=torch.float32)
 
 
 def generate(log_level: str = 'error', engine_dir: str = 'whisper_outputs', input_file: str = 'synthetic',

@@ -24,6 +24,7 @@ N_MELS = 80
 HOP_LENGTH = 160
 CHUNK_LENGTH = 30
 N_SAMPLES = CHUNK_LENGTH * SAMPLE_RATE  # 480000 samples in a 30-second chunk
+N_FRAMES = N_SAMPLES // HOP_LENGTH       # 3000 frames in a mel spectrogram input
 
 
 def load_audio(file: str, sr: int = SAMPLE_RATE) -> np.ndarray:
@@ -112,3 +113,30 @@ def log_mel_spectrogram(audio: Union[str, np.ndarray, torch.Tensor], n_mels: int
     log_spec = torch.clamp(mel_spec, min=1e-10).log10()
     log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
     return (log_spec + 4.0) / 4.0
+
+
+def log_mel_spectrogram_device(audio: torch.Tensor, n_mels: int = N_MELS, dtype: torch.dtype = torch.float16,
+                               stream: Optional[int] = None) -> torch.Tensor:
+    """The same transform as a HIP kernel (`wm_log_mel`, csrc/frontend.hip): `audio` fp32 [B, n] or [n]
+    on the GPU, already padded / trimmed (n a multiple of HOP_LENGTH) -> [B, n_mels, n // HOP_LENGTH]
+    (or [n_mels, frames] for a 1-D input) in `dtype` (fp16: what the encoder engine takes; fp32: what
+    log_mel_spectrogram returns).  Each clip is clamped to its own max - 8, i.e. the reference applied
+    per clip.  No CPU fallback: without the native library this raises."""
+    import ctypes as C
+    import native
+    assert audio.is_cuda and audio.dtype == torch.float32, "audio must be an fp32 tensor on the GPU"
+    assert dtype in (torch.float16, torch.float32)
+    single = audio.dim() == 1
+    a = (audio[None] if single else audio).contiguous()
+    lib = native.load_library()
+    B, n = a.shape
+    filt = mel_filters(a.device, n_mels).float().contiguous()
+    out = torch.empty((B, n_mels, n // HOP_LENGTH), dtype=dtype, device=a.device)
+    ws_bytes = lib.wm_log_mel_workspace_bytes(B, n, n_mels)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+    s = torch.cuda.current_stream(a.device).cuda_stream if stream is None else stream
+    o16 = out.data_ptr() if dtype == torch.float16 else None
+    o32 = out.data_ptr() if dtype == torch.float32 else None
+    native.check(lib.wm_log_mel(a.data_ptr(), B, n, a.stride(0), filt.data_ptr(), n_mels, o16, o32, ws.data_ptr(),
+                                C.c_size_t(ws_bytes), s), "wm_log_mel")
+    return out[0] if single else out

@@ -155,6 +155,17 @@ int wm_attn_decode_self(const float* qkv, int B, int L, int T, int H, const void
 /* q = sat_s8(rne(x * inv_scale)) (quantizeTensorPlugin / attention.py:340-348). */
 int wm_quantize_i8(const void* x, void* q, int64_t n, float inv_scale, wm_stream_t stream);
 
+/* ---- audio front end ----------------------------------------------------------------
+ * log_mel_spectrogram (W/whisper_utils.py:99-146) for a batch of equally long clips already padded /
+ * trimmed by the caller (pad_or_trim, W/whisper_utils.py:56-81): audio fp32 [batch][audio_ld], 16 kHz,
+ * n_samples a multiple of 160; filters fp32 [n_mels][201] (the mel_filters.npz matrix,
+ * W/whisper_utils.py:84-96).  Writes n_frames = n_samples / 160 frames per clip as fp16 and/or fp32
+ * [batch][n_mels][n_frames] (either pointer may be NULL); the max - 8 clamp is taken per clip. */
+size_t wm_log_mel_workspace_bytes(int batch, int n_samples, int n_mels);
+int wm_log_mel(const float* audio, int batch, int n_samples, int64_t audio_ld, const float* filters,
+               int n_mels, void* mel_f16, float* mel_f32, void* workspace, size_t workspace_bytes,
+               wm_stream_t stream);
+
 /* ---- in-situ timing of the dominant decode kernel (cross-attention), for the roofline report ------
  * When enabled, wm_decoder_step brackets the cross-attention launch of every `layer_stride`-th layer
  * with a HIP event pair on the launch stream, up to `max_samples` pairs.  wm_profile_read waits for

@@ -291,3 +291,39 @@ def test_greedy_step_matches_reference_rules(lib, golden_dir):
         assert int(tok_buf[0, cur]) == int(fixr[f"c{c}_next"]), f"case {c}"
         assert abs(float(s[0]) - float(fixr[f"c{c}_sumlp"])) < 2e-4, f"case {c}"
         assert bool(int(n_done[0])) == bool(fixr[f"c{c}_done"]), f"case {c}"
+
+
+@pytest.mark.gpu
+def test_log_mel_device(lib, golden_dir):
+    """wm_log_mel (device STFT + mel) against the reference's log_mel_spectrogram output (tests/golden/mel.npz)
+    and, at the full 30 s size, against the torch.stft mirror clip by clip (silence, padding tail, loud clip)."""
+    import whisper_utils as wu
+    g = np.load(os.path.join(golden_dir, "mel.npz"))
+    rng = np.random.Generator(np.random.Philox(int(g["audio_seed"])))
+    audio = (rng.standard_normal(int(g["n_audio"])) * 0.1).astype(np.float32)
+    padded = torch.from_numpy(wu.pad_or_trim(audio, int(g["n_padded"]))).cuda()
+    MEL_ATOL = 5e-4        # fp32 direct DFT vs pocketfft, after log10 and /4
+    mel = wu.log_mel_spectrogram_device(padded, dtype=torch.float32)
+    assert tuple(mel.shape) == g["mel"].shape
+    np.testing.assert_allclose(mel.cpu().numpy(), g["mel"], atol=MEL_ATOL)
+    mel16 = wu.log_mel_spectrogram_device(padded)
+    assert mel16.dtype == torch.float16 and torch.equal(mel16, mel.half())
+
+    gen = torch.Generator().manual_seed(77)
+    clips = torch.zeros(4, wu.N_SAMPLES)
+    clips[0] = torch.randn(wu.N_SAMPLES, generator=gen) * 0.05
+    clips[1, :200000] = torch.sin(torch.arange(200000) * 0.05) * 0.5 + torch.randn(200000, generator=gen) * 0.01
+    clips[3] = torch.randn(wu.N_SAMPLES, generator=gen).clamp(-1, 1)
+    dev = wu.log_mel_spectrogram_device(clips.cuda(), dtype=torch.float32).cpu()
+    assert tuple(dev.shape) == (4, 80, wu.N_FRAMES)
+    for b in range(4):
+        ref = wu.log_mel_spectrogram(clips[b])
+        np.testing.assert_allclose(dev[b].numpy(), ref.numpy(), atol=MEL_ATOL, err_msg=f"clip {b}")
+    assert float((dev[2] + 1.5).abs().max()) < 1e-6           # silence: log10(1e-10) everywhere
+    # ragged batch view: a strided slice of a bigger buffer (audio_ld > n_samples)
+    big = torch.zeros(2, wu.N_SAMPLES + 320, device="cuda")
+    big[:, :wu.N_SAMPLES] = clips[:2].cuda()
+    view = big[:, :wu.N_SAMPLES]
+    assert not view.is_contiguous()
+    out_view = wu.log_mel_spectrogram_device(view.contiguous(), dtype=torch.float32).cpu()
+    assert torch.equal(out_view, dev[:2])
