@@ -194,6 +194,7 @@ class WhisperDecoding:
         self.vocab_path = vocab_path
         multilingual = self.decoder_config.get('vocab_size', 51865) >= 51865
         self.tokenizer = self.get_tokenizer(multilingual, 'en', 'transcribe')
+        self.is_multilingual = multilingual
 
         self.sot_sequence = self.tokenizer.sot_sequence
         self.initial_tokens = tuple(list(self.sot_sequence))
@@ -383,6 +384,8 @@ class WhisperDecoding:
     def detect_language_reference(self, audio_features):
         """The reference's language-ID pass literally (W/decoding.py:703-741): cross K/V engine, one
         `decode()` of the single <|sot|> token through the by-name protocol."""
+        if not self.is_multilingual:
+            return ['en'] * audio_features.shape[0], None      # English-only vocabulary: no language tokens
         languages = [self.options.language] * audio_features.shape[0]
         language_probs = None
         if self.options.language is None or self.options.task == "lang_id":
@@ -403,6 +406,8 @@ class WhisperDecoding:
         """Language-ID pass, fast path: same arithmetic as detect_language_reference, but the cross
         K/V land in the persistent buffers main_loop re-uses (the reference computes them twice,
         SURVEY F6) and the one-token decoder call runs per utterance group on its stream."""
+        if not self.is_multilingual:
+            return ['en'] * audio_features.shape[0], None      # English-only vocabulary: no language tokens
         languages = [self.options.language] * audio_features.shape[0]
         language_probs = None
         if self.options.language is None or self.options.task == "lang_id":
@@ -435,6 +440,8 @@ class WhisperDecoding:
 
     def torch_detect_language(self, model, audio_features):
         """PyTorch path (W/decoding.py:661-701): `model.logits(tokens, audio_features)`."""
+        if not self.is_multilingual:
+            return ['en'] * audio_features.shape[0], None
         with torch.no_grad():
             languages = [self.options.language] * audio_features.shape[0]
             language_probs = None

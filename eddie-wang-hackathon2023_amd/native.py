@@ -20,11 +20,18 @@ EXPORTS = (
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
     "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
+    "wm_flac_info", "wm_flac_decode",
 )
 
 
 class WmError(RuntimeError):
     pass
+
+
+class WmFlacStreamInfo(C.Structure):
+    """wm_flac_streaminfo (include/whisper_mi355.h)."""
+    _fields_ = [("sample_rate", C.c_int32), ("channels", C.c_int32), ("bits_per_sample", C.c_int32),
+                ("max_block_size", C.c_int32), ("total_samples", C.c_int64), ("md5", C.c_uint8 * 16)]
 
 
 class WmDims(C.Structure):
@@ -113,6 +120,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_log_mel_workspace_bytes.argtypes = [i32, i32, i32]
     lib.wm_log_mel_workspace_bytes.restype = sz
     lib.wm_log_mel.argtypes = [vp, i32, i32, C.c_int64, vp, i32, vp, vp, vp, sz, vp]
+    lib.wm_flac_info.argtypes = [vp, sz, C.POINTER(WmFlacStreamInfo)]
+    lib.wm_flac_decode.argtypes = [vp, sz, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.wm_step_advance.argtypes = [vp, vp]
     lib.wm_profile_configure.argtypes = [i32, i32, i32]
     lib.wm_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]

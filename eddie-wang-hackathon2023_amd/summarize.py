@@ -1,0 +1,202 @@
+"""WER of the engines on a LibriSpeech-style directory: mirror of W/summarize.py (same flags, same text
+pipeline: strip [.,!?] + upper-case, EnglishTextNormalizer on both sides, corpus WER), with the parts the
+MI355X boxes lack replaced: FLAC through the library's own decoder instead of ffmpeg, the log-mel on the
+GPU (wm_log_mel), jiwer.wer by wer.py.
+
+Differences from the reference, all opt-in or additive:
+  * utterances are decoded `--batch_size` at a time (the reference is batch 1) and, under torch.distributed,
+    sharded over the ranks (dp.py); the WER is computed on rank 0 over the gathered hypotheses;
+  * the data set may be the nested LibriSpeech tree (speaker/chapter/*.flac + *.trans.txt, what
+    W/summarize.py:112-118 walks) or a flat directory such as W/LibriSpeech/valid-clean;
+  * `--test_torch` needs a PyTorch Whisper with `.encoder` / `.logits` built from `--checkpoint_file`
+    (openai-whisper's `whisper.model.Whisper`); without that package the flag raises.
+"""
+import argparse
+import logging
+import re
+import time
+from pathlib import Path
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from decoding import WhisperDecoding
+from encoding import WhisperEncoding
+from normalizers import EnglishTextNormalizer
+from wer import wer as word_error_rate
+from whisper_utils import N_SAMPLES, load_audio, log_mel_spectrogram, log_mel_spectrogram_device, pad_or_trim
+
+logger = logging.getLogger("whisper_mi355.summarize")
+AUDIO_SUFFIXES = (".flac", ".wav", ".npy")
+
+
+def load_dataset(dataset_dir) -> Tuple[List[Path], List[str]]:
+    """One directory: the transcript file (`*.txt`, lines `<utterance-id> <TEXT>`) and the audio files.
+    Returns (audio files sorted by name, reference texts in transcript order) — W/summarize.py:56-71."""
+    label_file, audio_files = None, []
+    for f in Path(dataset_dir).iterdir():
+        if f.name.endswith("txt"):
+            label_file = f
+        elif f.suffix in AUDIO_SUFFIXES:
+            audio_files.append(f)
+    references = []
+    if label_file is not None:
+        with open(label_file) as fh:
+            references = [line.split(" ", 1)[1].replace("\n", "") for line in fh if " " in line]
+    return sorted(audio_files), references
+
+
+def discover(dataset_dir) -> List[Tuple[Path, str]]:
+    """(audio file, reference text) pairs of every directory under `dataset_dir` that holds a transcript."""
+    root = Path(dataset_dir)
+    leaves = sorted({p.parent for p in root.rglob("*.txt")} | ({root} if any(root.glob("*.txt")) else set()))
+    pairs: List[Tuple[Path, str]] = []
+    for leaf in leaves:
+        audio_files, references = load_dataset(leaf)
+        if len(audio_files) != len(references):
+            # match by utterance id when the directory is not one-line-per-file
+            by_id = {}
+            for f in leaf.iterdir():
+                if f.name.endswith("txt"):
+                    with open(f) as fh:
+                        by_id.update(dict(line.rstrip("\n").split(" ", 1) for line in fh if " " in line))
+            pairs += [(a, by_id[a.stem]) for a in audio_files if a.stem in by_id]
+        else:
+            pairs += list(zip(audio_files, references))
+    return pairs
+
+
+def clean_hypothesis(text: str) -> str:
+    """What the reference does to the engine output before normalising (W/summarize.py:125-127)."""
+    punctuations = re.findall(r"[.,!?]", text)
+    return text.translate(str.maketrans({p: "" for p in punctuations})).upper()
+
+
+def mel_batch(audio_list: List[np.ndarray], device) -> torch.Tensor:
+    """fp16 [B, 80, 3000] on `device`: pad_or_trim each clip, STFT + mel projection on the GPU."""
+    padded = np.stack([pad_or_trim(a) for a in audio_list]).astype(np.float32)
+    if torch.device(device).type == "cuda":
+        return log_mel_spectrogram_device(torch.from_numpy(padded).to(device), dtype=torch.float16)
+    return torch.stack([log_mel_spectrogram(torch.from_numpy(p)) for p in padded]).half()
+
+
+def eval_engines(whisper_encoding, whisper_decoding, mel) -> list:
+    audio_features = whisper_encoding.get_audio_features(mel)
+    languages, _ = whisper_decoding.detect_language(audio_features)
+    tokens, sum_logprobs, no_speech_probs = whisper_decoding.main_loop(audio_features)
+    return whisper_decoding.post_process(tokens, sum_logprobs, no_speech_probs, audio_features, languages)
+
+
+def eval_torch(whisper_encoding, whisper_decoding, mel, model) -> list:
+    audio_features = whisper_encoding.torch_get_audio_features(model, mel)
+    languages, _ = whisper_decoding.torch_detect_language(model, audio_features)
+    tokens, sum_logprobs, no_speech_probs = whisper_decoding.torch_main_loop(model, audio_features)
+    return whisper_decoding.post_process(tokens, sum_logprobs, no_speech_probs, audio_features, languages)
+
+
+def load_torch_model(checkpoint_file: str, device):
+    try:
+        from whisper.model import ModelDimensions, Whisper          # openai-whisper
+    except ImportError as e:
+        raise RuntimeError("--test_torch needs a PyTorch Whisper implementation (pip package `openai-whisper`); "
+                           "the engines themselves do not") from e
+    checkpoint = torch.load(checkpoint_file, map_location="cpu")
+    model = Whisper(ModelDimensions(**checkpoint["dims"]))
+    model.load_state_dict(checkpoint["model_state_dict"])
+    return model.to(device)
+
+
+def score(hypotheses: List[str], references: List[str], normalizer=None) -> float:
+    normalizer = normalizer or EnglishTextNormalizer()
+    return word_error_rate([normalizer(t) for t in references], [normalizer(t) for t in hypotheses])
+
+
+def transcribe_dataset(pairs, evaluate, batch_size: int, device) -> Tuple[List[str], List[str], float]:
+    """Run `evaluate(mel) -> [DecodingResult]` over the clips that fit 30 s; returns (hypotheses, references,
+    seconds spent in `evaluate`)."""
+    hyps, refs, batch_audio, batch_refs = [], [], [], []
+    elapsed = 0.0
+
+    def flush():
+        nonlocal elapsed
+        if not batch_audio:
+            return
+        mel = mel_batch(batch_audio, device)
+        torch.cuda.synchronize() if mel.is_cuda else None
+        t0 = time.time()
+        results = evaluate(mel)
+        torch.cuda.synchronize() if mel.is_cuda else None
+        elapsed += time.time() - t0
+        for ref, res in zip(batch_refs, results):
+            hyps.append(clean_hypothesis(res.text))
+            refs.append(ref)
+            logger.info("---------------------------------------------------------")
+            logger.info(f"\n Reference : {ref}")
+            logger.info(f"\n Output : {hyps[-1]}")
+        batch_audio.clear()
+        batch_refs.clear()
+
+    for audio_file, ref in pairs:
+        audio = load_audio(str(audio_file))
+        if audio.shape[-1] > N_SAMPLES:          # the reference skips clips longer than one window (summarize.py:114-115)
+            continue
+        batch_audio.append(audio)
+        batch_refs.append(ref)
+        if len(batch_audio) == batch_size:
+            flush()
+    flush()
+    return hyps, refs, elapsed
+
+
+def main(args) -> Optional[dict]:
+    logging.basicConfig(level=getattr(logging, args.log_level.upper(), logging.INFO))
+    import torch.distributed as dist
+    import dp
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    device = torch.device("cuda", torch.cuda.current_device())
+    engine_dir = Path(args.engine_dir)
+    whisper_encoding = WhisperEncoding(engine_dir)
+    whisper_decoding = WhisperDecoding(engine_dir, vocab_path=args.vocab)
+    pairs = discover(args.dataset_dir)
+    lo, hi = dp.shard_bounds(len(pairs), rank, world)
+    report = {}
+    runs = []
+    if args.test_torch:
+        model = load_torch_model(args.checkpoint_file, device)
+        runs.append(("Torch", lambda mel: eval_torch(whisper_encoding, whisper_decoding, mel, model)))
+    if args.test_trt_llm:
+        runs.append(("whisper-mi355", lambda mel: eval_engines(whisper_encoding, whisper_decoding, mel)))
+    for name, evaluate in runs:
+        hyps, refs, seconds = transcribe_dataset(pairs[lo:hi], evaluate, args.batch_size, device)
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (hyps, refs, seconds))
+            hyps = [h for g in gathered for h in g[0]]
+            refs = [r for g in gathered for r in g[1]]
+            seconds = max(g[2] for g in gathered)
+        if rank == 0:
+            value = score(hyps, refs)
+            logger.info(f"{name} (total latency: {seconds} sec)")
+            logger.info(f"{name} beam 0 result")
+            logger.info(f"\nWER: {value * 100:.2f} %")
+            report[name] = dict(wer=value, seconds=seconds, utterances=len(hyps))
+    return report if rank == 0 else None
+
+
+def parse_arguments(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--test_torch', action='store_true')
+    parser.add_argument('--test_trt_llm', action='store_true', help='evaluate the engines (flag name kept from the reference)')
+    parser.add_argument('--data_type', type=str, choices=['fp16'], default='fp16')
+    parser.add_argument('--log_level', type=str, default='info')
+    parser.add_argument('--engine_dir', type=str, default='whisper_outputs')
+    parser.add_argument('--dataset_dir', type=str, default='./LibriSpeech/test-clean')
+    parser.add_argument('--checkpoint_file', type=str, default='./large-v2.pt')
+    parser.add_argument('--batch_size', type=int, default=32, help='utterances decoded together (the reference: 1)')
+    parser.add_argument('--vocab', type=str, default=None, help='path to multilingual.tiktoken / gpt2.tiktoken')
+    return parser.parse_args(argv)
+
+
+if __name__ == '__main__':
+    main(parse_arguments())

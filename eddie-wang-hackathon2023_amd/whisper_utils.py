@@ -27,13 +27,48 @@ N_SAMPLES = CHUNK_LENGTH * SAMPLE_RATE  # 480000 samples in a 30-second chunk
 N_FRAMES = N_SAMPLES // HOP_LENGTH       # 3000 frames in a mel spectrogram input
 
 
+def decode_flac(data: bytes, verify_md5: bool = True):
+    """FLAC bytes -> (int32 samples [n, channels], sample_rate, bits_per_sample) through the native decoder
+    (wm_flac_decode, csrc/flac_decode.hip; frame CRCs checked there).  With `verify_md5` the decoded PCM is
+    hashed and compared with the stream's own STREAMINFO signature (skipped when the encoder left it zero)."""
+    import ctypes as C
+    import hashlib
+    import native
+    lib = native.load_library()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    info = native.WmFlacStreamInfo()
+    native.check(lib.wm_flac_info(buf, len(data), C.byref(info)), "wm_flac_info")
+    capacity = int(info.total_samples)
+    if capacity == 0:      # unknown length: every frame holds at most max_block_size samples and at least 11 bytes
+        capacity = (len(data) // 11 + 1) * max(int(info.max_block_size), 16)
+    pcm = np.empty((capacity, info.channels), dtype=np.int32)
+    n = C.c_int64(0)
+    native.check(lib.wm_flac_decode(buf, len(data), pcm.ctypes.data, capacity, C.byref(n)), "wm_flac_decode")
+    pcm = pcm[: n.value]
+    signature = bytes(info.md5)
+    if verify_md5 and any(signature):
+        width = (info.bits_per_sample + 7) // 8
+        raw = pcm.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width].tobytes()
+        if hashlib.md5(raw).digest() != signature:
+            raise RuntimeError("FLAC MD5 signature mismatch: decoded audio differs from what the encoder saw")
+    return pcm, int(info.sample_rate), int(info.bits_per_sample)
+
+
 def load_audio(file: str, sr: int = SAMPLE_RATE) -> np.ndarray:
-    """Mono float32 waveform in [-1, 1] at `sr` Hz from a PCM16 .wav (or a float .npy)."""
+    """Mono float32 waveform in [-1, 1] at `sr` Hz (W/whisper_utils.py:17-54, which pipes every file
+    through ffmpeg).  Without ffmpeg: PCM16 .wav, .flac (own decoder) and float .npy, already at `sr` Hz;
+    several channels are averaged."""
+    file = str(file)
     if file.endswith(".npy"):
         return np.load(file).astype(np.float32).flatten()
+    if file.endswith(".flac"):
+        with open(file, "rb") as f:
+            pcm, rate, bits = decode_flac(f.read())
+        if rate != sr:
+            raise RuntimeError(f"{file}: {rate} Hz, need {sr} Hz (no resampler without ffmpeg)")
+        return (pcm.astype(np.float32).mean(axis=1) / float(1 << (bits - 1))).astype(np.float32)
     if not file.endswith(".wav"):
-        raise RuntimeError(f"cannot decode {file}: only PCM16 .wav / .npy are supported without ffmpeg "
-                           f"(FLAC/m4a decoding is next-scope, SURVEY 8f-1)")
+        raise RuntimeError(f"cannot decode {file}: only .wav (PCM16) / .flac / .npy are supported without ffmpeg")
     with wave.open(file, "rb") as w:
         if w.getsampwidth() != 2 or w.getframerate() != sr:
             raise RuntimeError(f"{file}: need 16-bit PCM at {sr} Hz, got {8 * w.getsampwidth()}-bit at {w.getframerate()} Hz")

@@ -166,6 +166,22 @@ int wm_log_mel(const float* audio, int batch, int n_samples, int64_t audio_ld, c
                int n_mels, void* mel_f16, float* mel_f32, void* workspace, size_t workspace_bytes,
                wm_stream_t stream);
 
+/* FLAC decoder (host code, no GPU needed): replaces the ffmpeg subprocess of load_audio
+ * (W/whisper_utils.py:17-54) for the LibriSpeech .flac files.  wm_flac_decode writes interleaved
+ * int32 samples [n][channels]; frame CRC-8 / CRC-16 are verified, `md5` is the STREAMINFO signature of
+ * the PCM (little-endian, ceil(bits/8) bytes per sample) for the caller to check. */
+typedef struct wm_flac_streaminfo {
+    int32_t sample_rate;
+    int32_t channels;
+    int32_t bits_per_sample;
+    int32_t max_block_size;
+    int64_t total_samples;      /* per channel; 0 = unknown */
+    uint8_t md5[16];
+} wm_flac_streaminfo;
+int wm_flac_info(const void* data, size_t bytes, wm_flac_streaminfo* info);
+int wm_flac_decode(const void* data, size_t bytes, int32_t* pcm, int64_t capacity_samples,
+                   int64_t* n_decoded);
+
 /* ---- in-situ timing of the dominant decode kernel (cross-attention), for the roofline report ------
  * When enabled, wm_decoder_step brackets the cross-attention launch of every `layer_stride`-th layer
  * with a HIP event pair on the launch stream, up to `max_samples` pairs.  wm_profile_read waits for

@@ -349,3 +349,31 @@ def test_large_v2_width_engine_matches_oracle(tmpdir_module):
         tol=LOGIT_TOL_INT8_KV)
     assert d_xa < 3e-2 and d_ckv < 3e-2 and worst < LOGIT_TOL_INT8_KV, (d_xa, d_ckv, worst)
     assert n_ok == n_safe and n_safe > 0
+
+
+def test_summarize_pipeline_on_flac(tmpdir_module, golden_dir, tmp_path):
+    """summarize.py end to end on real audio framing: FLAC decode -> pad_or_trim -> device log-mel -> encoder ->
+    language / greedy loop -> text clean-up -> normaliser -> WER, tiny.en-shape engine with random weights
+    (so the WER itself is meaningless: the point is that every stage runs on 30 s inputs and is deterministic)."""
+    import shutil
+    import summarize as S
+    import whisper_utils as wu
+    eng = build_engine(tmpdir_module, "tiny.en", 21)
+    chapter = tmp_path / "ds" / "1089" / "134691"
+    chapter.mkdir(parents=True)
+    for i in range(3):
+        shutil.copy(os.path.join(golden_dir, "librispeech_1089-134691-0000.flac"), chapter / f"1089-134691-000{i}.flac")
+    (chapter / "1089-134691.trans.txt").write_text("".join(f"1089-134691-000{i} HE COULD WAIT NO LONGER\n" for i in range(3)))
+    args = S.parse_arguments(["--test_trt_llm", "--engine_dir", str(eng), "--dataset_dir", str(tmp_path / "ds"),
+                              "--batch_size", "2", "--log_level", "error"])
+    report = S.main(args)["whisper-mi355"]
+    assert report["utterances"] == 3 and np.isfinite(report["wer"]) and report["wer"] >= 0
+    # same clip three times, batch sizes 2 + 1: identical hypotheses, and the same as one batch of 3
+    pairs = S.discover(tmp_path / "ds")
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    hyps, refs, _ = S.transcribe_dataset(pairs, lambda mel: S.eval_engines(enc, dec, mel), 3, torch.device("cuda"))
+    assert len(set(hyps)) == 1 and refs == ["HE COULD WAIT NO LONGER"] * 3
+    # the mel the pipeline fed: device front end == torch.stft mirror on the decoded FLAC
+    audio = wu.pad_or_trim(wu.load_audio(str(pairs[0][0])))
+    dev = wu.log_mel_spectrogram_device(torch.from_numpy(audio).cuda(), dtype=torch.float32).cpu()
+    np.testing.assert_allclose(dev.numpy(), wu.log_mel_spectrogram(audio).numpy(), atol=5e-4)

@@ -1,0 +1,214 @@
+"""CPU tests of the rows either side of the hot path: FLAC decoder, text normalisers
+(pinned to the reference's own output, tests/golden/normalizer.json from oracle/gen_golden_text.py), WER,
+and the summarize.py host logic."""
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from flac_writer import encode_flac  # noqa: E402
+
+FLAC_FIXTURE = "librispeech_1089-134691-0000.flac"      # "HE COULD WAIT NO LONGER", LibriSpeech test-clean (CC BY 4.0)
+
+
+# ---- FLAC ---------------------------------------------------------------------------------------------
+def test_flac_librispeech_clip(golden_dir):
+    import whisper_utils as wu
+    data = open(os.path.join(golden_dir, FLAC_FIXTURE), "rb").read()
+    pcm, rate, bits = wu.decode_flac(data)          # CRC-8/CRC-16 per frame in C, MD5 of the PCM here
+    assert (pcm.shape, rate, bits) == ((33360, 1), 16000, 16)
+    assert int(pcm.astype(np.int64).sum()) == -95452 and int(np.abs(pcm).max()) == 25185
+    assert pcm[1000:1004, 0].tolist() == [52, 40, 53, 43]
+    assert hashlib.sha256(pcm.astype("<i2").tobytes()).hexdigest().startswith("8765bbf3602482c6")
+    audio = wu.load_audio(os.path.join(golden_dir, FLAC_FIXTURE))
+    assert audio.dtype == np.float32 and audio.shape == (33360,)
+    np.testing.assert_array_equal(audio, pcm[:, 0].astype(np.float32) / 32768.0)     # what ffmpeg s16le / 32768 gives
+
+
+def test_flac_corruption_is_detected(golden_dir):
+    import native
+    import whisper_utils as wu
+    data = bytearray(open(os.path.join(golden_dir, FLAC_FIXTURE), "rb").read())
+    flipped = bytearray(data)
+    flipped[len(data) // 2] ^= 0x10
+    with pytest.raises(native.WmError, match="flac"):
+        wu.decode_flac(bytes(flipped))
+    with pytest.raises(native.WmError, match="flac"):
+        wu.decode_flac(bytes(data[: len(data) // 2]))
+    with pytest.raises(native.WmError, match="fLaC"):
+        wu.decode_flac(b"RIFF" + bytes(data[4:]))
+    bad_md5 = bytearray(data)
+    bad_md5[4 + 4 + 18] ^= 0xff                      # STREAMINFO signature byte
+    with pytest.raises(RuntimeError, match="MD5"):
+        wu.decode_flac(bytes(bad_md5))
+    pcm, _, _ = wu.decode_flac(bytes(bad_md5), verify_md5=False)
+    assert pcm.shape == (33360, 1)
+
+
+def _smooth(rng, n, nch, bps, wasted=0):
+    """Band-limited noise that uses most of the sample range (so LPC / FIXED residuals are small but not tiny)."""
+    x = np.cumsum(rng.integers(-300, 301, size=(n, nch)), axis=0)
+    x = x - x.mean(axis=0, keepdims=True).astype(np.int64)
+    lim = (1 << (bps - 1 - wasted)) - 1
+    x = np.clip(x * max(1, lim // 40000), -lim, lim).astype(np.int64)
+    return x << wasted
+
+
+FLAC_CASES = {
+    "mono16_fixed_orders": dict(nch=1, bps=16, frames=[dict(block=192, kind=f"fixed{k}") for k in range(5)]),
+    "mono16_lpc_rice2_partitions": dict(nch=1, bps=16, frames=[
+        dict(block=256, kind="lpc", lpc=dict(coefs=[1900, -900, 20], shift=10, precision=12), rice2=True, porder=3),
+        dict(block=512, kind="lpc", lpc=dict(coefs=[7, -3, 1, 2, -1, 1, 0, 1], shift=3, precision=5), porder=4)]),
+    "mono16_escape_and_verbatim": dict(nch=1, bps=16, frames=[
+        dict(block=256, kind="fixed2", escape=True, porder=2), dict(block=100, kind="verbatim"),
+        dict(block=4096, kind="fixed1", rice2=True, escape=True, porder=5)]),
+    "mono16_constant_and_wasted": dict(nch=1, bps=16, wasted=3, const_first=True, frames=[
+        dict(block=64, kind="constant"), dict(block=576, kind="fixed3", wasted=3), dict(block=33, kind="verbatim", wasted=3)]),
+    "stereo16_all_assignments": dict(nch=2, bps=16, frames=[
+        dict(block=256, kind="fixed2", assignment=a, porder=1) for a in (1, 8, 9, 10)] + [
+        dict(block=1000, kinds=["lpc", "fixed4"], lpc=dict(coefs=[30, -14], shift=4, precision=7), assignment=10)]),
+    "stereo24_explicit_fields": dict(nch=2, bps=24, frame0=125, frames=[
+        dict(block=300, kind="fixed2", assignment=8, explicit_rate=True),
+        dict(block=4096, kind="fixed3", assignment=10, explicit_block=True, bits_from_streaminfo=True),
+        dict(block=17, kind="verbatim", assignment=9), dict(block=16, kind="fixed4", assignment=1)] +
+        [dict(block=20, kind="fixed1") for _ in range(6)]),
+    "mono8_unknown_length_no_md5": dict(nch=1, bps=8, known_total=False, with_md5=False, frames=[
+        dict(block=1152, kind="fixed1"), dict(block=200, kind="fixed0", rice2=True)]),
+    "five_channels_12bit": dict(nch=5, bps=12, frames=[dict(block=192, kind="fixed2"), dict(block=50, kind="verbatim")]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FLAC_CASES))
+def test_flac_synthetic_streams(name):
+    """Streams from tests/flac_writer.py (an independent encoder) that reach every decoder branch."""
+    import whisper_utils as wu
+    case = FLAC_CASES[name]
+    rng = np.random.default_rng(sorted(FLAC_CASES).index(name))
+    n = sum(f["block"] for f in case["frames"])
+    x = _smooth(rng, n, case["nch"], case["bps"], case.get("wasted", 0))
+    if case.get("const_first"):
+        x[: case["frames"][0]["block"]] = -1234 << case.get("wasted", 0)
+    blob = encode_flac(x, case["bps"], case["frames"], first_frame_number=case.get("frame0", 0),
+                       known_total=case.get("known_total", True), with_md5=case.get("with_md5", True))
+    pcm, rate, bits = wu.decode_flac(blob)
+    assert (rate, bits) == (16000, case["bps"])
+    np.testing.assert_array_equal(pcm, x)
+
+
+# ---- normalisers --------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def normalizer_golden(golden_dir):
+    with open(os.path.join(golden_dir, "normalizer.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_english_normalizer_matches_reference(normalizer_golden):
+    from normalizers import EnglishTextNormalizer
+    norm = EnglishTextNormalizer()
+    assert len(normalizer_golden["english"]) > 700
+    for text, expected in normalizer_golden["english"]:
+        assert norm(text) == expected, text
+
+
+def test_number_normalizer_matches_reference_on_random_word_sequences(normalizer_golden):
+    from normalizers import EnglishNumberNormalizer
+    norm = EnglishNumberNormalizer()
+    assert len(normalizer_golden["numbers"]) == 2500
+    for text, expected in normalizer_golden["numbers"]:
+        assert norm(text) == expected, text
+
+
+def test_basic_normalizer_matches_reference(normalizer_golden):
+    from normalizers import BasicTextNormalizer
+    plain, folded = BasicTextNormalizer(), BasicTextNormalizer(remove_diacritics=True)
+    for text, e_plain, e_folded in normalizer_golden["basic"]:
+        assert plain(text) == e_plain and folded(text) == e_folded, text
+    assert BasicTextNormalizer(split_letters=True)("ab c") == "a b c"
+
+
+def test_normalizer_examples():
+    """The documented behaviours (W/normalizers/english.py:13-21)."""
+    from normalizers import EnglishTextNormalizer
+    n = EnglishTextNormalizer()
+    assert n("$20 million") == "$20000000" and n("twenty dollars") == "$20"
+    assert n("one oh one") == "101" and n("the 1960s, the 274th, the 32nd") == "the 1960s the 274th the 32nd"
+    assert n("Mr. Brown's colour") == "mister brown is color"
+    assert n("two and a half percent") == "2.5%"
+
+
+# ---- WER ----------------------------------------------------------------------------------------------
+def test_wer_known_answers():
+    from wer import edit_counts, wer
+    assert wer("a b c d", "a b c d") == 0.0
+    assert wer("a b c d", "a x c d") == 0.25
+    assert wer("a b c d", "a c d") == 0.25
+    assert wer("a b c d", "a b b c d") == 0.25
+    assert wer("a b c d", "") == 1.0
+    assert wer("a b", "x y z") == 1.5                      # insertions can push it above 1
+    c = edit_counts("the cat sat on the mat".split(), "the cat sit on mat now".split())
+    assert c["substitutions"] + c["deletions"] + c["insertions"] == 3      # two optimal alignments exist
+    assert edit_counts("a b c".split(), "a c".split()) == dict(hits=2, substitutions=0, deletions=1, insertions=0)
+    assert edit_counts("a c".split(), "a b c".split()) == dict(hits=2, substitutions=0, deletions=0, insertions=1)
+    # corpus level: errors and words are pooled (what jiwer.wer does with two lists), not averaged per sentence
+    assert wer(["a b c d", "e f"], ["a b c d", "e x"]) == pytest.approx(1 / 6)
+    assert wer(["  a   b ", "c"], ["a b", "c"]) == 0.0
+    with pytest.raises(ValueError):
+        wer(["a", "b"], ["a"])
+    with pytest.raises(ValueError):
+        wer([""], ["a"])
+
+
+def test_wer_against_brute_force():
+    from wer import edit_counts
+    rng = np.random.default_rng(3)
+
+    def brute(r, h):
+        from functools import lru_cache
+
+        @lru_cache(None)
+        def d(i, j):
+            if i == 0 or j == 0:
+                return i + j
+            return min(d(i - 1, j - 1) + (r[i - 1] != h[j - 1]), d(i - 1, j) + 1, d(i, j - 1) + 1)
+        return d(len(r), len(h))
+    for _ in range(200):
+        r = tuple(rng.integers(0, 4, rng.integers(0, 9)).tolist())
+        h = tuple(rng.integers(0, 4, rng.integers(0, 9)).tolist())
+        c = edit_counts(r, h)
+        assert c["substitutions"] + c["deletions"] + c["insertions"] == brute(r, h)
+        assert c["hits"] + c["substitutions"] + c["deletions"] == len(r)
+        assert c["hits"] + c["substitutions"] + c["insertions"] == len(h)
+
+
+# ---- summarize.py host logic ----------------------------------------------------------------------------
+def test_summarize_dataset_discovery_and_scoring(golden_dir, tmp_path):
+    import summarize as S
+    # nested LibriSpeech layout (speaker/chapter) and a flat directory with one transcript file
+    src = os.path.join(golden_dir, FLAC_FIXTURE)
+    chapter = tmp_path / "nested" / "1089" / "134691"
+    chapter.mkdir(parents=True)
+    for i in range(3):
+        shutil.copy(src, chapter / f"1089-134691-000{i}.flac")
+    (chapter / "1089-134691.trans.txt").write_text(
+        "1089-134691-0000 HE COULD WAIT NO LONGER\n1089-134691-0001 SECOND LINE\n1089-134691-0002 THIRD LINE HERE\n")
+    pairs = S.discover(tmp_path / "nested")
+    assert [p.name for p, _ in pairs] == [f"1089-134691-000{i}.flac" for i in range(3)]
+    assert [r for _, r in pairs] == ["HE COULD WAIT NO LONGER", "SECOND LINE", "THIRD LINE HERE"]
+    flat = tmp_path / "flat"
+    flat.mkdir()
+    shutil.copy(src, flat / "b-0.flac")
+    shutil.copy(src, flat / "a-0.flac")
+    (flat / "valid.trans.txt").write_text("a-0 FIRST\nb-0 SECOND\nc-0 NO AUDIO FOR THIS ONE\n")
+    assert [(p.name, r) for p, r in S.discover(flat)] == [("a-0.flac", "FIRST"), ("b-0.flac", "SECOND")]
+    assert S.clean_hypothesis("Hello, world! Isn't it? Yes.") == "HELLO WORLD ISN'T IT YES"
+    assert S.score(["HE COULD WAIT NO LONGER", "MR BROWN PAID TWENTY DOLLARS"],
+                   ["he could wait no longer", "mister brown paid $20"]) == 0.0
+    assert S.score(["HE COULD WAIT NO LONGER"], ["HE COULD WEIGHT NO LONGER"]) == pytest.approx(0.2)
+    args = S.parse_arguments(["--test_trt_llm", "--engine_dir", "e", "--dataset_dir", "d"])
+    assert args.test_trt_llm and not args.test_torch and args.data_type == "fp16" and args.checkpoint_file == "./large-v2.pt"
