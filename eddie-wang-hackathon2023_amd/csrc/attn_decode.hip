@@ -234,10 +234,14 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     __shared__ float s_red[L][4][2];
     __shared__ float s_o[4][L][64];
 
-    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int sub = lane & 7, rowi = lane >> 3;           // 16-byte column, row inside an 8-row group
     const int per_split = (((p.Tk + p.nsplit - 1) / p.nsplit) + 7) & ~7;
+    // a workgroup walks over (head, utterance, key split) items: with fewer workgroups than items the
+    // launch is persistent and leaves wave slots on every CU to the other streams' short kernels
+    const int n_items = p.H * p.B * p.nsplit;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int h = item % p.H, b = (item / p.H) % p.B, sp = item / (p.H * p.B);
     const int k_begin = sp * per_split, k_end = min(p.Tk, k_begin + per_split);
     const int nkeys = max(0, k_end - k_begin);
     if (nkeys == 0) {          // empty split (only possible when nsplit > 1): neutral element
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
             float* w = p.ws + ((((size_t)b * p.H + h) * p.nsplit + sp) * L) * 66;
             w[idx] = (idx % 66 == 0) ? -INFINITY : 0.f;
         }
-        return;
+        continue;
     }
 
     const h16* K = p.kv + (size_t)b * p.kv_bstride + ((size_t)(0 * p.H + h) * p.Tk) * 64;
@@ -402,6 +406,8 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
             if (d == 0) { w[0] = gmax[i]; w[1] = gsum[i]; }
         }
     }
+    __syncthreads();          // the next item re-uses the LDS buffers
+    }
 }
 
 // combine the key-range splits: softmax-weighted merge of (max, sum, unnormalised o)
@@ -424,7 +430,9 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream) {
     WM_REQUIRE(p.L >= 1 && p.L <= MAX_L, "attn_cross: L=%d out of range [1,%d]", p.L, MAX_L);
     WM_REQUIRE(p.Tk >= 1 && p.Tk <= CROSS_MAX_KEYS, "attn_cross: Tk=%d out of range", p.Tk);
     WM_REQUIRE(p.nsplit >= 1 && (p.nsplit == 1 || p.ws != nullptr), "attn_cross: split needs a workspace");
-    dim3 grid(p.H, p.B, p.nsplit);
+    static const int persist_wgs = [] { const char* v = getenv("WM_CROSS_PERSIST_WGS"); return v ? atoi(v) : 0; }();
+    const int n_items = p.H * p.B * p.nsplit;
+    dim3 grid(persist_wgs > 0 && persist_wgs < n_items ? persist_wgs : n_items);
     switch (p.L) {
         case 1: hipLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, p); break;
         case 2: hipLaunchKernelGGL(attn_cross_kernel<2>, grid, dim3(256), 0, stream, p); break;

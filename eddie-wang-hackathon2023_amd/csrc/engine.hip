@@ -474,86 +474,186 @@ size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new) {
     return carve_decoder(e, batch, n_new, nullptr).total;
 }
 
-int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream_) {
-    WM_REQUIRE(e && e->kind == WM_ENGINE_DECODER, "wm_decoder_step: not a decoder engine");
-    WM_REQUIRE(io && io->tokens && io->positional_embedding && io->present && io->cross && io->logits && io->workspace,
-               "wm_decoder_step: null argument");
-    hipStream_t s = (hipStream_t)stream_;
-    const wm_dims& d = e->dims;
-    const int B = io->batch, L = io->n_new, T = io->n_past, C = d.n_text_state, H = d.n_text_head, M = B * L;
-    WM_REQUIRE(B >= 1 && L >= 1 && L <= 4 && T >= 0, "wm_decoder_step: bad batch/n_new/n_past (%d, %d, %d)", B, L, T);
-    WM_REQUIRE(T + L <= d.n_text_ctx, "wm_decoder_step: T+L=%d exceeds n_text_ctx=%d", T + L, d.n_text_ctx);
-    WM_REQUIRE(T == 0 || io->past, "wm_decoder_step: n_past > 0 needs past buffers");
-    WM_REQUIRE(!io->n_past_dev || (L == 1 && io->past), "wm_decoder_step: a device step counter needs n_new == 1 and past buffers");
-    WM_REQUIRE(C == H * 64, "head size must be 64");
-    DecWs w = carve_decoder(e, B, L, io->workspace);
-    WM_REQUIRE(io->workspace_bytes >= w.total, "decoder workspace too small: %zu < %zu", io->workspace_bytes, w.total);
+namespace {
+// One utterance group's decode step, cut into the phases between which the cross-attention kernel sits, so
+// that several groups can be interleaved layer by layer (wm_decoder_step_multi).
+struct GroupStep {
+    const wm_engine* e; const wm_decoder_io* io; DecWs w;
+    int B, L, T, C, H, M;
 
-    EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
-                   (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev};
-    if (launch_embed(ep, s)) return 2;
+    int init(const wm_engine* e_, const wm_decoder_io* io_) {
+        e = e_; io = io_;
+        WM_REQUIRE(io && io->tokens && io->positional_embedding && io->present && io->cross && io->logits && io->workspace,
+                   "wm_decoder_step: null argument");
+        const wm_dims& d = e->dims;
+        B = io->batch; L = io->n_new; T = io->n_past; C = d.n_text_state; H = d.n_text_head; M = B * L;
+        WM_REQUIRE(B >= 1 && L >= 1 && L <= 4 && T >= 0, "wm_decoder_step: bad batch/n_new/n_past (%d, %d, %d)", B, L, T);
+        WM_REQUIRE(T + L <= d.n_text_ctx, "wm_decoder_step: T+L=%d exceeds n_text_ctx=%d", T + L, d.n_text_ctx);
+        WM_REQUIRE(T == 0 || io->past, "wm_decoder_step: n_past > 0 needs past buffers");
+        WM_REQUIRE(!io->n_past_dev || (L == 1 && io->past), "wm_decoder_step: a device step counter needs n_new == 1 and past buffers");
+        WM_REQUIRE(C == H * 64, "head size must be 64");
+        w = carve_decoder(e, B, L, io->workspace);
+        WM_REQUIRE(io->workspace_bytes >= w.total, "decoder workspace too small: %zu < %zu", io->workspace_bytes, w.total);
+        return 0;
+    }
 
-    auto finish = [&](const Lin& l, int ks, int mode, const h16* g, const h16* bta, h16* out, int ldo, int N) {
+    int finish(const Lin& l, int ks, int mode, const h16* g, const h16* bta, h16* out, int ldo, int N, hipStream_t s) {
         RowFinishParams p{};
         p.part = w.part; p.ksplit = ks; p.M = M; p.N = N; p.ldp = l.N; p.part_sstride = (long)M * l.N;
         p.bias = l.b; p.mode = mode; p.gelu_kind = e->gelu(); p.x = w.x; p.ldx = C; p.ln_g = g; p.ln_b = bta;
         p.out = out; p.ldo = ldo;
         return launch_row_finish(p, s);
-    };
+    }
 
-    int ks = 0;
-    if (launch_layernorm(w.x, C, M, C, e->dec[0].ln1g, e->dec[0].ln1b, w.xn, C, s)) return 2;
-    for (int i = 0; i < d.n_text_layer; ++i) {
+    // token + positional embedding, first LayerNorm
+    int begin(hipStream_t s) {
+        const wm_dims& d = e->dims;
+        EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
+                       (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev};
+        if (launch_embed(ep, s)) return 2;
+        return launch_layernorm(w.x, C, M, C, e->dec[0].ln1g, e->dec[0].ln1b, w.xn, C, s);
+    }
+
+    // self-attention block and the cross-attention query projection of layer i
+    int pre_cross(int i, hipStream_t s) {
         const DecLayer& Lr = e->dec[i];
-        // ---- self-attention -----------------------------------------------------------------------
+        int ks = 0;
         if (skinny_all(Lr.qkv, w.xn, C, M, w.part, &ks, s)) return 2;
-        {
-            AttnSelfParams p{};
-            p.part = w.part; p.ksplit = ks; p.ldp = Lr.qkv.N; p.part_sstride = (long)M * Lr.qkv.N; p.bias = Lr.qkv.b;
-            p.B = B; p.L = L; p.T = T; p.H = H;
-            WM_REQUIRE(io->present[i], "wm_decoder_step: present[%d] is null", i);
-            p.present = io->present[i]; p.present_cap = io->present_capacity; p.present_bstride = (long)2 * H * io->present_capacity * 64;
-            if (T > 0) {
-                WM_REQUIRE(io->past[i], "wm_decoder_step: past[%d] is null", i);
-                p.past = io->past[i]; p.past_cap = io->past_capacity; p.past_bstride = (long)2 * H * io->past_capacity * 64;
-            } else { p.past = p.present; p.past_cap = p.present_cap; p.past_bstride = p.present_bstride; }
-            p.int8_kv = e->i8kv(); p.kv_scale = Lr.kv_scale; p.out = w.ctx; p.ldo = C;
-            p.amax = io->qkv_amax ? io->qkv_amax + i : nullptr;
-            p.t_dev = io->n_past_dev;
-            if (launch_attn_self(p, s)) return 2;
-        }
+        AttnSelfParams p{};
+        p.part = w.part; p.ksplit = ks; p.ldp = Lr.qkv.N; p.part_sstride = (long)M * Lr.qkv.N; p.bias = Lr.qkv.b;
+        p.B = B; p.L = L; p.T = T; p.H = H;
+        WM_REQUIRE(io->present[i], "wm_decoder_step: present[%d] is null", i);
+        p.present = io->present[i]; p.present_cap = io->present_capacity; p.present_bstride = (long)2 * H * io->present_capacity * 64;
+        if (T > 0) {
+            WM_REQUIRE(io->past[i], "wm_decoder_step: past[%d] is null", i);
+            p.past = io->past[i]; p.past_cap = io->past_capacity; p.past_bstride = (long)2 * H * io->past_capacity * 64;
+        } else { p.past = p.present; p.past_cap = p.present_cap; p.past_bstride = p.present_bstride; }
+        p.int8_kv = e->i8kv(); p.kv_scale = Lr.kv_scale; p.out = w.ctx; p.ldo = C;
+        p.amax = io->qkv_amax ? io->qkv_amax + i : nullptr;
+        p.t_dev = io->n_past_dev;
+        if (launch_attn_self(p, s)) return 2;
         if (skinny_all(Lr.out, w.ctx, C, M, w.part, &ks, s)) return 2;
-        if (finish(Lr.out, ks, 0, Lr.lncg, Lr.lncb, w.xn, C, C)) return 2;
-        // ---- cross-attention ----------------------------------------------------------------------
-        if (skinny_all(Lr.cq, w.xn, C, M, w.part, &ks, s)) return 2;
-        {
-            AttnCrossParams p{};
-            p.part = w.part; p.ksplit = ks; p.ldp = Lr.cq.N; p.part_sstride = (long)M * Lr.cq.N; p.bias = Lr.cq.b;
-            p.B = B; p.L = L; p.H = H; p.Tk = d.n_audio_ctx;
-            WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
-            p.kv = (const h16*)io->cross[i]; p.kv_bstride = (long)2 * H * d.n_audio_ctx * 64;
-            p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
-            const int slot = prof_begin(i, s);
-            if (launch_attn_cross(p, s)) return 2;
-            prof_end(slot, s);
-        }
+        if (finish(Lr.out, ks, 0, Lr.lncg, Lr.lncb, w.xn, C, C, s)) return 2;
+        if (skinny_all(Lr.cq, w.xn, C, M, w.part, &cq_ks, s)) return 2;
+        return 0;
+    }
+    int cq_ks = 0;
+
+    // the HBM-bound kernel: K and V of every utterance of the group, once
+    int cross(int i, hipStream_t s) {
+        const DecLayer& Lr = e->dec[i];
+        const wm_dims& d = e->dims;
+        AttnCrossParams p{};
+        p.part = w.part; p.ksplit = cq_ks; p.ldp = Lr.cq.N; p.part_sstride = (long)M * Lr.cq.N; p.bias = Lr.cq.b;
+        p.B = B; p.L = L; p.H = H; p.Tk = d.n_audio_ctx;
+        WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
+        p.kv = (const h16*)io->cross[i]; p.kv_bstride = (long)2 * H * d.n_audio_ctx * 64;
+        p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
+        const int slot = prof_begin(i, s);
+        if (launch_attn_cross(p, s)) return 2;
+        prof_end(slot, s);
+        return 0;
+    }
+
+    // cross-attention output projection and the MLP of layer i (ends with the next layer's LayerNorm)
+    int post_cross(int i, hipStream_t s) {
+        const DecLayer& Lr = e->dec[i];
+        const wm_dims& d = e->dims;
+        int ks = 0;
         if (skinny_all(Lr.cout, w.ctx, C, M, w.part, &ks, s)) return 2;
-        if (finish(Lr.cout, ks, 0, Lr.ln2g, Lr.ln2b, w.xn, C, C)) return 2;
-        // ---- MLP ----------------------------------------------------------------------------------
+        if (finish(Lr.cout, ks, 0, Lr.ln2g, Lr.ln2b, w.xn, C, C, s)) return 2;
         if (skinny_all(Lr.mlp1, w.xn, C, M, w.part, &ks, s)) return 2;
-        if (finish(Lr.mlp1, ks, 1, nullptr, nullptr, w.hid, 4 * C, 4 * C)) return 2;
+        if (finish(Lr.mlp1, ks, 1, nullptr, nullptr, w.hid, 4 * C, 4 * C, s)) return 2;
         if (skinny_all(Lr.mlp2, w.hid, 4 * C, M, w.part, &ks, s)) return 2;
         const bool last = (i + 1 == d.n_text_layer);
-        if (finish(Lr.mlp2, ks, 0, last ? e->lnfg : e->dec[i + 1].ln1g, last ? e->lnfb : e->dec[i + 1].ln1b, w.xn, C, C)) return 2;
+        return finish(Lr.mlp2, ks, 0, last ? e->lnfg : e->dec[i + 1].ln1g, last ? e->lnfb : e->dec[i + 1].ln1b, w.xn, C, C, s);
     }
-    // ---- logits = ln(x) . E^T (fp16 out, whisper/model.py:288-290) ----------------------------------
-    for (int r0 = 0; r0 < M; r0 += 128) {
-        GemmSkinnyParams p{};
-        p.A = w.xn + (size_t)r0 * C; p.lda = C; p.M = (M - r0) < 128 ? (M - r0) : 128; p.K = C;
-        p.Wt = e->emb_t; p.n_blocks = e->emb_blocks; p.w8 = 0; p.ksplit = 1;
-        p.out = (h16*)io->logits + (size_t)r0 * d.n_vocab; p.ldc = d.n_vocab; p.n_valid = d.n_vocab;
-        if (launch_gemm_skinny(p, s)) return 2;
+
+    // logits = ln(x) . E^T (fp16 out, whisper/model.py:288-290)
+    int end(hipStream_t s) {
+        const wm_dims& d = e->dims;
+        for (int r0 = 0; r0 < M; r0 += 128) {
+            GemmSkinnyParams p{};
+            p.A = w.xn + (size_t)r0 * C; p.lda = C; p.M = (M - r0) < 128 ? (M - r0) : 128; p.K = C;
+            p.Wt = e->emb_t; p.n_blocks = e->emb_blocks; p.w8 = 0; p.ksplit = 1;
+            p.out = (h16*)io->logits + (size_t)r0 * d.n_vocab; p.ldc = d.n_vocab; p.n_valid = d.n_vocab;
+            if (launch_gemm_skinny(p, s)) return 2;
+        }
+        return 0;
     }
+};
+
+// events that order a group's light stream against the shared heavy stream: [group][layer][0: q ready, 1: ctx ready]
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    hipEvent_t get(size_t idx) {
+        while (ev.size() <= idx) {
+            hipEvent_t x = nullptr;
+            if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ev.push_back(x);
+        }
+        return ev[idx];
+    }
+} g_events;
+}  // namespace
+
+int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream_) {
+    WM_REQUIRE(e && e->kind == WM_ENGINE_DECODER, "wm_decoder_step: not a decoder engine");
+    hipStream_t s = (hipStream_t)stream_;
+    GroupStep g;
+    if (g.init(e, io)) return 1;
+    if (g.begin(s)) return 2;
+    for (int i = 0; i < e->dims.n_text_layer; ++i) {
+        if (g.pre_cross(i, s)) return 2;
+        if (g.cross(i, s)) return 2;
+        if (g.post_cross(i, s)) return 2;
+    }
+    return g.end(s);
+}
+
+int wm_decoder_step_multi(const wm_engine* e, int n_groups, const wm_decoder_io* const* ios,
+                          const wm_stream_t* light_streams, wm_stream_t heavy_stream) {
+    WM_REQUIRE(e && e->kind == WM_ENGINE_DECODER, "wm_decoder_step_multi: not a decoder engine");
+    WM_REQUIRE(n_groups >= 1 && n_groups <= 8 && ios && light_streams && heavy_stream, "wm_decoder_step_multi: bad arguments");
+    hipStream_t hs = (hipStream_t)heavy_stream;
+    GroupStep g[8];
+    for (int k = 0; k < n_groups; ++k) {
+        WM_REQUIRE(light_streams[k] && light_streams[k] != heavy_stream, "wm_decoder_step_multi: group %d needs its own stream", k);
+        if (g[k].init(e, ios[k])) return 1;
+    }
+    const int n_layer = e->dims.n_text_layer;
+    for (int k = 0; k < n_groups; ++k)
+        if (g[k].begin((hipStream_t)light_streams[k])) return 2;
+    for (int i = 0; i < n_layer; ++i) {
+        for (int k = 0; k < n_groups; ++k) {
+            hipStream_t ls = (hipStream_t)light_streams[k];
+            hipEvent_t q_ready = g_events.get(((size_t)k * n_layer + i) * 2), ctx_ready = g_events.get(((size_t)k * n_layer + i) * 2 + 1);
+            WM_REQUIRE(q_ready && ctx_ready, "wm_decoder_step_multi: hipEventCreate failed");
+            if (g[k].pre_cross(i, ls)) return 2;
+            WM_CHECK_HIP(hipEventRecord(q_ready, ls));
+            WM_CHECK_HIP(hipStreamWaitEvent(hs, q_ready, 0));
+            if (g[k].cross(i, hs)) return 2;
+            WM_CHECK_HIP(hipEventRecord(ctx_ready, hs));
+            WM_CHECK_HIP(hipStreamWaitEvent(ls, ctx_ready, 0));
+        }
+        for (int k = 0; k < n_groups; ++k)
+            if (g[k].post_cross(i, (hipStream_t)light_streams[k])) return 2;
+    }
+    for (int k = 0; k < n_groups; ++k)
+        if (g[k].end((hipStream_t)light_streams[k])) return 2;
+    return 0;
+}
+
+int wm_stream_create_cu_mask(const uint32_t* mask, int n_words, wm_stream_t* out) {
+    WM_REQUIRE(mask && n_words >= 1 && out, "wm_stream_create_cu_mask: bad arguments");
+    hipStream_t s = nullptr;
+    WM_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+    *out = (wm_stream_t)s;
+    return 0;
+}
+
+int wm_stream_destroy(wm_stream_t stream) {
+    if (stream) WM_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
     return 0;
 }
 

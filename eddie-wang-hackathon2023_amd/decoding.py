@@ -234,6 +234,13 @@ class WhisperDecoding:
         self._state = {}                  # per-batch-size device buffers of the fast path
         self.poll_every = 8
         self.micro_batches = 2            # stream-level overlap of independent utterance groups
+        # experimental schedule (off by default): cross-attention on its own CU set
+        # (wm_decoder_step_multi).  Steady state 12.9 ms/step vs 13.9 for the captured graphs at B = 256, but the
+        # cross-queue event hand-offs cost 12 us each and only resolve quickly while the host is busy issuing.
+        self.cu_partition = False
+        self.light_cus = 96               # CUs reserved for the latency-bound kernels of all groups
+        self.run_ahead = 3                # decode steps the host may be ahead of the GPU in the partitioned loop
+        self._partition = None            # (light streams, heavy stream), created on first use
         self.use_graphs = True            # replay one captured decode step per token (hipGraph)
         self._streams = []
 
@@ -552,6 +559,22 @@ class WhisperDecoding:
             self._streams.append(torch.cuda.Stream(device=dev))
         return self._streams[:n]
 
+    def _partition_streams(self, n, dev):
+        """CU-partitioned streams for wm_decoder_step_multi: `n` light streams that may only use the first
+        `light_cus` CUs and one heavy stream that owns the rest.  Measured on MI355X (scripts/cumask_probe.py):
+        192 CUs still pull 6.4 TB/s through the cross-attention kernel, 64 CUs run the weight-streaming chain
+        at its full-chip speed, and only with disjoint CU sets do the two actually run at the same time."""
+        if self._partition is None or len(self._partition[0]) < n:
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            light_cus = max(8, min(self.light_cus, n_cu // 2))
+            light_mask = [i < light_cus for i in range(n_cu)]
+            heavy_mask = [not b for b in light_mask]
+            with torch.cuda.device(dev):
+                light = [native.create_masked_stream(light_mask, k) for k in range(n)]
+                heavy = native.create_masked_stream(heavy_mask, n)
+            self._partition = (light, heavy)
+        return self._partition[0][:n], self._partition[1]
+
     def _groups(self, n_batch):
         n_micro = self.micro_batches if n_batch >= 8 * self.micro_batches else 1
         return n_micro, [(g * n_batch // n_micro, (g + 1) * n_batch // n_micro) for g in range(n_micro)]
@@ -606,6 +629,8 @@ class WhisperDecoding:
         st['sum_logprobs'].zero_()
         st['n_done'].zero_()
         n_micro, bounds = self._groups(n_batch)
+        if self.cu_partition and n_micro > 1 and self.decoder_session.qkv_amax is None:
+            return self._main_loop_partitioned(audio_features, st, cross, L0, n_micro, bounds, ignore_eot)
         main = torch.cuda.current_stream()
         streams = self._group_streams(n_micro, dev)
         for s_ in streams:
@@ -635,8 +660,6 @@ class WhisperDecoding:
                             st['counters'][gkey].fill_(cur - 1)
                         st['counters'][gkey + ('fresh',)] = False
                     with torch.cuda.stream(streams[slot]):
-                        if i == 2 and slot == 1 and getattr(self, '_phase_sleep_cycles', 0):
-                            torch.cuda._sleep(self._phase_sleep_cycles)     # experiment: de-phase the groups
                         st['graphs'][gkey].replay()
                 else:
                     sess.decoder_step(gr['tokens'][:, cur - 1:cur], pos[cur - 1:cur], gr['cross'], gr['kv'], cap,
@@ -677,6 +700,80 @@ class WhisperDecoding:
                     break
         for s_ in streams:
             main.wait_stream(s_)
+        return self._finish_main_loop(st, cur, L0, n_batch, ignore_eot,
+                                      nsp_dev if self.tokenizer.no_speech is not None else None)
+
+    def _main_loop_partitioned(self, audio_features, st, cross, L0, n_micro, bounds, ignore_eot):
+        """The decode loop scheduled for the chip (wm_decoder_step_multi): every group's cross-attention kernel
+        on one stream that owns most CUs, each group's short kernels on a stream confined to the remaining
+        CUs, eager launches with the step counter on the device (the call is identical for every token).
+        Same arithmetic, same tokens as the single-stream loop."""
+        dev = audio_features.device
+        cfg = self.decoder_config
+        V, cap = cfg['vocab_size'], cfg['num_text_ctx']
+        n_batch = st['tokens'].shape[0]
+        sess, pos, lib = self.decoder_session, self.positional_embedding, native.load_library()
+        main = torch.cuda.current_stream()
+        light, heavy = self._partition_streams(n_micro, dev)
+        for s_ in light + [heavy]:
+            s_.wait_stream(main)
+        light_ptrs, heavy_ptr = [s_.cuda_stream for s_ in light], heavy.cuda_stream
+        key = ('partition', n_micro)
+        if key not in st['graphs']:
+            counters = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in bounds]
+            views = [dict(kv=[t[lo:hi] for t in st['kv']], cross=[t[lo:hi] for t in cross], logits=st['logits'][lo:hi],
+                          tokens=st['tokens'][lo:hi]) for lo, hi in bounds]
+            prefill = [sess.make_decoder_io(v['tokens'][:, :L0], pos[0:L0], v['cross'], None, cap, v['kv'], cap, v['logits'], 0,
+                                            slot=g) for g, v in enumerate(views)]
+            step = [sess.make_decoder_io(v['tokens'], pos, v['cross'], v['kv'], cap, v['kv'], cap, v['logits'], 1, slot=g,
+                                         n_past_dev=counters[g], n_new=1) for g, v in enumerate(views)]
+            st['graphs'][key] = dict(counters=counters, prefill=prefill, step=step, views=views)
+        plan = st['graphs'][key]
+        cur = L0
+        steps_done = 0
+        in_flight = []            # one event per issued step: the three queues only interleave well while the host
+        for i in range(self.sample_len):          # is a few steps ahead, not when it runs into a full queue mid-step
+            if len(in_flight) >= self.run_ahead:
+                in_flight.pop(0).synchronize()
+            if i == 0:
+                sess.decoder_step_multi(plan['prefill'], light_ptrs, heavy_ptr)
+                for g, (lo, hi) in enumerate(bounds):
+                    self._greedy(st, lo, hi, plan['views'][g]['logits'].data_ptr() + (L0 - 1) * V * 2, L0 * V, cur, light_ptrs[g])
+                if self.tokenizer.no_speech is not None:
+                    # the greedy kernel wrote -inf into the LAST position's row only; the <|sot|> row is untouched
+                    for s_ in light:
+                        main.wait_stream(s_)
+                    nsp_dev = st['logits'][:, self.sot_index].float().softmax(dim=-1)[:, self.tokenizer.no_speech]
+                    for s_ in light:
+                        s_.wait_stream(main)
+            else:
+                if i == 1:
+                    for g, s_ in enumerate(light):
+                        with torch.cuda.stream(s_):
+                            plan['counters'][g].fill_(cur - 1)      # the device step counter holds n_past = cur - 1
+                sess.decoder_step_multi(plan['step'], light_ptrs, heavy_ptr)
+                for g, (lo, hi) in enumerate(bounds):
+                    self._greedy(st, lo, hi, plan['views'][g]['logits'].data_ptr(), V, 0, light_ptrs[g],
+                                 n_past_dev=plan['counters'][g])
+                    native.check(lib.wm_step_advance(plan['counters'][g].data_ptr(), light_ptrs[g]), "wm_step_advance")
+            done = torch.cuda.Event()
+            done.record(light[0])
+            in_flight.append(done)
+            cur += 1
+            steps_done += 1
+            if cur > cap:
+                break
+            if not ignore_eot and (steps_done % self.poll_every == 0):
+                for s_ in light:
+                    main.wait_stream(s_)
+                if bool((st['tokens'][:, cur - 1] == self.tokenizer.eot).all()):
+                    break
+        for s_ in light + [heavy]:
+            main.wait_stream(s_)
+        return self._finish_main_loop(st, cur, L0, n_batch, ignore_eot,
+                                      nsp_dev if self.tokenizer.no_speech is not None else None)
+
+    def _finish_main_loop(self, st, cur, L0, n_batch, ignore_eot, nsp_dev):
         tokens = st['tokens'][:, :cur].to(torch.int64)
         if not ignore_eot:
             # cut at the first column where every row is EOT: where the per-step check would have stopped
@@ -684,7 +781,7 @@ class WhisperDecoding:
             if bool(all_eot.any()):
                 tokens = tokens[:, :L0 + int(all_eot.float().argmax()) + 1]
         no_speech_probs = [np.nan] * n_batch
-        if self.tokenizer.no_speech is not None:
+        if nsp_dev is not None:
             no_speech_probs = nsp_dev.tolist()
         return tokens, st['sum_logprobs'].clone(), no_speech_probs
 

@@ -20,7 +20,7 @@ EXPORTS = (
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
     "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
-    "wm_flac_info", "wm_flac_decode",
+    "wm_flac_info", "wm_flac_decode", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy",
 )
 
 
@@ -120,6 +120,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_log_mel_workspace_bytes.argtypes = [i32, i32, i32]
     lib.wm_log_mel_workspace_bytes.restype = sz
     lib.wm_log_mel.argtypes = [vp, i32, i32, C.c_int64, vp, i32, vp, vp, vp, sz, vp]
+    lib.wm_decoder_step_multi.argtypes = [vp, i32, C.POINTER(C.POINTER(WmDecoderIO)), C.POINTER(vp), vp]
+    lib.wm_stream_create_cu_mask.argtypes = [C.POINTER(C.c_uint32), i32, C.POINTER(vp)]
+    lib.wm_stream_destroy.argtypes = [vp]
     lib.wm_flac_info.argtypes = [vp, sz, C.POINTER(WmFlacStreamInfo)]
     lib.wm_flac_decode.argtypes = [vp, sz, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.wm_step_advance.argtypes = [vp, vp]
@@ -173,3 +176,25 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+_MASKED_STREAMS = {}
+
+
+def create_masked_stream(cu_enabled, index: int = 0):
+    """A torch stream whose kernels run only on the CUs with a true entry in `cu_enabled` (CU i = entry i):
+    wm_stream_create_cu_mask wrapped as torch.cuda.ExternalStream (so wait_stream / synchronize work).
+    Streams are cached per (device, mask, index) for the life of the process: hardware queues are a scarce
+    resource (ROCm multiplexes streams onto GPU_MAX_HW_QUEUES of them), so callers share, never re-create."""
+    import torch
+    key = (torch.cuda.current_device(), tuple(bool(b) for b in cu_enabled), index)
+    if key not in _MASKED_STREAMS:
+        n_words = (len(cu_enabled) + 31) // 32
+        words = (C.c_uint32 * n_words)()
+        for i, on in enumerate(cu_enabled):
+            if on:
+                words[i // 32] |= 1 << (i % 32)
+        handle = C.c_void_p()
+        check(load_library().wm_stream_create_cu_mask(words, n_words, C.byref(handle)), "wm_stream_create_cu_mask")
+        _MASKED_STREAMS[key] = torch.cuda.ExternalStream(handle.value)
+    return _MASKED_STREAMS[key]

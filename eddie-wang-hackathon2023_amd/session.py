@@ -184,17 +184,17 @@ class Session(object):
         check(lib.wm_cross_kv(self._engine.handle, xa.data_ptr(), b, ptr_array(outs), ws.data_ptr(), ws.numel(),
                               stream), "wm_cross_kv")
 
-    def decoder_step(self, tokens: torch.Tensor, pos: torch.Tensor, cross: Sequence[torch.Tensor],
-                     past: Optional[Sequence[torch.Tensor]], past_capacity: int,
-                     present: Sequence[torch.Tensor], present_capacity: int, logits: torch.Tensor,
-                     n_past: int, stream: int, qkv_amax: Optional[torch.Tensor] = None, slot: int = 0,
-                     n_past_dev: Optional[torch.Tensor] = None, n_new: Optional[int] = None):
-        """tokens int32 [B, L] (any row stride: a column window of a wider buffer works);
-        past/present per layer [B,2,H,capacity,64]; present may be the same tensors as past
-        (in-place append)."""
+    def make_decoder_io(self, tokens: torch.Tensor, pos: torch.Tensor, cross: Sequence[torch.Tensor],
+                        past: Optional[Sequence[torch.Tensor]], past_capacity: int,
+                        present: Sequence[torch.Tensor], present_capacity: int, logits: torch.Tensor,
+                        n_past: int, qkv_amax: Optional[torch.Tensor] = None, slot: int = 0,
+                        n_past_dev: Optional[torch.Tensor] = None, n_new: Optional[int] = None) -> WmDecoderIO:
+        """The wm_decoder_io of one call.  tokens int32 [B, L] (any row stride: a column window of a wider
+        buffer works); past/present per layer [B,2,H,capacity,64]; present may be the same tensors as past
+        (in-place append).  The struct keeps its pointer arrays alive (`io._keep`)."""
         lib = self._engine.lib
         b, l = tokens.shape
-        if n_new is not None:          # graph capture: `tokens` is the whole [B, capacity] buffer
+        if n_new is not None:          # device step counter: `tokens` is the whole [B, capacity] buffer
             l = n_new
         assert tokens.dtype == torch.int32 and tokens.stride(1) == 1
         ws = self._workspace(("dec", b, l, slot), lib.wm_decoder_workspace_bytes(self._engine.handle, b, l))
@@ -215,4 +215,20 @@ class Session(object):
             qkv_amax = self.qkv_amax          # calibration hook set by torch_whisper_convert.py
         io.qkv_amax = qkv_amax.data_ptr() if qkv_amax is not None else None
         io.n_past_dev = n_past_dev.data_ptr() if n_past_dev is not None else None
-        check(lib.wm_decoder_step(self._engine.handle, C.byref(io), stream), "wm_decoder_step")
+        io._keep = (past_arr, present_arr, cross_arr, ws)
+        return io
+
+    def decoder_step(self, tokens, pos, cross, past, past_capacity, present, present_capacity, logits, n_past,
+                     stream: int, qkv_amax=None, slot: int = 0, n_past_dev=None, n_new=None):
+        io = self.make_decoder_io(tokens, pos, cross, past, past_capacity, present, present_capacity, logits, n_past,
+                                  qkv_amax, slot, n_past_dev, n_new)
+        check(self._engine.lib.wm_decoder_step(self._engine.handle, C.byref(io), stream), "wm_decoder_step")
+
+    def decoder_step_multi(self, ios: Sequence[WmDecoderIO], light_streams: Sequence[int], heavy_stream: int):
+        """One decode step of several utterance groups, interleaved layer by layer (wm_decoder_step_multi):
+        each group's short kernels on its own light stream, all cross-attention kernels on `heavy_stream`."""
+        n = len(ios)
+        io_ptrs = (C.POINTER(WmDecoderIO) * n)(*[C.pointer(io) for io in ios])
+        streams = (C.c_void_p * n)(*light_streams)
+        check(self._engine.lib.wm_decoder_step_multi(self._engine.handle, n, io_ptrs, streams, heavy_stream),
+              "wm_decoder_step_multi")

@@ -105,6 +105,21 @@ typedef struct wm_decoder_io {
 size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new);
 int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream);
 
+/* The same step for n_groups (<= 8) independent utterance groups at once, scheduled for the chip:
+ * group g's latency-bound kernels (weight-streaming GEMMs, row kernels, self-attention) are enqueued on
+ * light_streams[g]; every group's cross-attention kernel -- the HBM-bound part, 245.76 MB per utterance --
+ * goes to heavy_stream in (layer, group) order, tied to its group's stream by events.  With the light
+ * streams confined to a few CUs and the heavy stream to the rest (wm_stream_create_cu_mask) the short
+ * kernels of one group run at full speed WHILE another group streams its K/V; on ordinary streams the
+ * hardware queues starve them (scripts/cumask_probe.py).  Results are identical to n_groups calls of
+ * wm_decoder_step.  Eager launches only (CU masks do not survive hipGraph capture). */
+int wm_decoder_step_multi(const wm_engine* e, int n_groups, const wm_decoder_io* const* ios,
+                          const wm_stream_t* light_streams, wm_stream_t heavy_stream);
+/* A stream whose kernels only run on the CUs whose bit is set in mask[0..n_words) (bit i of word i/32 =
+ * CU i; MI355X: 256 CUs = 8 words).  hipExtStreamCreateWithCUMask behind the C ABI. */
+int wm_stream_create_cu_mask(const uint32_t* mask, int n_words, wm_stream_t* out);
+int wm_stream_destroy(wm_stream_t stream);
+
 /* ---- fused greedy step (device-side restatement of W/decoding.py:134-217,274-300) ----------------
  * Applies SuppressBlank / SuppressTokens / ApplyTimestampRules to the last-position logits of each
  * utterance, picks the arg-max, accumulates its log-probability, keeps finished rows at EOT and

@@ -257,6 +257,34 @@ def test_micro_batched_streams_give_identical_tokens(tmpdir_module):
     assert len({tuple(r) for r in t1.cpu().tolist()}) > 1          # rows differ: the test is not vacuous
 
 
+@pytest.mark.parametrize("n_groups,int8", [(2, False), (2, True), (3, True)])
+def test_cu_partitioned_schedule_gives_identical_tokens(tmpdir_module, n_groups, int8):
+    """wm_decoder_step_multi (cross-attention on its own CU set, short kernels on CU-masked streams, eager,
+    device step counter) against the single-stream hipGraph loop and the by-name reference loop."""
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3, weight_only=int8, int8_kv=int8,
+                       kv_scales=[0.05] * dims.n_text_layer if int8 else None)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    dec.sample_len = 12
+    mel = synthetic_mel(24, 2 * dims.n_audio_ctx, dims.n_mels, 41).cuda()
+    xa = enc.get_audio_features(mel)
+    dec.detect_language(xa)
+    dec.micro_batches, dec.cu_partition = n_groups, False
+    t1, lp1, nsp1 = dec.main_loop(xa)
+    dec.cu_partition = True
+    t2, lp2, nsp2 = dec.main_loop(xa)
+    t3, lp3, nsp3 = dec.main_loop(xa)                      # second call re-uses the cached call plan
+    assert ('partition', n_groups) in dec._state[24]['graphs']
+    for t, lp, nsp in ((t2, lp2, nsp2), (t3, lp3, nsp3)):
+        assert torch.equal(t1.cpu(), t.cpu())
+        assert torch.equal(lp1.cpu(), lp.cpu())
+        assert np.array_equal(nsp1, nsp)
+    tr, lpr, _ = dec.main_loop_reference(xa)
+    n = min(tr.shape[1], t2.shape[1])
+    assert torch.equal(tr[:, :n].cpu(), t2[:, :n].cpu())
+    assert len({tuple(r) for r in t1.cpu().tolist()}) > 1
+
+
 def test_detect_language_fast_equals_reference(tmpdir_module):
     dims = Dims(**synthetic.DIMS["micro-fullvocab"])
     eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
