@@ -31,7 +31,7 @@ constexpr int BM = 256, BK = 64, STAGES = 2, NWAVE = 8;
 
 // BN = 256 (N % 256 == 0: every large-v2 shape) or 128.  8 waves as 4 (M) x 2 (N); a wave owns
 // 64 x BN/2 outputs = 4 x TN MFMA blocks.
-template <int BN>
+template <int BN, int ACT>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU (compile-time: keeps the epilogue small)
 __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
     using namespace f16gemm;
     constexpr int A_STAGE = BM * BK * 2, B_STAGE = BN * BK * 2, STAGE = A_STAGE + B_STAGE;
@@ -116,76 +116,81 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------
-    // Operands were swapped, so a lane holds 4 CONSECUTIVE output channels of one token row per block:
-    // bias / activation / q-k scaling are applied on those in registers (fp32 -> the Linear's fp16
-    // output), the fp16 tile of the wave (64 x BN/2) is transposed through LDS (the ring is free), and
-    // the residual add + store then run on whole 16-byte row segments: all residual loads of a lane
-    // are issued before the first store (a store in between would make the counted vmcnt wait for it).
-    __builtin_amdgcn_s_barrier();                                   // every wave is done reading the ring
+    // Operands were swapped, so a lane holds 4 CONSECUTIVE output channels of one token row per block: bias,
+    // activation, q-k scaling and the residual are applied on those in registers and go out as 8-byte
+    // accesses straight from the accumulator layout (a wave instruction covers 16 rows x 32 B).  Measured
+    // (scripts/lab/gemm_lab.hip, bench_gemm.py): cheaper than transposing the tile through LDS for 16-byte
+    // row segments -- 8.7 us per 256 x 256 tile instead of 24.7.
     constexpr int WN_COLS = BN / 2;                                 // columns per wave
-    constexpr int EPLD = WN_COLS + 8;                               // halves per staged row (16-byte pad)
-    h16* ep = (h16*)smem + (size_t)wid * 64 * EPLD;
-    {
-        half4v b4[TN];
+    const bool scale_cols = p.colscale_n > 0;
+    half4v b4[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = col0 + wc * WN_COLS + j * 16 + g * 4;
-            b4[j] = p.bias ? *(const half4v*)(p.bias + col) : half4v{0, 0, 0, 0};
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + wc * WN_COLS + j * 16 + g * 4;
+        b4[j] = p.bias ? *(const half4v*)(p.bias + col) : half4v{0, 0, 0, 0};
+    }
+    // every kernel-argument test sits OUTSIDE the element loops: one unrolled pass per optional step, so the
+    // epilogue stays a few hundred instructions (with the tests inside, the unrolled body grew to 18 000
+    // instructions and 1 100 branches -- more than the instruction cache -- and cost more than the K loop)
+    const int colw = col0 + wc * WN_COLS + g * 4;                   // this lane's first column
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wr * 64 + i * 16 + (lane & 15);
+        const int rowc = row < p.M ? row : p.M - 1;
+        half4v r4[TN];
+        if (p.residual) {                                           // all of this row's residual loads first
+            const h16* rrow = p.residual + (size_t)(p.res_mod > 0 ? rowc % p.res_mod : rowc) * p.ldr + colw;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) r4[j] = *(const half4v*)(rrow + j * 16);
         }
+        float v[TN][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[j][r] = r16(acc[i][j][r] + (float)b4[j][r]);      // the Linear's fp16 output
+        if (ACT == 1) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j][r] = r16(gelu_erf(v[j][r]));
+        } else if (ACT == 2) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j][r] = r16(gelu_tanh(v[j][r]));
+        }
+        if (scale_cols) {                                           // q, k * d^-0.25 (torch_model.py:93-95)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = col0 + wc * WN_COLS + j * 16 + g * 4;
-                half4v o;
+                const float sc = (colw + j * 16 < p.colscale_n) ? p.colscale : 1.0f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = r16(acc[i][j][r] + (float)b4[j][r]);            // the Linear's fp16 output
-                    if (p.act == 1) v = r16(gelu_erf(v));
-                    else if (p.act == 2) v = r16(gelu_tanh(v));
-                    if (col < p.colscale_n) v = r16(v * p.colscale);          // q, k * d^-0.25 (torch_model.py:93-95)
-                    o[r] = (h16)v;
-                }
-                *(half4v*)(ep + (i * 16 + (lane & 15)) * EPLD + j * 16 + g * 4) = o;
+                for (int r = 0; r < 4; ++r) v[j][r] = r16(v[j][r] * sc);
             }
         }
-    }
-    // one wave's private LDS region: program order + lgkmcnt are enough, no barrier
-    constexpr int SEG = WN_COLS / 8;                                // 16-byte segments per row (8 or 16)
-    constexpr int RPI = 64 / SEG;                                   // rows covered per wave-instruction (8 or 4)
-    constexpr int NIT = 64 / RPI;                                   // iterations (8 or 16)
-    const int cseg = (lane % SEG) * 8, rsub = lane / SEG;
-    const int colw = col0 + wc * WN_COLS + cseg;
-    half8v res[NIT];
-    if (p.residual) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            int row = row0 + wr * 64 + it * RPI + rsub;
-            if (row > p.M - 1) row = p.M - 1;
-            res[it] = *(const half8v*)(p.residual + (size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.ldr + colw);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int rl = it * RPI + rsub;
-        const int row = row0 + wr * 64 + rl;
-        half8v o = *(const half8v*)(ep + rl * EPLD + cseg);
         if (p.residual) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (h16)((float)o[e] + (float)res[it][e]);
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[j][r] += (float)r4[j][r];
         }
         if (row >= p.M) continue;
-        size_t off;
         if (p.out_mode == 0) {
-            off = p.c_rows > 0 ? (size_t)(row / p.c_rows) * p.c_bstride + (size_t)(row % p.c_rows) * p.ldc + colw
-                               : (size_t)row * p.ldc + colw;
-        } else {   // head-split [B, 2, H, T, 64] (whisper/model.py:519); 8 channels stay inside one head
+            h16* crow = p.C + (p.c_rows > 0 ? (size_t)(row / p.c_rows) * p.c_bstride + (size_t)(row % p.c_rows) * p.ldc
+                                            : (size_t)row * p.ldc) + colw;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *(half4v*)(crow + j * 16) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
+        } else {       // head-split [B, 2, H, T, 64] (whisper/model.py:519); a lane's 4 channels stay inside one head
             const int HC = p.hs_H * 64;
-            const int kv = p.hs_kv < 0 ? colw / HC : p.hs_kv, cc = p.hs_kv < 0 ? colw % HC : colw;
-            const int bb = row / p.hs_T, t = row % p.hs_T, h = cc >> 6, d = cc & 63;
-            off = ((((size_t)bb * 2 + kv) * p.hs_H + h) * p.hs_T + t) * 64 + d;
+            const int bb = row / p.hs_T, t = row % p.hs_T;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = colw + j * 16;
+                const int kv = p.hs_kv < 0 ? col / HC : p.hs_kv, cc = p.hs_kv < 0 ? col % HC : col;
+                const size_t off = ((((size_t)bb * 2 + kv) * p.hs_H + (cc >> 6)) * p.hs_T + t) * 64 + (cc & 63);
+                *(half4v*)(p.C + off) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
+            }
         }
-        *(half8v*)(p.C + off) = o;
     }
 }
 
@@ -200,19 +205,20 @@ int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream) {
     const bool wide = (p.N % 256 == 0);
     const int bn = wide ? 256 : 128;
     const int grid = ((p.M + BM - 1) / BM) * (p.N / bn);
-    // ring, or the epilogue's per-wave fp16 staging tile (8 waves x 64 rows x (bn/2 + 8) halves), whichever is larger
-    const size_t ring = (size_t)STAGES * (BM + bn) * BK * 2, stage = (size_t)8 * 64 * (bn / 2 + 8) * 2;
-    const size_t lds = ring > stage ? ring : stage;
+    const size_t lds = (size_t)STAGES * (BM + bn) * BK * 2;         // the K-tile ring
+    WM_REQUIRE(p.act >= 0 && p.act <= 2, "gemm_f16: act=%d", p.act);
+    using Kern = void (*)(GemmBigParams);
+    static const Kern kerns[2][3] = {{gemm_f16_kernel<256, 0>, gemm_f16_kernel<256, 1>, gemm_f16_kernel<256, 2>},
+                                     {gemm_f16_kernel<128, 0>, gemm_f16_kernel<128, 1>, gemm_f16_kernel<128, 2>}};
     static bool attr_set = false;
     if (!attr_set) {
-        WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         8 * 64 * (128 + 8) * 2 > STAGES * (BM + 256) * BK * 2 ? 8 * 64 * (128 + 8) * 2 : STAGES * (BM + 256) * BK * 2));
-        WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         STAGES * (BM + 128) * BK * 2));
+        for (int a = 0; a < 3; ++a) {
+            WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[0][a], hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * (BM + 256) * BK * 2));
+            WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[1][a], hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * (BM + 128) * BK * 2));
+        }
         attr_set = true;
     }
-    if (wide) hipLaunchKernelGGL(gemm_f16_kernel<256>, dim3(grid), dim3(512), lds, stream, p);
-    else hipLaunchKernelGGL(gemm_f16_kernel<128>, dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(kerns[wide ? 0 : 1][p.act], dim3(grid), dim3(512), lds, stream, p);
     WM_LAUNCH_CHECK(stream, "gemm_f16");
     return 0;
 }

@@ -7,8 +7,12 @@ lib = native.load_library()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 M = 1500 * B
 for (N, K, act, res) in [(3840, 1280, 0, 0), (1280, 1280, 0, 1), (5120, 1280, 1, 0), (1280, 5120, 0, 1), (2560, 1280, 0, 0)]:
-    A = (torch.randn(M, K, device="cuda") * 0.5).half()
-    W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    if os.environ.get("LAB_DATA"):      # the value distribution of scripts/lab/gemm_lab.hip (MFMA power is data dependent)
+        A = (torch.randint(-1000, 1001, (M, K), device="cuda") / 1000.0).half()
+        W = (torch.randint(-1000, 1001, (N, K), device="cuda") / 30000.0).half()
+    else:
+        A = (torch.randn(M, K, device="cuda") * 0.5).half()
+        W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
     bias = torch.randn(N, device="cuda").half()
     R = torch.randn(M, N, device="cuda").half() if res else None
     C = torch.empty(M, N, device="cuda", dtype=torch.float16)
@@ -16,11 +20,12 @@ for (N, K, act, res) in [(3840, 1280, 0, 0), (1280, 1280, 0, 1), (5120, 1280, 1,
     def run():
         native.check(lib.wm_gemm(A.data_ptr(), K, M, K, W.data_ptr(), N, 0, None, bias.data_ptr(),
                                  R.data_ptr() if res else None, N, act, C.data_ptr(), N, s))
+    REPS = int(os.environ.get('REPS', '10'))
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10): run()
+    for _ in range(REPS): run()
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
+    ms = e0.elapsed_time(e1) / REPS
     print(f"M={M} N={N} K={K} act={act} res={res}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.0f} TFLOP/s", flush=True)

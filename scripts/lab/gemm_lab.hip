@@ -165,18 +165,14 @@ int main() {
     h16 *bias, *R;
     CK(hipMalloc(&bias, 5120 * 2)); CK(hipMemset(bias, 0, 5120 * 2));
     CK(hipMalloc(&R, (size_t)M * 5120 * 2)); CK(hipMemset(R, 0, (size_t)M * 5120 * 2));
-    struct S { int N, K; } shapes[] = {{1280, 1280}, {3840, 1280}, {5120, 1280}, {1280, 5120}};
+    struct S { int N, K; } shapes[] = {{1280, 640}, {1280, 1280}, {1280, 2560}, {1280, 5120}, {3840, 1280}, {5120, 1280}};
     for (auto sh : shapes) {
         const int N = sh.N, K = sh.K;
-        run<256, 128, 4, 2, 2, 0, 0>("256x128 2st minimal-epi", A, W, C, M, N, K);
-        run<256, 128, 4, 2, 2, 0, 1>("256x128 2st swapped epi bias", A, W, C, M, N, K, bias);
-        run<256, 128, 4, 2, 2, 0, 1>("256x128 2st swapped epi bias+res", A, W, C, M, N, K, bias, R);
-        run<256, 128, 4, 2, 2, 0, 2>("256x128 2st swapped epi bias+gelu", A, W, C, M, N, K, bias);
         run<256, 256, 4, 2, 2, 0, 0>("256x256 2st minimal-epi", A, W, C, M, N, K);
+        run<256, 256, 4, 2, 2, 2, 0>("256x256 2st minimal-epi NO MFMA", A, W, C, M, N, K);
+        run<256, 256, 4, 2, 2, 1, 0>("256x256 2st minimal-epi NO loads", A, W, C, M, N, K);
         run<256, 256, 4, 2, 2, 0, 1>("256x256 2st swapped epi bias", A, W, C, M, N, K, bias);
         run<256, 256, 4, 2, 2, 0, 1>("256x256 2st swapped epi bias+res", A, W, C, M, N, K, bias, R);
-        run<256, 256, 4, 2, 2, 0, 2>("256x256 2st swapped epi bias+gelu", A, W, C, M, N, K, bias);
-        run<128, 128, 2, 2, 2, 0, 1>("128x128 2st(2WG) swapped epi bias+res", A, W, C, M, N, K, bias, R);
     }
     return 0;
 }
