@@ -21,6 +21,8 @@
 //  * K/V tiles of 64 keys are register-staged one tile ahead into a double-buffered LDS image
 //    with 144-byte rows; one barrier per tile.  Each wave owns QB blocks of 16 queries and
 //    re-uses every K / V fragment for all of them.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -31,7 +33,7 @@ constexpr int AROW = 144;                      // LDS bytes per key row (64 halv
 constexpr int KV_TILE = KT_KEYS * AROW;        // 9216
 
 template <int QB>
-__global__ __launch_bounds__(256) void attn_encoder_kernel(AttnEncParams p) {
+__global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {     // 2 waves per SIMD: <= 256 registers
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * KV_TILE];
     auto sK = [&](int b) { return smem + b * 2 * KV_TILE; };
     auto sV = [&](int b) { return smem + b * 2 * KV_TILE + KV_TILE; };
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(256) void attn_encoder_kernel(AttnEncParams p) {
     // V transposed read: lane i of its 16-lane group supplies row (i >> 2), columns 4 * (i & 3) ..
     const int v_off = (4 * g + (li >> 2)) * AROW + (li & 3) * 8;
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile_body = [&](int t, auto TAIL_) {
+        constexpr bool TAIL = decltype(TAIL_)::value;     // only the last tile masks keys >= T
         const int cur = t & 1;
         if (t + 1 < ntiles) load_kv(t + 1);
 
@@ -120,39 +123,49 @@ __global__ __launch_bounds__(256) void attn_encoder_kernel(AttnEncParams p) {
         }
         // ---- mask the tail, round to fp16, online softmax (per lane = per query) ------------------
         const int key0 = t * KT_KEYS + 4 * g;          // + 16 kb + r
-        const bool tail = (t == ntiles - 1) && (p.T % KT_KEYS != 0);
         half8v pf[2][QB];                              // P^T fragments per 32-key chunk
+        constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
+            // the maximum is taken on the raw scores and rounded once (rounding is monotonic); scores and
+            // probabilities are rounded to fp16 in pairs (v_cvt_pk_f16_f32), exp(s - m) is one mixed-precision
+            // fma + v_exp_f32 on the fp16 score, the row sum one v_dot2 per pair
             float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float s = r16(sacc[kb][qb][r]);
-                    if (tail && key0 + 16 * kb + r >= p.T) s = -INFINITY;
-                    sacc[kb][qb][r] = s;
-                    mx = fmaxf(mx, s);
+                    if (TAIL && key0 + 16 * kb + r >= p.T) sacc[kb][qb][r] = -INFINITY;
+                    mx = fmaxf(mx, sacc[kb][qb][r]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qb], mx);
-            const float alpha = __expf(m_run[qb] - m_new);
+            const float m_old = m_run[qb];
+            const float m_new = fmaxf(m_old, r16(mx));
+            const float mL = m_new * LOG2E;
+            const float alpha = __builtin_amdgcn_exp2f(m_old * LOG2E - mL);       // exp(m_old - m_new); 0 on the first tile
             m_run[qb] = m_new;
             float ps = 0.f;
+            const half2v one2 = {(h16)1.0f, (h16)1.0f};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const h16 ph = (h16)__expf(sacc[kb][qb][r] - m_new);
-                    ps += (float)ph;
-                    pf[kb >> 1][qb][(kb & 1) * 4 + r] = ph;
+                for (int r = 0; r < 4; r += 2) {
+                    const half2v s2 = __builtin_convertvector(float2v{sacc[kb][qb][r], sacc[kb][qb][r + 1]}, half2v);
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf((float)s2[0], LOG2E, -mL));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf((float)s2[1], LOG2E, -mL));
+                    const half2v p2 = __builtin_convertvector(float2v{p0, p1}, half2v);
+                    ps = __builtin_amdgcn_fdot2(p2, one2, ps, false);
+                    pf[kb >> 1][qb][(kb & 1) * 4 + r] = p2[0];
+                    pf[kb >> 1][qb][(kb & 1) * 4 + r + 1] = p2[1];
                 }
             ps += __shfl_xor(ps, 16);
             ps += __shfl_xor(ps, 32);
             l_run[qb] = l_run[qb] * alpha + ps;
+            if (__builtin_amdgcn_ballot_w64(m_new != m_old)) {      // wave-uniform: skip the accumulator round trip while
 #pragma unroll
-            for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
+                for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;  // no query's maximum moved (alpha == 1 exactly)
+            }
         }
         // ---- O^T += V^T . P^T ------------------------------------------------------------------------
 #pragma unroll
@@ -175,7 +188,9 @@ __global__ __launch_bounds__(256) void attn_encoder_kernel(AttnEncParams p) {
         }
         if (t + 1 < ntiles) store_kv(cur ^ 1);
         __syncthreads();
-    }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) tile_body(t, std::false_type{});
+    if (p.T % KT_KEYS != 0) tile_body(ntiles - 1, std::true_type{}); else tile_body(ntiles - 1, std::false_type{});
 
     // ---- normalise and store: lane owns query li, dims 16 db + 4 g + r ------------------------------
 #pragma unroll

@@ -9,6 +9,7 @@ namespace wm {
 
 typedef _Float16 h16;
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
