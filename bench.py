@@ -39,7 +39,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-CONFIGS = {"fp16": (False, False), "int8wo": (True, False), "int8kv": (False, True), "int8": (True, True)}
+CONFIGS = {"fp16": (False, False), "int8wo": (True, False), "int8kv": (False, True), "int8": (True, True),
+           "int4": ("int4", True)}       # weight-only precision (False / True = int8 / "int4"), int8 KV cache
+WORKLOADS = {"fp16": "fp16 GEMMs + fp16 self-KV + fp16 cross-KV", "int8wo": "weight-only int8 GEMMs + fp16 self-KV + fp16 cross-KV",
+             "int8kv": "fp16 GEMMs + int8 self-KV + fp16 cross-KV", "int8": "weight-only int8 GEMMs + int8 self-KV + fp16 cross-KV",
+             "int4": "weight-only int4 GEMMs + int8 self-KV + fp16 cross-KV"}
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
 
@@ -69,7 +73,7 @@ def build_engines(args, out_dir: Path):
     t0 = time.time()
     ck = synthetic.synthetic_checkpoint(args.model, args.seed, device="cuda")
     argv = ["--output_dir", str(out_dir), "--log_level", "error", "--use_gpt_attention_plugin", "--use_gemm_plugin",
-            "--use_layernorm_plugin"] + (["--use_weight_only"] if wo else [])
+            "--use_layernorm_plugin"] + (["--use_weight_only"] if wo else []) + (["--weight_only_precision", "int4"] if wo == "int4" else [])
     if i8kv:
         # int8-KV calibration.  The reference calibrates the un-quantised fp16 model; to keep
         # the bench start-up short this uses the engines of the same weight precision with an fp16 cache.
@@ -229,14 +233,14 @@ def main():
         value = n_total * T / (ms_per_step * 1e-3)
         result = {
             "metric": "decode tokens/s, whole job (encoder + cross-KV + language-ID + prefill + greedy decode), "
-                      "Whisper large-v2 int8 weight-only + int8 KV; rtf reported beside it",
+                      f"Whisper {args.model} " + ("int8 weight-only + int8 KV" if args.config == "int8" else args.config)
+                      + "; rtf reported beside it",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "rtf": round((ms_per_step * 1e-3) / (B * 30.0), 6),
             "utterances_per_s": round(n_total / (ms_per_step * 1e-3), 2),
-            "config": {"workload": f"whisper {args.model} {args.config}: weight-only int8 GEMMs + int8 self-KV + fp16 "
-                                   f"cross-KV; {B} x 30 s utterances per GPU per step, {T} forced greedy tokens each "
+            "config": {"workload": f"whisper {args.model} {args.config}: {WORKLOADS[args.config]}; {B} x 30 s utterances per GPU per step, {T} forced greedy tokens each "
                                    f"(+3-token prefill, +1-token language-ID pass); random-init weights",
                        "batch_per_gpu": B, "decode_steps": T, "parallelism": f"dp{world} (utterance sharding, no "
                                                                             f"data-path collective)"},

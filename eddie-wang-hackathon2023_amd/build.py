@@ -89,8 +89,6 @@ def parse_arguments(args=None):
             setattr(args, plugin_arg, args.dtype)
     if args.dtype != 'float16':
         raise ValueError("the gfx950 engine computes in float16 (the reference's Whisper build is float16 only)")
-    if args.use_weight_only and args.weight_only_precision == 'int4':
-        raise NotImplementedError("int4 weight-only is listed under SURVEY section 8f (next); int8 is implemented")
     if args.world_size != 1:
         raise ValueError("Whisper engines are built with tensor_parallel=1 (W/build.py:159,234)")
     return args
@@ -115,6 +113,11 @@ def save_config(builder_config: dict, plugin_config: dict, config_path: str):
     logger.info(f'Config saved to {config_path}.')
 
 
+def _wo(args):
+    """False, 'int8' or 'int4': what the weight loaders take (W/build.py:102-112 maps the same pair of flags to QuantMode)."""
+    return args.weight_only_precision if args.use_weight_only else False
+
+
 def _flags(args, int8_kv=False) -> int:
     f = 0
     if args.use_weight_only:
@@ -133,7 +136,7 @@ def build_encoder(model, args):
         num_heads=md['n_audio_head'], hidden_size=md['n_audio_state'], max_batch_size=args.max_batch_size,
         int8=False, fp8=False, timing_cache=None, opt_level=None, use_refit=False, strongly_typed=False,
         num_mels=md['n_mels'], num_audio_ctx=md['n_audio_ctx'])
-    tensors = load_encoder_weight(md, params, md['n_audio_layer'], use_weight_only=args.use_weight_only)
+    tensors = load_encoder_weight(md, params, md['n_audio_layer'], use_weight_only=_wo(args))
     blob = W.serialize_engine_blob(W.ENGINE_ENCODER, _flags(args), md, tensors)
     save_config(builder_config, _plugin_config(args), os.path.join(args.output_dir, 'encoder_config.json'))
     serialize_engine(blob, os.path.join(args.output_dir, get_engine_name(MODEL_ENCODER_NAME, 'float16', 1, 0)))
@@ -152,7 +155,7 @@ def build_decoder(model, args):
         use_int8_kv_cache=bool(args.int8_kv_cache), int8=bool(args.int8_kv_cache), fp8=False, timing_cache=None,
         opt_level=None, use_refit=False, strongly_typed=False)
     tensors = load_decoder_weight(params, md['n_text_layer'], args.quantize_dir,
-                                  use_weight_only=args.use_weight_only, use_int8_kv_cache=args.int8_kv_cache)
+                                  use_weight_only=_wo(args), use_int8_kv_cache=args.int8_kv_cache)
     blob = W.serialize_engine_blob(W.ENGINE_DECODER, _flags(args, args.int8_kv_cache), md, tensors)
     save_config(builder_config, _plugin_config(args), os.path.join(args.output_dir, 'decoder_config.json'))
     serialize_engine(blob, os.path.join(args.output_dir, get_engine_name(MODEL_DECODER_NAME, args.dtype, 1, 0)))
@@ -164,7 +167,7 @@ def build_crossattn_kv_linear(model, args):
         name=MODEL_CROSSATTN_NAME, precision='float16', tensor_parallel=1, num_layers=md['n_text_layer'],
         num_heads=md['n_text_head'], int8=False, fp8=False, timing_cache=None, opt_level=None, use_refit=False,
         strongly_typed=False, hidden_size=md['n_text_state'], num_audio_ctx=md['n_audio_ctx'])
-    tensors = load_crossattn_linear_weight(params, md['n_text_layer'], use_weight_only=args.use_weight_only)
+    tensors = load_crossattn_linear_weight(params, md['n_text_layer'], use_weight_only=_wo(args))
     blob = W.serialize_engine_blob(W.ENGINE_CROSS_KV, _flags(args), md, tensors)
     save_config(builder_config, _plugin_config(args), os.path.join(args.output_dir, 'cross_attn_config.json'))
     serialize_engine(blob, os.path.join(args.output_dir, get_engine_name(MODEL_CROSSATTN_NAME, 'float16', 1, 0)))

@@ -53,7 +53,7 @@ struct BlobHeader {
 };
 struct BlobTensor {
     char name[64];
-    uint32_t dtype;           // 0 f16, 1 i8, 2 f32, 3 i32
+    uint32_t dtype;           // 0 f16, 1 i8, 2 f32, 3 i32, 4 packed int4 (two biased nibbles per byte)
     uint32_t ndim;
     uint64_t shape[4];
     uint64_t offset;          // from data_offset, 256-byte aligned
@@ -66,6 +66,7 @@ struct Tensor { const unsigned char* ptr = nullptr; uint32_t dtype = 0; uint64_t
 struct Lin {                  // one Linear: weight (row-major or tile-linear), optional scale, bias
     const void* w = nullptr; const h16* s = nullptr; const h16* b = nullptr;
     int N = 0, K = 0, n_blocks = 0;
+    int wcode = 0;            // weight encoding for the skinny GEMM: 0 fp16, 1 int8, 4 packed int4
 };
 struct EncLayer { const h16 *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, out, mlp1, mlp2; };
 struct DecLayer {
@@ -116,11 +117,16 @@ int get_lin(const wm_engine* e, const std::string& base, bool tiled, bool quanti
     if (find(e, base + (tiled ? ".t" : ".w"), &w)) return 1;
     l->w = w.ptr;
     const bool q = quantisable && e->w8();
-    if ((w.dtype == 1) != q) { set_error("tensor %s: dtype does not match the engine's weight-only flag", base.c_str()); return 1; }
+    const bool packed4 = w.dtype == 4;
+    if ((w.dtype == 1 || packed4) != q || (packed4 && !tiled)) {
+        set_error("tensor %s: dtype does not match the engine's weight-only flag", base.c_str());
+        return 1;
+    }
+    l->wcode = packed4 ? 4 : (q ? 1 : 0);
     if (tiled) {           // shape = [n_blocks, k_tiles, 64, 16 bytes]
         l->n_blocks = (int)w.shape[0];
         l->N = l->n_blocks * 16;
-        l->K = (int)w.shape[1] * (q ? 64 : 32);
+        l->K = (int)w.shape[1] * (packed4 ? 128 : (q ? 64 : 32));
     } else {
         l->N = (int)w.shape[0]; l->K = (int)w.shape[1];
     }
@@ -438,7 +444,7 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
     // split-K slabs: the widest product is ksplit * N over the six Linears; ksplit <= 24 by construction
     size_t widest = 0;
     const int Mc = (int)(M < 128 ? M : 128);
-    const bool q = e->w8();
+    const int q = e->dec.empty() ? (e->w8() ? 1 : 0) : e->dec[0].qkv.wcode;     // every Linear of an engine shares one encoding
     const int Ns[6] = {(int)(3 * C), (int)C, (int)C, (int)C, (int)(4 * C), (int)C};
     const int Ks[6] = {(int)C, (int)C, (int)C, (int)C, (int)C, (int)(4 * C)};
     for (int i = 0; i < 6; ++i) {
@@ -456,11 +462,11 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
 // skinny GEMM over all M rows in chunks of 64; slabs laid out [ksplit][M_total][ldp]
 int skinny_all(const Lin& l, const h16* A, int lda, int M, float* part, int* ksplit_out, hipStream_t s) {
     const int Mc = M < 128 ? M : 128;
-    const int ks = skinny_default_ksplit(Mc, l.K, l.n_blocks, l.s != nullptr);
+    const int ks = skinny_default_ksplit(Mc, l.K, l.n_blocks, l.wcode);
     for (int r0 = 0; r0 < M; r0 += 128) {
         GemmSkinnyParams p{};
         p.A = A + (size_t)r0 * lda; p.lda = lda; p.M = (M - r0) < 128 ? (M - r0) : 128; p.K = l.K;
-        p.Wt = l.w; p.n_blocks = l.n_blocks; p.w8 = l.s != nullptr; p.scale = l.s; p.ksplit = ks;
+        p.Wt = l.w; p.n_blocks = l.n_blocks; p.w8 = l.wcode; p.scale = l.s; p.ksplit = ks;
         p.part = part + (size_t)r0 * l.N; p.part_sstride = (long)M * l.N;
         if (launch_gemm_skinny(p, s)) return 2;
     }

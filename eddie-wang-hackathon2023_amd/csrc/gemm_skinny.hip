@@ -1,4 +1,4 @@
-// Weight-streaming GEMM for the decode path: M <= 64 activation rows (M = B for a decode step,
+// Weight-streaming GEMM for the decode path: M <= 128 activation rows (M = B for a decode step,
 // 3B for the prefill) against a weight matrix that is read from HBM exactly once.
 //
 // Replaces WeightOnlyQuantMatmulPlugin::enqueue's M == 1 GEMV
@@ -13,6 +13,11 @@
 // contiguous HBM and lands every lane's bytes already in the B-operand layout of
 // v_mfma_f32_16x16x32_f16 (B[k = 8 * (lane >> 4) + j][n = lane & 15]); int8 tiles feed two MFMAs
 // (their first / second 8 inputs per lane) after an exact int8 -> fp16 expansion in registers.
+// Packed int4 (--weight_only_precision int4; weightOnlyMatrixVectorMultiplication.cu:207-277 in the
+// reference): KT = 128, a lane's 16 bytes are 32 biased nibbles (q + 8) for inputs 32 * (l >> 4) .. +32 of
+// channel l & 15, i.e. four MFMA B operands; inside each 32-bit word the nibble of input j sits at position
+// j/2 (j even) or 4 + j/2 (j odd), so that (word >> 4s) & 0x000F000F yields the fp16 pair (input 2s, 2s+1)
+// after OR-ing in the exponent of 1024 and subtracting 1032.
 // There is no LDS round trip for the streamed operand; only the small activation block is staged
 // in LDS (shared by the 4 waves of a workgroup, each wave owning a different 16-channel block).
 //
@@ -25,12 +30,13 @@
 namespace wm {
 
 
-template <bool W8, int MT, int NW>      // NW waves per workgroup share one staged activation chunk
+template <int WB, int MT, int NW>       // WB: weight bits (16, 8, 4); NW waves per workgroup share one staged activation chunk
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p) {
     constexpr int KC = MT > 4 ? 128 : 256;    // activation chunk staged per barrier (inputs); LDS <= 35 KB
     constexpr int A_ROW = KC * 2 + 16;        // LDS row stride in bytes
-    constexpr int KT = W8 ? 64 : 32;          // inputs per weight tile
-    constexpr int TPC = KC / KT;              // tiles per chunk: 4 (int8) / 8 (fp16)
+    constexpr bool W8 = WB == 8;
+    constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);   // inputs per 1 KiB weight tile
+    constexpr int TPC = KC / KT;              // tiles per chunk
     __shared__ __attribute__((aligned(16))) unsigned char sA[MT * 16 * A_ROW];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -79,7 +85,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
 #pragma unroll
             for (int i = 0; i < TPC; ++i) {
                 if (t0 + i < t_end) {
-                    if (W8) {
+                    if (WB == 4) {
+                        // lane's 32 inputs start at 32 * (lane >> 4) inside the 128-wide tile; word m feeds MFMA m
+                        const unsigned char* ab = sA + frag_row + (i * 128 + (lane >> 4) * 32) * 2;
+                        const uint32_t wv[4] = {wcur[i].x, wcur[i].y, wcur[i].z, wcur[i].w};
+                        const half2v bias8 = {(h16)1032.0f, (h16)1032.0f};
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            half8v b;
+#pragma unroll
+                            for (int sft = 0; sft < 4; ++sft) {
+                                const uint32_t bits = ((wv[m] >> (4 * sft)) & 0x000F000Fu) | 0x64006400u;   // fp16 (1024 + u) x 2
+                                const half2v pr = __builtin_bit_cast(half2v, bits) - bias8;                  // u - 8 = q, exact
+                                b[2 * sft] = pr[0]; b[2 * sft + 1] = pr[1];
+                            }
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) {
+                                const half8v a = *(const half8v*)(ab + mt * 16 * A_ROW + m * 16);
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[mt], 0, 0, 0);
+                            }
+                        }
+                    } else if (W8) {
                         half2v h[8];
                         cvt_s8x4_f16x4(wcur[i].x, h[0], h[1]);
                         cvt_s8x4_f16x4(wcur[i].y, h[2], h[3]);
@@ -117,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
 
     if (!wave_active) return;
     const int col = nb * 16 + (lane & 15);
-    const float sc = (W8 && p.scale) ? (float)p.scale[col] : 1.0f;
+    const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
     const int ldp = p.n_blocks * 16;
     const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.M * ldp;
 #pragma unroll
@@ -139,12 +165,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
 static inline int skinny_waves(int M) { return M > 32 ? 8 : 4; }
 constexpr int SKINNY_MAX_M = 128;   // bigger activation block -> share it wider
 
+static inline int skinny_kt(int w8) { return w8 == 4 ? 128 : (w8 ? 64 : 32); }    // w8: 0 fp16, 1 int8, 4 packed int4
+
 int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
-    const int kt_total = K / (w8 ? 64 : 32);
+    const int kt_total = K / skinny_kt(w8);
     const int nw = skinny_waves(M);
     const int nwg_n = (n_blocks + nw - 1) / nw;
     int s = (3072 / nw + nwg_n - 1) / nwg_n;      // aim for ~3000 waves in flight (12 per CU)                 // aim for ~3 workgroups per CU
-    const int min_tiles = w8 ? 2 : 4;                  // at least 2 KiB (int8) / 4 KiB (fp16) per wave
+    const int min_tiles = w8 == 4 ? 1 : (w8 ? 2 : 4);  // at least 128 inputs per slice
     s = min(s, max(1, kt_total / min_tiles));
     // the fp32 slabs (s * M * N * 4 B) are written and re-read through L2 / Infinity Cache: keep them
     // under ~16 MB so that they stay on-die; below that, more slices = more bytes in flight, which is
@@ -158,30 +186,31 @@ int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
     return max(1, s);
 }
 
-template <bool W8>
+template <int WB>
 static int launch_mt(const GemmSkinnyParams& p, hipStream_t stream) {
     const int mt = (p.M + 15) / 16;
     const int g4 = ((p.n_blocks + 3) / 4) * p.ksplit, g8 = ((p.n_blocks + 7) / 8) * p.ksplit;
     switch (mt) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 1, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 2, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 3, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 4, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 6, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<W8, 8, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 1, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 2, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 3, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 4, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 6, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 8, 8>), dim3(g8), dim3(512), 0, stream, p); break;
     }
     return 0;
 }
 
 int launch_gemm_skinny(const GemmSkinnyParams& p, hipStream_t stream) {
     WM_REQUIRE(p.M >= 1 && p.M <= SKINNY_MAX_M, "gemm_skinny: M=%d out of range [1,%d]", p.M, SKINNY_MAX_M);
-    const int KT = p.w8 ? 64 : 32;
+    const int KT = skinny_kt(p.w8);
+    WM_REQUIRE(p.w8 == 0 || p.w8 == 1 || p.w8 == 4, "gemm_skinny: w8=%d (0 fp16, 1 int8, 4 packed int4)", p.w8);
     WM_REQUIRE(p.K % KT == 0, "gemm_skinny: K=%d must be a multiple of %d", p.K, KT);
     WM_REQUIRE(p.lda % 8 == 0, "gemm_skinny: lda=%d must be a multiple of 8", p.lda);
     WM_REQUIRE(p.ksplit >= 1, "gemm_skinny: ksplit must be >= 1");
     WM_REQUIRE(p.out == nullptr || p.ksplit == 1, "gemm_skinny: direct output needs ksplit == 1");
     WM_REQUIRE(p.out != nullptr || p.part != nullptr, "gemm_skinny: no output buffer");
-    if (p.w8) launch_mt<true>(p, stream); else launch_mt<false>(p, stream);
+    if (p.w8 == 4) launch_mt<4>(p, stream); else if (p.w8) launch_mt<8>(p, stream); else launch_mt<16>(p, stream);
     WM_LAUNCH_CHECK(stream, "gemm_skinny");
     return 0;
 }

@@ -40,7 +40,7 @@ FLAG_WEIGHT_ONLY_INT8, FLAG_INT8_KV, FLAG_GELU_TANH = 1, 2, 4
 DIM_KEYS = ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
             "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")
 _DTYPE_CODE = {np.dtype(np.float16): 0, np.dtype(np.int8): 1, np.dtype(np.float32): 2, np.dtype(np.int32): 3,
-               np.dtype(np.uint8): 1}
+               np.dtype(np.uint8): 4}          # uint8 = two biased int4 values per byte (tile_linear_int4)
 
 
 def _np(t) -> np.ndarray:
@@ -76,24 +76,37 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.
 # weight-only int8
 # ---------------------------------------------------------------------------------------------
 
-def _symmetric_quantize_t(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def _weight_bits(use_weight_only) -> int:
+    """0 (fp16) / 8 / 4 from the builder's `use_weight_only` + `weight_only_precision` pair: the loaders accept
+    False, True (= int8), 'int8' or 'int4'."""
+    if not use_weight_only:
+        return 0
+    if use_weight_only is True or use_weight_only == 'int8':
+        return 8
+    if use_weight_only == 'int4':
+        return 4
+    raise ValueError(f"unknown weight-only precision {use_weight_only!r}")
+
+
+def _symmetric_quantize_t(w: torch.Tensor, bits: int = 8) -> Tuple[torch.Tensor, torch.Tensor]:
     w = w.float()
+    half_range = float(1 << (bits - 1))
     absmax = w.abs().amax(dim=1)
-    scale = absmax * (1.0 / 128.0)
+    scale = absmax * (1.0 / half_range)
     safe = torch.where(scale > 0, scale, torch.ones_like(scale))
     r = w / safe[:, None]
     q = torch.trunc(r + torch.copysign(torch.full_like(r, 0.5), r))     # C round(): half away from zero
-    q = q.clamp_(-128, 127).to(torch.int8)
+    q = q.clamp_(-half_range, half_range - 1).to(torch.int8)
     q[scale == 0] = 0
     return q, scale.half()
 
 
-def symmetric_quantize(w_out_in) -> Tuple[np.ndarray, np.ndarray]:
-    """Per-output-channel symmetric int8 (cutlass_preprocessors.cpp:641-686):
-    scale = absmax / 128 in fp32, q = clip(round_half_away(w / scale), -128, 127), stored scale =
-    fp16(scale).  Input [out, in] (the reference quantises the transposed [in, out] matrix per
-    column, which is the same thing).  Returns (int8 [out, in], fp16 [out]) as numpy arrays."""
-    q, s = _symmetric_quantize_t(_t(w_out_in))
+def symmetric_quantize(w_out_in, bits: int = 8) -> Tuple[np.ndarray, np.ndarray]:
+    """Per-output-channel symmetric int8 / int4 (cutlass_preprocessors.cpp:641-708):
+    scale = absmax / 2^(bits-1) in fp32, q = clip(round_half_away(w / scale), -2^(bits-1), 2^(bits-1) - 1),
+    stored scale = fp16(scale).  Input [out, in] (the reference quantises the transposed [in, out] matrix per
+    column, which is the same thing).  Returns (int8 [out, in] holding the integer codes, fp16 [out])."""
+    q, s = _symmetric_quantize_t(_t(w_out_in), bits)
     return q.cpu().numpy(), s.cpu().numpy()
 
 
@@ -113,6 +126,44 @@ def _tile_linear_t(w: torch.Tensor) -> torch.Tensor:
     t = w.reshape(npad // 16, 16, k // kt, 4, per)          # (nb, n, kt, g, j)
     t = t.permute(0, 2, 3, 1, 4)                            # (nb, kt, g, n, j): lane = g * 16 + n
     return t.contiguous().reshape(npad // 16, k // kt, 64, per)
+
+
+_NIBBLE_OF_INPUT = [0, 4, 1, 5, 2, 6, 3, 7]      # input j of an 8-input group sits at nibble j/2 (even) or 4 + j/2 (odd)
+
+
+def _tile_linear_int4_t(q: torch.Tensor) -> torch.Tensor:
+    """int4 codes (int8 tensor, values -8..7) [N, K] -> packed tile-linear uint8 [N/16, K/128, 64, 16]: lane
+    l = 16 g + n holds channel n, inputs 128 kt + 32 g .. +32 as 32 biased nibbles (q + 8); 32-bit word m of the
+    lane is the B operand of MFMA m (inputs 8 m .. 8 m + 7 of the lane), nibble order _NIBBLE_OF_INPUT
+    (csrc/gemm_skinny.hip unpacks a word with four shift-and-mask steps)."""
+    n, k = q.shape
+    if k % 128:
+        raise ValueError(f"tile_linear_int4: K={k} must be a multiple of 128")
+    npad = (n + 15) // 16 * 16
+    if npad != n:
+        q = torch.cat([q, torch.zeros((npad - n, k), dtype=q.dtype, device=q.device)], dim=0)
+    u = (q.to(torch.int16) + 8).to(torch.uint8).reshape(npad // 16, 16, k // 128, 4, 4, 8)     # (nb, n, kt, g, m, j)
+    nib = torch.empty_like(u)
+    nib[..., _NIBBLE_OF_INPUT] = u                                                              # (.., nibble position)
+    packed = nib[..., 0::2] | (nib[..., 1::2] << 4)                                             # (nb, n, kt, g, m, byte)
+    packed = packed.permute(0, 2, 3, 1, 4, 5)                                                   # (nb, kt, g, n, m, byte)
+    return packed.contiguous().reshape(npad // 16, k // 128, 64, 16)
+
+
+def tile_linear_int4(q) -> np.ndarray:
+    return _tile_linear_int4_t(_t(q)).cpu().numpy()
+
+
+def untile_linear_int4(t: np.ndarray, n: int) -> np.ndarray:
+    """Inverse of tile_linear_int4 (tests): packed tiles -> int8 codes [n, K]."""
+    nb, kt = t.shape[:2]
+    b = t.reshape(nb, kt, 4, 16, 4, 4)                                      # (nb, kt, g, n, m, byte)
+    nib = np.empty(b.shape[:-1] + (8,), dtype=np.uint8)
+    nib[..., 0::2] = b & 15
+    nib[..., 1::2] = b >> 4
+    u = nib[..., _NIBBLE_OF_INPUT]                                          # (nb, kt, g, n, m, j)
+    q = u.astype(np.int16) - 8
+    return q.transpose(0, 3, 1, 2, 4, 5).reshape(nb * 16, kt * 128)[:n].astype(np.int8)
 
 
 def tile_linear(w) -> np.ndarray:
@@ -135,12 +186,14 @@ def _linear(out: Dict[str, np.ndarray], name: str, w, b, use_weight_only: bool, 
     """Add one Linear: weight `[out, in]` fp16, optional bias."""
     w = _t(w).half()
     n = w.shape[0]
-    if use_weight_only:
-        q, s = _symmetric_quantize_t(w)
+    bits = _weight_bits(use_weight_only)
+    if bits:
+        q, s = _symmetric_quantize_t(w, bits)
         if tiled:
             npad = (n + 15) // 16 * 16
             s = torch.cat([s, torch.zeros(npad - n, dtype=torch.float16, device=s.device)])
-            q = _tile_linear_t(q)
+            q = _tile_linear_int4_t(q) if bits == 4 else _tile_linear_t(q)     # row-major int4 codes stay one per byte:
+                                                                               # those matrices are expanded to fp16 at load
         out[name + (".t" if tiled else ".w")] = q.cpu().numpy()
         out[name + ".s"] = s.cpu().numpy()
     else:

@@ -210,6 +210,23 @@ def symmetric_quantize_int8(w_out_in: np.ndarray) -> Tuple[np.ndarray, np.ndarra
     return q, scale.astype(np.float16)
 
 
+def symmetric_quantize_int4(w_out_in: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Per-output-channel symmetric int4 (`--weight_only_precision int4`, W/build.py:102-112).
+
+    Same routine as int8 with bits_in_type = 4 (cutlass_preprocessors.cpp:641 quant_range_scale = 1 / 2^(bits-1);
+    :700-703 `round`, then clamp to [-8, 7] before packing): scale_f32 = absmax / 8, stored as fp16.
+    Returns (int8 array holding the codes -8..7 [out, in], scales fp16 [out])."""
+    w = np.asarray(w_out_in, dtype=np.float32)
+    absmax = np.abs(w).max(axis=1)
+    scale = (absmax * np.float32(1.0 / 8.0)).astype(np.float32)
+    safe = np.where(scale > 0, scale, np.float32(1.0))
+    r = w / safe[:, None]
+    q = np.sign(r) * np.floor(np.abs(r) + np.float32(0.5))   # C round(): half away from zero
+    q = np.clip(q, -8, 7).astype(np.int8)
+    q[scale == 0] = 0
+    return q, scale.astype(np.float16)
+
+
 def dequantize_int8(q: np.ndarray, scales_f16: np.ndarray) -> np.ndarray:
     """fp16(fp16(q) * scale_fp16): the per-element dequantisation both reference kernels apply
     before the multiply (weightOnlyMatrixVectorMultiplication.cu:44-53 `halves[i] *= scale`)."""
@@ -265,7 +282,7 @@ def _r(x: torch.Tensor, act: str) -> torch.Tensor:
 class OracleConfig:
     act: str = "float16"              # "float16" | "float32"
     gelu: str = "erf"                 # "erf" (torch path) | "tanh" (TRT path, functional.py:2044-2056)
-    weight_only: bool = False         # F7
+    weight_only: object = False       # F7: False, True (= int8) or 'int4'
     int8_kv: bool = False             # F2
     kv_scales: Optional[List[float]] = None   # t per decoder layer (F8)
 
@@ -290,7 +307,8 @@ class OracleModel:
             v = v.detach()
             is_linear_w = v.ndim == 2 and k.endswith(".weight") and ".blocks." in k and "_ln" not in k
             if cfg.weight_only and is_linear_w:
-                q, s = symmetric_quantize_int8(v.float().numpy())
+                quantize = symmetric_quantize_int4 if cfg.weight_only == 'int4' else symmetric_quantize_int8
+                q, s = quantize(v.float().numpy())
                 self.q[k] = (q, s)
                 self.p[k] = torch.from_numpy(dequantize_int8(q, s).astype(np.float32))
             else:

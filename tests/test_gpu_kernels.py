@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 import native  # noqa: E402
 import weight as W  # noqa: E402
 from oracle import decoding_rules as DR  # noqa: E402
-from oracle.whisper_oracle import (OracleConfig, OracleModel, Dims, symmetric_quantize_int8, kv_quantize,
+from oracle.whisper_oracle import (OracleConfig, OracleModel, Dims, symmetric_quantize_int8, symmetric_quantize_int4, kv_quantize,
                                    kv_dequantize, woq_reference_matmul, woq_colwise_atol)  # noqa: E402
 
 
@@ -85,7 +85,13 @@ def test_gemm_big(lib, M, N, K, w8, act, resid):
 def _run_skinny(lib, A, Wmat, w8, ksplit):
     M, K = A.shape
     N = Wmat.shape[0]
-    if w8:
+    if w8 == 4:
+        q, s = symmetric_quantize_int4(Wmat)
+        tiles = W.tile_linear_int4(q)
+        npad = tiles.shape[0] * 16
+        s_dev = dev(np.concatenate([s, np.zeros(npad - N, dtype=np.float16)]))
+        ref = (A.astype(np.float32) @ q.astype(np.float32).T) * s.astype(np.float32)[None, :]
+    elif w8:
         q, s = symmetric_quantize_int8(Wmat)
         tiles = W.tile_linear(q)
         npad = tiles.shape[0] * 16
@@ -113,6 +119,9 @@ def _run_skinny(lib, A, Wmat, w8, ksplit):
     (1, 272, 320, 1, 1), (3, 272, 320, 1, 3), (17, 128, 1280, 1, 5), (64, 1280, 1280, 1, 4),
     (1, 272, 320, 0, 1), (5, 200, 256, 0, 2), (33, 128, 1280, 0, 7), (64, 5120, 1280, 0, 3),
     (48, 1280, 5120, 1, 10), (96, 1280, 1280, 1, 4), (128, 3840, 1280, 1, 8), (128, 1280, 5120, 1, 8), (100, 272, 256, 0, 2),
+    # packed int4 tiles (K a multiple of 128): M = 1 GEMV, ragged N, every MT variant, split-K
+    (1, 272, 384, 4, 1), (3, 272, 384, 4, 3), (17, 128, 1280, 4, 5), (40, 1280, 1280, 4, 2), (64, 3840, 1280, 4, 10),
+    (90, 1280, 5120, 4, 8), (128, 5120, 1280, 4, 6),
 ])
 def test_gemm_skinny(lib, M, N, K, w8, ksplit):
     r = rng(M * 7 + N + K + w8)

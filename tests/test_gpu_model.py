@@ -46,11 +46,13 @@ def _write_kv_scales(qdir, scales):
 
 
 def build_engine(tmp, model_name, seed, weight_only=False, int8_kv=False, kv_scales=None):
-    out = os.path.join(tmp, f"eng_{model_name}_{int(weight_only)}{int(int8_kv)}")
+    out = os.path.join(tmp, f"eng_{model_name}_{weight_only if isinstance(weight_only, str) else int(weight_only)}{int(int8_kv)}")
     argv = ["--output_dir", out, "--use_gpt_attention_plugin", "--use_gemm_plugin", "--use_layernorm_plugin",
             "--log_level", "error"]
     if weight_only:
         argv.append("--use_weight_only")
+    if weight_only == "int4":
+        argv += ["--weight_only_precision", "int4"]
     if int8_kv:
         qdir = os.path.join(tmp, f"quantize_{model_name}", "1-gpu")
         _write_kv_scales(qdir, kv_scales)
@@ -111,7 +113,8 @@ def test_fp16_engine_matches_reference_golden(fx, tmpdir_module):
     assert np.abs(_flat(kv[0][:, 0]).float().cpu().numpy() - fx["f16_self_k0"]).max() < 2e-2
 
 
-@pytest.mark.parametrize("weight_only,int8_kv", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("weight_only,int8_kv", [(False, False), (True, False), (False, True), (True, True),
+                                                 ("int4", False), ("int4", True)])
 def test_engine_matches_oracle_all_configs(fx, tmpdir_module, weight_only, int8_kv):
     dims = Dims(**{k: int(v) for k, v in zip(fx["dims_keys"], fx["dims"])})
     seed = int(fx["seed"])

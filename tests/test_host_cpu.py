@@ -284,3 +284,37 @@ def test_log_mel_matches_reference_golden(golden_dir, tmp_path):
     assert tuple(wu.pad_or_trim(torch.ones(2, 10), 4).shape) == (2, 4)
     with pytest.raises(RuntimeError):
         wu.load_audio("clip.m4a")          # needs ffmpeg: not decodable here
+
+
+def test_int4_weight_only_quantiser_and_packing():
+    """--weight_only_precision int4 (cutlass_preprocessors.cpp:641-708): scale = absmax / 8, round half away, clamp
+    to [-8, 7]; the product quantiser equals the oracle's, and the packed tile layout round-trips."""
+    import weight as W
+    from oracle.whisper_oracle import symmetric_quantize_int4, dequantize_int8
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((40, 256)) * 0.1).astype(np.float16)
+    w[3] = 0                                           # an all-zero channel
+    w[7, :4] = [0.35, -0.35, 0.05, -0.05]              # ties and the asymmetric ends of the range
+    q, s = W.symmetric_quantize(w, bits=4)
+    qo, so = symmetric_quantize_int4(w)
+    np.testing.assert_array_equal(q, qo)
+    np.testing.assert_array_equal(s, so)
+    assert q.min() >= -8 and q.max() <= 7 and q.dtype == np.int8
+    absmax = np.abs(w.astype(np.float32)).max(axis=1)
+    np.testing.assert_array_equal(s, (absmax / 8).astype(np.float16))
+    assert (q[3] == 0).all() and s[3] == 0
+    # the channel maximum maps to +-8 before the clamp: +absmax -> 7 (clamped), -absmax -> -8
+    ch = int(np.argmax(absmax))
+    col = int(np.argmax(np.abs(w[ch].astype(np.float32))))
+    assert q[ch, col] == (7 if w[ch, col] > 0 else -8)
+    err = np.abs(dequantize_int8(q, s).astype(np.float32) - w.astype(np.float32))
+    live = absmax > 0
+    assert (err[live] <= (absmax[live, None] / 8) * 1.01 + 1e-3).all()       # within one step (the +7 clamp costs a full one)
+    tiles = W.tile_linear_int4(q)
+    assert tiles.shape == (3, 2, 64, 16) and tiles.dtype == np.uint8
+    np.testing.assert_array_equal(W.untile_linear_int4(tiles, 40), q)
+    # lane 16 g + n of tile (nb, kt): channel 16 nb + n, inputs 128 kt + 32 g ..: first word, first nibble = input 0
+    assert (tiles[1, 1, 16 * 2 + 5, 0] & 15) == q[16 + 5, 128 + 64] + 8
+    assert (tiles[1, 1, 16 * 2 + 5, 0] >> 4) == q[16 + 5, 128 + 64 + 2] + 8   # nibble 1 = input 2
+    with pytest.raises(ValueError):
+        W.tile_linear_int4(q[:, :192])
