@@ -23,6 +23,8 @@
 //   covers 8 whole rows (1 KiB contiguous), 8 lanes share a row and combine their partial dot
 //   products with three DPP-style shuffles.  Scores for the whole key range live in LDS, so the
 //   softmax is the exact two-pass one (no online rescaling), then V is streamed the same way.
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -426,14 +428,18 @@ __global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams 
     p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + d] = (h16)(num / den);
 }
 
-int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream) {
+int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     WM_REQUIRE(p.L >= 1 && p.L <= MAX_L, "attn_cross: L=%d out of range [1,%d]", p.L, MAX_L);
     WM_REQUIRE(p.Tk >= 1 && p.Tk <= CROSS_MAX_KEYS, "attn_cross: Tk=%d out of range", p.Tk);
     WM_REQUIRE(p.nsplit >= 1 && (p.nsplit == 1 || p.ws != nullptr), "attn_cross: split needs a workspace");
     static const int persist_wgs = [] { const char* v = getenv("WM_CROSS_PERSIST_WGS"); return v ? atoi(v) : 0; }();
     const int n_items = p.H * p.B * p.nsplit;
     dim3 grid(persist_wgs > 0 && persist_wgs < n_items ? persist_wgs : n_items);
-    switch (p.L) {
+    if (ev_start && ev_stop && p.L == 1) {
+        // in-situ roofline sample (bench.py): the events take the dispatch's own begin / end timestamps, as a
+        // profiler would -- events recorded around an ordinary launch add ~45 us of marker latency to a 148 us kernel
+        hipExtLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, ev_start, ev_stop, 0, p);
+    } else switch (p.L) {
         case 1: hipLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, p); break;
         case 2: hipLaunchKernelGGL(attn_cross_kernel<2>, grid, dim3(256), 0, stream, p); break;
         case 3: hipLaunchKernelGGL(attn_cross_kernel<3>, grid, dim3(256), 0, stream, p); break;

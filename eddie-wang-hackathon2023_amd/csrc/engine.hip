@@ -413,16 +413,12 @@ struct Profiler {
     std::vector<hipEvent_t> start, stop; size_t used = 0;
 } g_prof;
 
-int prof_begin(int layer, hipStream_t s) {
+// a free sample slot for an eager launch of layer `layer`, or -1; the launch itself stamps the slot's events
+int prof_slot(int layer, hipStream_t s) {
     if (!g_prof.enabled || layer % g_prof.layer_stride != 0 || g_prof.used >= g_prof.start.size()) return -1;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;   // eager launches only
-    const int slot = (int)g_prof.used++;
-    (void)hipEventRecord(g_prof.start[slot], s);
-    return slot;
-}
-void prof_end(int slot, hipStream_t s) {
-    if (slot >= 0) (void)hipEventRecord(g_prof.stop[slot], s);
+    return (int)g_prof.used++;
 }
 
 struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total; };
@@ -555,9 +551,8 @@ struct GroupStep {
         WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
         p.kv = (const h16*)io->cross[i]; p.kv_bstride = (long)2 * H * d.n_audio_ctx * 64;
         p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
-        const int slot = prof_begin(i, s);
-        if (launch_attn_cross(p, s)) return 2;
-        prof_end(slot, s);
+        const int slot = (L == 1) ? prof_slot(i, s) : -1;
+        if (launch_attn_cross(p, s, slot >= 0 ? g_prof.start[slot] : nullptr, slot >= 0 ? g_prof.stop[slot] : nullptr)) return 2;
         return 0;
     }
 

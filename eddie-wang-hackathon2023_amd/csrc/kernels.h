@@ -107,7 +107,7 @@ struct AttnCrossParams {
     int nsplit;                              // key-range splits per (b,h)  (1 = single pass)
     float* ws;                               // [B*H*nsplit][L][66] partial (m, l, o[64]) when nsplit > 1
 };
-int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream);
+int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---------------------------------------------------------------- greedy.hip
 struct GreedyParams {

@@ -234,6 +234,8 @@ class WhisperDecoding:
         self._state = {}                  # per-batch-size device buffers of the fast path
         self.poll_every = 8
         self.micro_batches = 2            # stream-level overlap of independent utterance groups
+        self.lang_id_sequential = False   # bench.py: run the language pass group by group (0.2 % of a step) so that its
+                                          # HIP-event kernel timings are not inflated by the other group's HBM share
         # experimental schedule (off by default): cross-attention on its own CU set
         # (wm_decoder_step_multi).  Steady state 12.9 ms/step vs 13.9 for the captured graphs at B = 256, but the
         # cross-queue event hand-offs cost 12 us each and only resolve quickly while the host is busy issuing.
@@ -434,6 +436,8 @@ class WhisperDecoding:
             cap = cfg['num_text_ctx']
             for g, (lo, hi) in enumerate(bounds):
                 streams[g].wait_stream(main)
+                if self.lang_id_sequential and g > 0:
+                    streams[g].wait_stream(streams[g - 1])     # one group at a time: kernels are timed un-shared (bench.py)
                 self.decoder_session.decoder_step(st['sot'][lo:hi], self.positional_embedding[0:1],
                                                   [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
                                                   st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g)
