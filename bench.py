@@ -143,6 +143,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; before anything initialises the GPU
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
