@@ -88,6 +88,9 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
 
     const int nk = p.K / BK;
     issue(0, 0);
+    // the second-dispatched half of the workgroup loses every issue arbitration against its SIMD partner; a static
+    // priority for it evens the two out (+3-4 % on the K loop, scripts/lab/gemm_lab.hip)
+    if (wid >= 4) __builtin_amdgcn_s_setprio(1);
 
     const int swz = (lane & 15) >> 1, g = lane >> 4;
     const int a_off = (wr * 64 + (lane & 15)) * 128;

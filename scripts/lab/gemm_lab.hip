@@ -62,6 +62,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k(const h16* A, const h16* W, h1
     const int swz = (lane & 15) >> 1, g = lane >> 4;
     const int a_off = (wr * (BM / WM) + (lane & 15)) * 128;
     const int b_off = A_STAGE + (wc * (BN / WN) + (lane & 15)) * 128;
+    if ((FLAGS & 16) && wid >= 4) __builtin_amdgcn_s_setprio(1);
     for (int kt = 0; kt < nk; ++kt) {
         if (!(FLAGS & 1)) {
             // tiles kt+1 .. kt+STAGES-2 may stay in flight
@@ -74,6 +75,25 @@ __global__ __launch_bounds__(WM * WN * 64) void k(const h16* A, const h16* W, h1
         asm volatile("" ::: "memory");
         if (!(FLAGS & 1) && kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
         const unsigned char* st = smem + ((FLAGS & 1) ? 0 : (kt % STAGES)) * STAGE;
+        if (FLAGS & 8) {
+            // fragments of both K-halves up front: the second half's LDS reads fly under the first half's MFMAs
+            half8v af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int pos = ((4 * s + g) ^ swz) * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[s][i] = *(const half8v*)(st + a_off + i * 16 * 128 + pos);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[s][j] = *(const half8v*)(st + b_off + j * 16 * 128 + pos);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int pos = ((4 * s + g) ^ swz) * 16;
@@ -96,6 +116,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k(const h16* A, const h16* W, h1
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
                     }
             }
+        }
         }
     }
     if (EPI) {   // D = W.A^T blocks: lane holds row m = lane&15 (per i), 4 consecutive n = 4g + r (per j)
@@ -165,14 +186,13 @@ int main() {
     h16 *bias, *R;
     CK(hipMalloc(&bias, 5120 * 2)); CK(hipMemset(bias, 0, 5120 * 2));
     CK(hipMalloc(&R, (size_t)M * 5120 * 2)); CK(hipMemset(R, 0, (size_t)M * 5120 * 2));
-    struct S { int N, K; } shapes[] = {{1280, 640}, {1280, 1280}, {1280, 2560}, {1280, 5120}, {3840, 1280}, {5120, 1280}};
+    struct S { int N, K; } shapes[] = {{1280, 5120}, {3840, 1280}};
     for (auto sh : shapes) {
         const int N = sh.N, K = sh.K;
         run<256, 256, 4, 2, 2, 0, 0>("256x256 2st minimal-epi", A, W, C, M, N, K);
-        run<256, 256, 4, 2, 2, 2, 0>("256x256 2st minimal-epi NO MFMA", A, W, C, M, N, K);
-        run<256, 256, 4, 2, 2, 1, 0>("256x256 2st minimal-epi NO loads", A, W, C, M, N, K);
-        run<256, 256, 4, 2, 2, 0, 1>("256x256 2st swapped epi bias", A, W, C, M, N, K, bias);
-        run<256, 256, 4, 2, 2, 0, 1>("256x256 2st swapped epi bias+res", A, W, C, M, N, K, bias, R);
+        run<256, 256, 4, 2, 2, 8, 0>("256x256 2st frag prefetch", A, W, C, M, N, K);
+        run<256, 256, 4, 2, 2, 16, 0>("256x256 2st setprio waves4-7", A, W, C, M, N, K);
+        run<256, 256, 4, 2, 2, 24, 0>("256x256 2st prefetch+setprio", A, W, C, M, N, K);
     }
     return 0;
 }
