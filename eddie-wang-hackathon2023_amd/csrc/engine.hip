@@ -471,9 +471,15 @@ int skinny_all(const Lin& l, const h16* A, int lda, int M, float* part, int* ksp
 }
 }  // namespace
 
+namespace { constexpr int DEC_CHUNK = 4; }      // query tokens per pass of the decoder kernels (attn_decode.hip: MAX_L)
+
+// n_new <= 4: one pass.  Longer token blocks (prompts / prefixes, W/decoding.py:485-513) are run as 4-token
+// passes over the growing cache; their logits pass through a [batch, 4, n_vocab] staging block at the end of the
+// workspace and are copied into the caller's [batch, n_new, n_vocab] tensor.
 size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new) {
     if (!e || e->kind != WM_ENGINE_DECODER || batch < 1 || n_new < 1) return 0;
-    return carve_decoder(e, batch, n_new, nullptr).total;
+    if (n_new <= DEC_CHUNK) return carve_decoder(e, batch, n_new, nullptr).total;
+    return carve_decoder(e, batch, DEC_CHUNK, nullptr).total + align_up((size_t)batch * DEC_CHUNK * e->dims.n_vocab * sizeof(h16));
 }
 
 namespace {
@@ -601,6 +607,31 @@ struct EventPool {
 int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream_) {
     WM_REQUIRE(e && e->kind == WM_ENGINE_DECODER, "wm_decoder_step: not a decoder engine");
     hipStream_t s = (hipStream_t)stream_;
+    if (io && io->n_new > DEC_CHUNK) {              // a long token block: 4-token passes over the growing cache
+        WM_REQUIRE(!io->n_past_dev, "wm_decoder_step: a device step counter needs n_new == 1");
+        WM_REQUIRE(io->tokens && io->positional_embedding && io->logits && io->workspace && io->present, "wm_decoder_step: null argument");
+        const int L = io->n_new, B = io->batch, C = e->dims.n_text_state, V = e->dims.n_vocab;
+        WM_REQUIRE(B >= 1 && io->n_past >= 0 && io->n_past + L <= e->dims.n_text_ctx, "wm_decoder_step: n_past+n_new=%d exceeds n_text_ctx=%d",
+                   io->n_past + L, e->dims.n_text_ctx);
+        const size_t base = carve_decoder(e, B, DEC_CHUNK, nullptr).total;
+        const size_t need = base + align_up((size_t)B * DEC_CHUNK * V * sizeof(h16));
+        WM_REQUIRE(io->workspace_bytes >= need, "decoder workspace too small: %zu < %zu", io->workspace_bytes, need);
+        h16* stage = (h16*)((unsigned char*)io->workspace + base);
+        for (int off = 0; off < L; off += DEC_CHUNK) {
+            const int l = (L - off) < DEC_CHUNK ? (L - off) : DEC_CHUNK;
+            wm_decoder_io sub = *io;
+            sub.n_new = l; sub.n_past = io->n_past + off;
+            sub.tokens = io->tokens + off; sub.tokens_ld = io->tokens_ld > 0 ? io->tokens_ld : L;
+            sub.positional_embedding = (const h16*)io->positional_embedding + (size_t)off * C;
+            sub.logits = stage; sub.workspace_bytes = base;
+            if (off > 0) { sub.past = (const void* const*)io->present; sub.past_capacity = io->present_capacity; }   // the cache so far lives in `present`
+            if (int rc = wm_decoder_step(e, &sub, stream_)) return rc;
+            // [B, l, V] -> rows off .. off+l of the caller's [B, L, V]
+            WM_CHECK_HIP(hipMemcpy2DAsync((h16*)io->logits + (size_t)off * V, (size_t)L * V * sizeof(h16), stage, (size_t)l * V * sizeof(h16),
+                                          (size_t)l * V * sizeof(h16), (size_t)B, hipMemcpyDeviceToDevice, s));
+        }
+        return 0;
+    }
     GroupStep g;
     if (g.init(e, io)) return 1;
     if (g.begin(s)) return 2;

@@ -74,7 +74,8 @@ int wm_cross_kv(const wm_engine* e, const void* xa, int batch, void* const* out_
 /* ---- decoder engine: W/decoding.py:543-659 -> WhisperDecoder.forward (model.py:241-299) ---------
  * One call = L new tokens for each of `batch` utterances on top of T cached tokens.               */
 typedef struct wm_decoder_io {
-    int32_t batch, n_new /* L: 1 for a decode step, len(sot_sequence) for the prefill */, n_past /* T */;
+    int32_t batch, n_new /* L: 1 for a decode step, len(sot_sequence) for the prefill; blocks longer than 4
+                            (prompts, prefixes) run as 4-token passes over the growing cache */, n_past /* T */;
     const int32_t* tokens;            /* int32 [batch, L]                               "x" */
     int32_t tokens_ld;                /* elements between utterances in `tokens` (0 = L); lets a
                                          step read column cur-1 of a [batch, capacity] buffer   */

@@ -158,6 +158,43 @@ def test_engine_matches_oracle_all_configs(fx, tmpdir_module, weight_only, int8_
         assert diff.max() <= 1 and (diff > 0).float().mean() < 0.01
 
 
+@pytest.mark.parametrize("weight_only,int8_kv,n_prompt", [(False, False, 11), (True, True, 6), (False, False, 5)])
+def test_long_prompt_block_matches_oracle(fx, tmpdir_module, weight_only, int8_kv, n_prompt):
+    """Prompts / prefixes make the first decoder call longer than the 3-4 token start sequence (W/decoding.py:485-513):
+    the engine runs such a block as 4-token passes over the growing cache; logits of every position against the
+    oracle's single pass, then decoding continues on that cache."""
+    dims = Dims(**{k: int(v) for k, v in zip(fx["dims_keys"], fx["dims"])})
+    seed = int(fx["seed"])
+    sd = synthetic_state_dict(dims, seed)
+    mel = synthetic_mel(2, 2 * dims.n_audio_ctx, dims.n_mels, int(fx["mel_seed"]))
+    scales = None
+    if int8_kv:
+        scales = OracleModel(dims, sd, OracleConfig(act="float16", weight_only=weight_only)).calibrate_kv_scales(mel, 6)
+    oracle = OracleModel(dims, sd, OracleConfig(act="float16", weight_only=weight_only, int8_kv=int8_kv, kv_scales=scales))
+    rng = np.random.default_rng(n_prompt)
+    prompt = [int(t) for t in rng.integers(0, dims.n_vocab, n_prompt)]
+    # int8 KV: the oracle (like the reference, attention.py:281-348) attends to the whole current block in full
+    # precision; a block cut into 4-token passes sees the earlier passes through the int8 cache, exactly as every
+    # later decode step sees them -- one more cache LSB (kv_scale ~ 0.06 here) on the block's own logits
+    tol = 2 * LOGIT_TOL_INT8_KV if int8_kv else LOGIT_TOL
+    ref = greedy_reference_run(oracle, mel, prompt, 4)
+    eng = build_engine(tmpdir_module, "micro", seed, weight_only, int8_kv, scales)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    xa = enc.get_audio_features(mel.cuda())
+    cross = dec.xa2cross_key_value(xa)
+    block = torch.tensor([prompt] * 2).cuda()
+    logits, kv = dec.decode(block, cross)
+    assert tuple(logits.shape) == (2, n_prompt, dims.n_vocab)
+    d0 = np.abs(logits.float().cpu().numpy() - ref["logits"][0].numpy())
+    print("prompt block max |dlogit| per position:", d0.max(axis=(0, 2)).round(4))
+    assert d0.max() < tol
+    assert d0[:, :4].max() < (LOGIT_TOL_INT8_KV if int8_kv else LOGIT_TOL)        # the first pass is exactly the reference's single call
+    for s in range(3):
+        logits, kv = dec.decode(ref["ids"][:, s:s + 1].cuda(), cross, kv)
+        assert np.abs(logits[:, 0].float().cpu().numpy() - ref["logits"][s + 1][:, 0].numpy()).max() < tol
+    assert kv[0].shape[3] == n_prompt + 3
+
+
 def _oracle_main_loop(oracle, dec, mel, sample_len, ignore_eot):
     """The oracle's restated decoding rules around the oracle model."""
     tk = dec.tokenizer
