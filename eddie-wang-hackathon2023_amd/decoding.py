@@ -205,6 +205,13 @@ class WhisperDecoding:
 
         self.n_group = self.options.beam_size or self.options.best_of or 1
         self.sample_len: int = self.options.sample_len or self.decoder_config['num_text_ctx'] // 2
+        if self.options.prompt or self.options.prefix:
+            # the reference carries _get_initial_tokens (W/decoding.py:485-513) but never calls it (its options are the
+            # defaults); with caller-supplied options the start sequence is <|startofprev|> prompt <|sot|> .. prefix
+            self.initial_tokens = self._get_initial_tokens()
+            self.initial_token_length = len(self.initial_tokens)
+            self.tokens = torch.tensor([self.initial_tokens]).repeat(self.decoder_config['num_audio'], 1)
+            self.sot_index = self.initial_tokens.index(self.tokenizer.sot)
         self.sample_begin: int = len(self.initial_tokens)
         self.use_int8_kv_cache = self.decoder_config['use_int8_kv_cache']
 
@@ -496,6 +503,8 @@ class WhisperDecoding:
         sum_logprobs: Tensor = torch.zeros(n_batch, device=audio_features.device)
         no_speech_probs = [np.nan] * n_batch
         past_key_value = None
+        if self.n_group > 1:        # best_of / beam candidates share their utterance's audio (upstream Whisper repeats it too)
+            audio_features = audio_features.repeat_interleave(self.n_group, dim=0)
         cross = self.xa2cross_key_value(audio_features)
         for i in range(self.sample_len):
             feed = tokens if tokens.shape[-1] <= self.initial_token_length else tokens[:, -1:]
@@ -796,7 +805,8 @@ class WhisperDecoding:
 
     def post_process(self, tokens, sum_logprobs, no_speech_probs, audio_features, languages):
         """Slice, rank, detokenise (W/decoding.py:827-878); n_audio comes from the batch, not the config."""
-        audio_features = audio_features[:: self.n_group]
+        if audio_features.shape[0] == len(no_speech_probs):          # already one row per candidate (the reference's convention)
+            audio_features = audio_features[:: self.n_group]
         no_speech_probs = no_speech_probs[:: self.n_group]
         n_audio = audio_features.shape[0]
         assert n_audio == len(no_speech_probs)

@@ -197,6 +197,12 @@ class Session(object):
         if n_new is not None:          # device step counter: `tokens` is the whole [B, capacity] buffer
             l = n_new
         assert tokens.dtype == torch.int32 and tokens.stride(1) == 1
+        for name, group in (("cross", cross), ("present", present), ("past", past or ())):
+            for t in group:
+                if t.shape[0] != b:     # raw pointers cross the C ABI: a short buffer would be read out of bounds
+                    raise native.WmError(f"decoder step: {name} K/V holds {t.shape[0]} utterances, tokens hold {b}")
+        if logits.shape[0] != b:
+            raise native.WmError(f"decoder step: logits hold {logits.shape[0]} utterances, tokens hold {b}")
         ws = self._workspace(("dec", b, l, slot), lib.wm_decoder_workspace_bytes(self._engine.handle, b, l))
         io = WmDecoderIO()
         io.batch, io.n_new, io.n_past = b, l, n_past

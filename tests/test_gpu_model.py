@@ -27,6 +27,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import build as B  # noqa: E402
+import native
 import synthetic  # noqa: E402
 from decoding import WhisperDecoding  # noqa: E402
 from encoding import WhisperEncoding  # noqa: E402
@@ -323,6 +324,44 @@ def test_cu_partitioned_schedule_gives_identical_tokens(tmpdir_module, n_groups,
     n = min(tr.shape[1], t2.shape[1])
     assert torch.equal(tr[:, :n].cpu(), t2[:, :n].cpu())
     assert len({tuple(r) for r in t1.cpu().tolist()}) > 1
+
+
+def test_prompt_prefix_and_sampling_options(tmpdir_module):
+    """Decode-loop features the reference carries (W/decoding.py:485-513 prompt / prefix, :274-300 temperature, best_of):
+    a prompted start sequence longer than four tokens through the fused loop == the literal reference loop, and the
+    sampling path (host GreedyDecoder with temperature, n_group = best_of) runs and ranks."""
+    from decoding import DecodingOptions
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
+    enc = WhisperEncoding(eng)
+    mel = synthetic_mel(16, 2 * dims.n_audio_ctx, dims.n_mels, 77).cuda()
+    xa = enc.get_audio_features(mel)
+    opts = DecodingOptions(prompt=[1200, 1201, 1202, 1203, 1204], prefix=[900, 901], sample_len=8)
+    dec = WhisperDecoding(eng, options=opts)
+    tk = dec.tokenizer
+    assert dec.initial_tokens[0] == tk.sot_prev and dec.initial_tokens[1:6] == (1200, 1201, 1202, 1203, 1204)
+    assert dec.initial_tokens[-2:] == (900, 901) and dec.sot_index == 6 and dec.sample_begin == len(dec.initial_tokens) == 11
+    dec.detect_language(xa)
+    fast = dec.main_loop(xa)
+    ref = dec.main_loop_reference(xa)
+    n = min(fast[0].shape[1], ref[0].shape[1])
+    assert n > dec.sample_begin and torch.equal(fast[0][:, :n].cpu(), ref[0][:, :n].cpu())
+    assert torch.equal(fast[0][:, :11].cpu(), dec.tokens[:, :11].cpu().long())
+    assert np.allclose(fast[2], ref[2], atol=1e-3)                       # no-speech probability read at the <|sot|> position
+    res = dec.post_process(*fast, xa, ["en"] * 16)
+    assert len(res) == 16 and all(len(r.tokens) <= 8 for r in res)
+    # sampling: temperature > 0 with best_of = 3 candidates per utterance
+    torch.manual_seed(0)
+    samp = WhisperDecoding(eng, options=DecodingOptions(temperature=0.7, best_of=3, sample_len=6))
+    xa4 = xa[:4].contiguous()
+    samp.detect_language(xa4)
+    toks, lps, nsp = samp.main_loop(xa4)                   # 3 candidates per utterance
+    assert toks.shape[0] == 12 and torch.isfinite(lps).all()
+    out = samp.post_process(toks, lps, nsp, xa4, ["en"] * 4)
+    assert len(out) == 4 and all(np.isfinite(r.avg_logprob) for r in out)
+    with pytest.raises(AssertionError, match="Engine execution failed"):   # mismatched batches are refused (Session.run -> False, as
+        samp.decode(                                                       # the reference's does), not read out of bounds
+            torch.zeros((5, 1), dtype=torch.int32, device="cuda"), samp.xa2cross_key_value(xa4))
 
 
 def test_detect_language_fast_equals_reference(tmpdir_module):
