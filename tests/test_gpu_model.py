@@ -46,14 +46,16 @@ def _write_kv_scales(qdir, scales):
             os.path.join(qdir, f"model.decoder.blocks.{i}.attn.query_key_value.scale_y_quant_orig.bin"))
 
 
-def build_engine(tmp, model_name, seed, weight_only=False, int8_kv=False, kv_scales=None):
-    out = os.path.join(tmp, f"eng_{model_name}_{weight_only if isinstance(weight_only, str) else int(weight_only)}{int(int8_kv)}")
+def build_engine(tmp, model_name, seed, weight_only=False, int8_kv=False, kv_scales=None, gelu="erf"):
+    out = os.path.join(tmp, f"eng_{model_name}_{weight_only if isinstance(weight_only, str) else int(weight_only)}{int(int8_kv)}_{gelu}")
     argv = ["--output_dir", out, "--use_gpt_attention_plugin", "--use_gemm_plugin", "--use_layernorm_plugin",
             "--log_level", "error"]
     if weight_only:
         argv.append("--use_weight_only")
     if weight_only == "int4":
         argv += ["--weight_only_precision", "int4"]
+    if gelu != "erf":
+        argv += ["--gelu", gelu]
     if int8_kv:
         qdir = os.path.join(tmp, f"quantize_{model_name}", "1-gpu")
         _write_kv_scales(qdir, kv_scales)
@@ -157,6 +159,28 @@ def test_engine_matches_oracle_all_configs(fx, tmpdir_module, weight_only, int8_
         # rounding boundary; allow at most 1 LSB on < 1 % of the entries
         diff = (kv[0].cpu().int() - ref["self_kv"][0].int()).abs()
         assert diff.max() <= 1 and (diff > 0).float().mean() < 0.01
+
+
+def test_tanh_gelu_engine_matches_oracle(fx, tmpdir_module):
+    """`build.py --gelu tanh`: the TensorRT path's tanh GELU (functional.py:2044-2056) instead of the PyTorch
+    path's erf GELU, encoder (conv + MLP epilogues) and decoder (row kernel) alike, against the oracle in that mode."""
+    dims = Dims(**{k: int(v) for k, v in zip(fx["dims_keys"], fx["dims"])})
+    seed = int(fx["seed"])
+    sd = synthetic_state_dict(dims, seed)
+    mel = synthetic_mel(2, 2 * dims.n_audio_ctx, dims.n_mels, int(fx["mel_seed"]))
+    ref_erf = greedy_reference_run(OracleModel(dims, sd, OracleConfig(act="float16")), mel, fx["prompt"].tolist(), 3)
+    ref = greedy_reference_run(OracleModel(dims, sd, OracleConfig(act="float16", gelu="tanh")), mel, fx["prompt"].tolist(), 3)
+    assert (ref["xa"] - ref_erf["xa"]).abs().max() > 1e-3              # the two activations are distinguishable here
+    eng = build_engine(tmpdir_module, "micro", seed, gelu="tanh")
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    xa = enc.get_audio_features(mel.cuda())
+    assert np.abs(xa.float().cpu().numpy() - ref["xa"].numpy()).max() < 2e-2
+    cross = dec.xa2cross_key_value(xa)
+    logits, kv = dec.decode(torch.tensor([fx["prompt"].tolist()] * 2).cuda(), cross)
+    assert np.abs(logits.float().cpu().numpy() - ref["logits"][0].numpy()).max() < LOGIT_TOL
+    for s_ in range(2):
+        logits, kv = dec.decode(ref["ids"][:, s_:s_ + 1].cuda(), cross, kv)
+        assert np.abs(logits[:, 0].float().cpu().numpy() - ref["logits"][s_ + 1][:, 0].numpy()).max() < LOGIT_TOL
 
 
 @pytest.mark.parametrize("weight_only,int8_kv,n_prompt", [(False, False, 11), (True, True, 6), (False, False, 5)])
