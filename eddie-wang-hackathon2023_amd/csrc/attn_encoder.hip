@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_old = m_run[qb];
             const float m_new = fmaxf(m_old, r16(mx));
-            const float mL = m_new * LOG2E;
-            const float alpha = __builtin_amdgcn_exp2f(m_old * LOG2E - mL);       // exp(m_old - m_new); 0 on the first tile
+            // explicit roundings (no fp-contract freedom): both template instantiations must give the same bits,
+            // the result of a clip must not depend on how many clips share the launch
+            const float mL = __fmul_rn(m_new, LOG2E);
+            const float alpha = __builtin_amdgcn_exp2f(__fsub_rn(__fmul_rn(m_old, LOG2E), mL));   // exp(m_old - m_new); 0 on the first tile
             m_run[qb] = m_new;
             float ps = 0.f;
             const half2v one2 = {(h16)1.0f, (h16)1.0f};
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
                     const half2v s2 = __builtin_convertvector(float2v{sacc[kb][qb][r], sacc[kb][qb][r + 1]}, half2v);
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf((float)s2[0], LOG2E, -mL));
-                    const float p1 = __builtin_amdgcn_exp2f(fmaf((float)s2[1], LOG2E, -mL));
+                    const float p0 = __builtin_amdgcn_exp2f(__fmaf_rn((float)s2[0], LOG2E, -mL));
+                    const float p1 = __builtin_amdgcn_exp2f(__fmaf_rn((float)s2[1], LOG2E, -mL));
                     const half2v p2 = __builtin_convertvector(float2v{p0, p1}, half2v);
                     ps = __builtin_amdgcn_fdot2(p2, one2, ps, false);
                     pf[kb >> 1][qb][(kb & 1) * 4 + r] = p2[0];
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
                 }
             ps += __shfl_xor(ps, 16);
             ps += __shfl_xor(ps, 32);
-            l_run[qb] = l_run[qb] * alpha + ps;
+            l_run[qb] = __fmaf_rn(l_run[qb], alpha, ps);
             if (__builtin_amdgcn_ballot_w64(m_new != m_old)) {      // wave-uniform: skip the accumulator round trip while
 #pragma unroll
                 for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;  // no query's maximum moved (alpha == 1 exactly)
@@ -203,7 +205,14 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
         for (int db = 0; db < 4; ++db) {
             half4v w;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = (h16)(o[db][qb][r] * inv);
+            for (int r = 0; r < 4; ++r) {
+                // fp32 product, THEN fp16.  Left alone, the compiler turns some of these (which ones differs between the
+                // two template instantiations) into v_fma_mixlo_f16, one rounding instead of two: the output of a clip
+                // would depend on how many clips share the launch.  The empty asm pins the fp32 value.
+                float t = o[db][qb][r] * inv;
+                asm volatile("" : "+v"(t));
+                w[r] = (h16)t;
+            }
             *(half4v*)(dst + db * 16 + g * 4) = w;
         }
     }
@@ -212,10 +221,11 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
 int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream) {
     WM_REQUIRE(p.T >= 1 && p.H >= 1 && p.B >= 1, "attn_encoder: bad shape");
     WM_REQUIRE(p.ld % 8 == 0 && p.ldo % 4 == 0, "attn_encoder: leading dimensions must keep 16-byte alignment");
-    // QB = 2: 128 queries per workgroup.  (QB = 4 halves LDS traffic per MFMA; chosen when the
-    // grid still fills the chip.)
-    const long wgs4 = (long)((p.T + 255) / 256) * p.H * p.B;
-    if (wgs4 >= 1024) {
+    // QB = 4 (256 queries per workgroup, half the LDS traffic per MFMA) whenever the sequence fills such a tile; it is
+    // the faster variant at every batch size for T = 1500 (B = 1: 60 vs 67 us, B = 128: 21 vs 36 us per clip-layer).
+    // The choice depends on T only, never on the batch: the two instantiations agree to one fp16 ulp, not bit for bit,
+    // and the result of a clip must not depend on how many clips share the launch (tests: batch independence).
+    if (p.T > 128) {
         dim3 grid((p.T + 255) / 256, p.H, p.B);
         hipLaunchKernelGGL(attn_encoder_kernel<4>, grid, dim3(256), 0, stream, p);
     } else {

@@ -5,7 +5,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "eddie-wang-hackathon2023_amd")]
 import torch, native
 lib = native.load_library()
 H, T = 20, 1500
-for B in (8, 32, 128):
+for B in (1, 2, 4, 8, 32, 128):
     qkv = (torch.randn(B * T, 3 * H * 64, device="cuda") * 0.5).half()
     out = torch.empty(B * T, H * 64, device="cuda", dtype=torch.float16)
     s = torch.cuda.current_stream().cuda_stream

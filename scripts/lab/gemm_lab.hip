@@ -63,6 +63,48 @@ __global__ __launch_bounds__(WM * WN * 64) void k(const h16* A, const h16* W, h1
     const int a_off = (wr * (BM / WM) + (lane & 15)) * 128;
     const int b_off = A_STAGE + (wc * (BN / WN) + (lane & 15)) * 128;
     if ((FLAGS & 16) && wid >= 4) __builtin_amdgcn_s_setprio(1);
+    if ((FLAGS & 32) && wid >= 4) {
+        // staggered half of the workgroup: runs half a K-tile behind its SIMD partners, so that one wave's LDS
+        // reads fall under the other's MFMAs.  The second half's fragments of K-tile kt are read before the
+        // next barrier and multiplied after it.
+        half8v af1[TM], bf1[TN];
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) % STAGES);
+            if (kt > 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
+            }
+            const unsigned char* st = smem + (kt % STAGES) * STAGE;
+            {
+                const int pos = ((4 * 0 + g) ^ swz) * 16;
+                half8v af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const half8v*)(st + a_off + i * 16 * 128 + pos);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *(const half8v*)(st + b_off + j * 16 * 128 + pos);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            {
+                const int pos = ((4 * 1 + g) ^ swz) * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af1[i] = *(const half8v*)(st + a_off + i * 16 * 128 + pos);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf1[j] = *(const half8v*)(st + b_off + j * 16 * 128 + pos);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         if (!(FLAGS & 1)) {
             // tiles kt+1 .. kt+STAGES-2 may stay in flight
@@ -186,13 +228,12 @@ int main() {
     h16 *bias, *R;
     CK(hipMalloc(&bias, 5120 * 2)); CK(hipMemset(bias, 0, 5120 * 2));
     CK(hipMalloc(&R, (size_t)M * 5120 * 2)); CK(hipMemset(R, 0, (size_t)M * 5120 * 2));
-    struct S { int N, K; } shapes[] = {{1280, 5120}, {3840, 1280}};
+    struct S { int N, K; } shapes[] = {{1280, 5120}, {3840, 1280}, {1280, 5120}};
     for (auto sh : shapes) {
         const int N = sh.N, K = sh.K;
-        run<256, 256, 4, 2, 2, 0, 0>("256x256 2st minimal-epi", A, W, C, M, N, K);
-        run<256, 256, 4, 2, 2, 8, 0>("256x256 2st frag prefetch", A, W, C, M, N, K);
         run<256, 256, 4, 2, 2, 16, 0>("256x256 2st setprio waves4-7", A, W, C, M, N, K);
-        run<256, 256, 4, 2, 2, 24, 0>("256x256 2st prefetch+setprio", A, W, C, M, N, K);
+        run<256, 256, 4, 2, 2, 32, 0>("256x256 2st stagger waves4-7", A, W, C, M, N, K);
+        run<256, 256, 4, 2, 2, 48, 0>("256x256 2st stagger+setprio", A, W, C, M, N, K);
     }
     return 0;
 }

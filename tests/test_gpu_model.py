@@ -482,6 +482,44 @@ def test_large_v2_width_engine_matches_oracle(tmpdir_module):
     assert n_ok == n_safe and n_safe > 0
 
 
+def test_full_size_large_v2_properties(tmpdir_module):
+    """BASELINE.json configs[3] at FULL size (32 + 32 layers, int8 weight-only + int8 KV; the CPU oracle would need
+    minutes per token there), through properties that do not need it: the fused graph-replayed loop == the literal
+    reference loop token for token, utterances are independent (a batch row == the same clip alone, bit for bit),
+    the cross K/V are the head-split projection of the encoder output, and nothing overflows fp16."""
+    import bench
+    import argparse
+    from pathlib import Path as _P
+    eng = _P(tmpdir_module) / "large-v2-int8-full"
+    if not (eng / "decoder_config.json").exists():
+        bench.build_engines(argparse.Namespace(model="large-v2", config="int8", seed=5), eng)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    d = synthetic.DIMS["large-v2"]
+    assert dec.decoder_config["num_layers"] == 32 and dec.use_int8_kv_cache
+    mel = synthetic_mel(20, 3000, 80, 8).cuda()
+    xa = enc.get_audio_features(mel)
+    assert tuple(xa.shape) == (20, 1500, 1280) and bool(torch.isfinite(xa.float()).all())
+    assert bool(torch.equal(enc.get_audio_features(mel[7:8])[0], xa[7]))                 # encoder: batch independent
+    dec.sample_len = 10
+    dec.detect_language(xa)
+    t_fast, lp_fast, nsp_fast = dec.main_loop(xa)                                         # 2 groups x 10, graph replay
+    assert len({tuple(r) for r in t_fast.cpu().tolist()}) > 1
+    ref_dec = WhisperDecoding(eng)
+    ref_dec.sample_len = 10
+    ref_dec.tokens = dec.tokens[:3].clone()                                               # the languages detected above
+    t_ref, lp_ref, nsp_ref = ref_dec.main_loop_reference(xa[:3].contiguous())            # by-name protocol, concat KV
+    n = min(t_fast.shape[1], t_ref.shape[1])
+    assert torch.equal(t_fast[:3, :n].cpu(), t_ref[:, :n].cpu())
+    assert torch.allclose(lp_fast[:3].cpu(), lp_ref.cpu(), atol=2e-2) and np.allclose(nsp_fast[:3], nsp_ref, atol=1e-3)
+    solo = WhisperDecoding(eng)
+    solo.sample_len = 10
+    solo.tokens = dec.tokens[11:12].clone()
+    t_solo, _, _ = solo.main_loop(xa[11:12].contiguous())
+    assert torch.equal(t_solo[0].cpu(), t_fast[11, :t_solo.shape[1]].cpu())              # decode: batch independent
+    cross = dec.xa2cross_key_value(xa[:2].contiguous())
+    assert len(cross) == 32 and tuple(cross[0].shape) == (2, 2, 20, 1500, 64) and bool(torch.isfinite(cross[31].float()).all())
+
+
 def test_summarize_pipeline_on_flac(tmpdir_module, golden_dir, tmp_path):
     """summarize.py end to end on real audio framing: FLAC decode -> pad_or_trim -> device log-mel -> encoder ->
     language / greedy loop -> text clean-up -> normaliser -> WER, tiny.en-shape engine with random weights
