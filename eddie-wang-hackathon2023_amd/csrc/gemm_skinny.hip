@@ -162,24 +162,23 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
     }
 }
 
-static inline int skinny_waves(int M) { return M > 32 ? 8 : 4; }
-constexpr int SKINNY_MAX_M = 128;   // bigger activation block -> share it wider
+constexpr int SKINNY_MAX_M = 128;   // rows per launch
 
 static inline int skinny_kt(int w8) { return w8 == 4 ? 128 : (w8 ? 64 : 32); }    // w8: 0 fp16, 1 int8, 4 packed int4
 
 int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
+    // The split depends on the weight matrix only, never on the number of rows: the order in which a row's K slices
+    // are summed (by the consumer kernels) must not change with the batch the row is in.
+    (void)M;
     const int kt_total = K / skinny_kt(w8);
-    const int nw = skinny_waves(M);
-    const int nwg_n = (n_blocks + nw - 1) / nw;
-    int s = (3072 / nw + nwg_n - 1) / nwg_n;      // aim for ~3000 waves in flight (12 per CU)                 // aim for ~3 workgroups per CU
+    const int nwg_n = (n_blocks + 7) / 8;
+    int s = (384 + nwg_n - 1) / nwg_n;                 // aim for ~3000 waves in flight (12 per CU)
     const int min_tiles = w8 == 4 ? 1 : (w8 ? 2 : 4);  // at least 128 inputs per slice
     s = min(s, max(1, kt_total / min_tiles));
-    // the fp32 slabs (s * M * N * 4 B) are written and re-read through L2 / Infinity Cache: keep them
-    // under ~16 MB so that they stay on-die; below that, more slices = more bytes in flight, which is
-    // what a latency-bound weight stream needs
-    const long slab = (long)max(M, 1) * n_blocks * 16 * 4;
-    const int cap = (int)max(1L, (16L << 20) / slab);
-    s = min(s, cap);
+    // the fp32 slabs (s * rows * N * 4 B) are written and re-read through L2 / Infinity Cache: keep them under
+    // ~16 MB at the largest row count a launch takes, so that they stay on-die
+    const long slab = (long)SKINNY_MAX_M * n_blocks * 16 * 4;
+    s = min(s, (int)max(1L, (16L << 20) / slab));
     // every slab is re-read by the row kernel (and its latency chain grows with the slab count);
     // measured (scripts/bench_skinny.py): 8 slices are already at the latency floor for every decode shape
     s = min(s, 8);
