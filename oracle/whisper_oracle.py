@@ -316,6 +316,12 @@ class OracleModel:
         if cfg.int8_kv:
             assert cfg.kv_scales is not None and len(cfg.kv_scales) == dims.n_text_layer
 
+    def to(self, device) -> "OracleModel":
+        """Move the parameters (tests run the full-size oracle on the GPU: same torch ops, fp32 matmuls, minutes
+        become seconds).  Inputs must then live on that device too."""
+        self.p = {k: v.to(device) for k, v in self.p.items()}
+        return self
+
     # -- primitives --------------------------------------------------------------------
     def _linear(self, x, wkey, bkey=None):
         y = x @ self.p[wkey].t()
@@ -362,7 +368,7 @@ class OracleModel:
         assert x.shape[1:] == (d.n_audio_ctx, d.n_audio_state), "incorrect audio shape"
         # the table reaches both reference paths rounded to fp16: the checkpoint buffer is fp16
         # (torch path) and W/weight.py:50 assigns the recomputed table to an fp16 Parameter
-        pe = sinusoids(d.n_audio_ctx, d.n_audio_state).half().float()
+        pe = sinusoids(d.n_audio_ctx, d.n_audio_state).half().float().to(x.device)
         x = _r(x + pe, act)
         for i in range(d.n_audio_layer):
             p = f"encoder.blocks.{i}"
@@ -405,8 +411,8 @@ class OracleModel:
         emb = self.p["decoder.token_embedding.weight"]
         x = _r(emb[tokens.long()] + self.p["decoder.positional_embedding"][T:T + L], act)
         # causal mask over [past | new] keys (W/torch_model.py:186-187,209)
-        mask = torch.zeros(L, T + L)
-        mask[:, T:] = torch.full((L, L), float("-inf")).triu_(1)
+        mask = torch.zeros(L, T + L, device=x.device)
+        mask[:, T:] = torch.full((L, L), float("-inf"), device=x.device).triu_(1)
         presents = []
         for i in range(d.n_text_layer):
             p = f"decoder.blocks.{i}"
@@ -489,7 +495,7 @@ def greedy_reference_run(model: OracleModel, mel: torch.Tensor, prompt: List[int
     xa = model.encoder(mel)
     ckv = model.cross_kv(xa)
     B = mel.shape[0]
-    tokens = torch.tensor([prompt] * B, dtype=torch.long)
+    tokens = torch.tensor([prompt] * B, dtype=torch.long, device=mel.device)
     logits_all, ids, margins = [], [], []
     kv = None
     cur = tokens

@@ -482,6 +482,53 @@ def test_large_v2_width_engine_matches_oracle(tmpdir_module):
     assert n_ok == n_safe and n_safe > 0
 
 
+def test_full_size_large_v2_matches_oracle_on_gpu(tmpdir_module):
+    """BASELINE.json configs[3] at FULL size against the oracle itself: the same restatement that is pinned to the
+    reference's golden vectors, with its parameters moved to the GPU (fp32 torch matmuls there, fp16 activation
+    rounding as on the CPU), teacher-forcing the engine with the oracle's ids.  32 + 32 layers, weight-only int8 +
+    int8 KV with the oracle's own calibration; tolerances as for the small models (drift does not grow with depth
+    beyond them: measured below)."""
+    dims_d = synthetic.DIMS["large-v2"]
+    dims = Dims(**dims_d)
+    ck = synthetic.synthetic_checkpoint("large-v2", 9, device="cuda")
+    sd = {k: v for k, v in ck["model_state_dict"].items()}
+    mel = synthetic_mel(2, 3000, 80, 4242).cuda()
+    cal = OracleModel(dims, {k: v.cpu() for k, v in sd.items()}, OracleConfig(act="float16", weight_only=True)).to("cuda")
+    scales = cal.calibrate_kv_scales(mel, 3)
+    del cal
+    oracle = OracleModel(dims, {k: v.cpu() for k, v in sd.items()},
+                         OracleConfig(act="float16", weight_only=True, int8_kv=True, kv_scales=scales)).to("cuda")
+    prompt = [dims.n_vocab - 1607, dims.n_vocab - 1606, dims.n_vocab - 1506]
+    n_steps = 5
+    ref = greedy_reference_run(oracle, mel, prompt, n_steps)
+    out = os.path.join(tmpdir_module, "eng_large-v2_full_oracle")
+    qdir = os.path.join(tmpdir_module, "quantize_large-v2_full", "1-gpu")
+    _write_kv_scales(qdir, scales)
+    args = B.parse_arguments(["--output_dir", out, "--use_gpt_attention_plugin", "--use_gemm_plugin", "--use_layernorm_plugin",
+                              "--log_level", "error", "--use_weight_only", "--int8_kv_cache", "--quantize_dir", qdir])
+    B.build_from_checkpoint(ck, args)
+    del ck, sd
+    torch.cuda.empty_cache()
+    enc, dec = WhisperEncoding(Path(out)), WhisperDecoding(Path(out))
+    xa = enc.get_audio_features(mel)
+    d_xa = float((xa.float() - ref["xa"]).abs().max())
+    cross = dec.xa2cross_key_value(xa)
+    d_ckv = max(float((c.float() - r).abs().max()) for c, r in zip(cross, ref["cross_kv"]))
+    logits, kv = dec.decode(torch.tensor([prompt] * 2).cuda(), cross)
+    worst = float((logits.float() - ref["logits"][0]).abs().max())
+    n_safe = n_ok = 0
+    for s_ in range(n_steps - 1):
+        logits, kv = dec.decode(ref["ids"][:, s_:s_ + 1], cross, kv)
+        worst = max(worst, float((logits[:, 0].float() - ref["logits"][s_ + 1][:, 0]).abs().max()))
+        safe = (ref["margins"][:, s_ + 1] > 2 * LOGIT_TOL_INT8_KV).cpu().numpy()
+        got = logits[:, 0].float().argmax(-1).cpu().numpy()
+        n_safe += int(safe.sum())
+        n_ok += int((got[safe] == ref["ids"][:, s_ + 1].cpu().numpy()[safe]).sum())
+    print(f"full size: max|xa - oracle| = {d_xa:.4f}, max|cross K/V| = {d_ckv:.4f}, max|logits| = {worst:.4f}, ids {n_ok}/{n_safe}")
+    assert d_xa < 5e-2 and d_ckv < 5e-2 and worst < LOGIT_TOL_INT8_KV, (d_xa, d_ckv, worst)
+    assert n_ok == n_safe and n_safe > 0
+
+
 def test_full_size_large_v2_properties(tmpdir_module):
     """BASELINE.json configs[3] at FULL size (32 + 32 layers, int8 weight-only + int8 KV; the CPU oracle would need
     minutes per token there), through properties that do not need it: the fused graph-replayed loop == the literal
