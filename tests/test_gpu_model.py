@@ -388,6 +388,29 @@ def test_prompt_prefix_and_sampling_options(tmpdir_module):
             torch.zeros((5, 1), dtype=torch.int32, device="cuda"), samp.xa2cross_key_value(xa4))
 
 
+def test_decode_to_the_cache_limit(tmpdir_module):
+    """Maximum size edge: decode until the self-attention cache (n_text_ctx = 448 positions) is full.  The fused,
+    graph-replayed loop must stop where the reference loop stops and agree with it token for token all the way
+    (int8 KV cache, key counts from 3 to 447 through the decode self-attention kernel)."""
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3, weight_only=True, int8_kv=True, kv_scales=[0.05] * dims.n_text_layer)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    assert dec.decoder_config["num_text_ctx"] == 448
+    dec.sample_len = 1000                                        # more than fits: the cache limit ends the loop
+    mel = synthetic_mel(16, 2 * dims.n_audio_ctx, dims.n_mels, 13).cuda()
+    xa = enc.get_audio_features(mel)
+    dec.detect_language(xa)
+    t_fast, lp_fast, _ = dec.main_loop(xa, ignore_eot=True)
+    assert t_fast.shape[1] == 449 and bool(torch.isfinite(lp_fast).all())        # 448 cached positions + the last sampled token
+    ref = WhisperDecoding(eng)
+    ref.sample_len = 1000
+    ref.tokens = dec.tokens[:2].clone()
+    ref.decoder.eot = -1                                          # the reference loop has no ignore_eot switch: never "complete"
+    t_ref, lp_ref, _ = ref.main_loop_reference(xa[:2].contiguous())
+    assert t_ref.shape[1] == 449
+    assert torch.equal(t_fast[:2].cpu(), t_ref.cpu())
+
+
 def test_detect_language_fast_equals_reference(tmpdir_module):
     dims = Dims(**synthetic.DIMS["micro-fullvocab"])
     eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
