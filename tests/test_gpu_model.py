@@ -617,3 +617,40 @@ def test_summarize_pipeline_on_flac(tmpdir_module, golden_dir, tmp_path):
     audio = wu.pad_or_trim(wu.load_audio(str(pairs[0][0])))
     dev = wu.log_mel_spectrogram_device(torch.from_numpy(audio).cuda(), dtype=torch.float32).cpu()
     np.testing.assert_allclose(dev.numpy(), wu.log_mel_spectrogram(audio).numpy(), atol=5e-4)
+
+
+def test_empty_and_invalid_calls_fail_cleanly(tmpdir_module):
+    """Empty batches, undersized workspaces and out-of-range lengths come back as errors with a message (the C ABI
+    never aborts and never touches memory for them); the session layer turns them into exceptions / False."""
+    import ctypes as C
+    dims = Dims(**synthetic.DIMS["micro"])
+    eng = build_engine(tmpdir_module, "micro", 7)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    lib = native.load_library()
+    h = enc.session._engine.handle
+    mel = synthetic_mel(2, 2 * dims.n_audio_ctx, dims.n_mels, 5).cuda()
+    out = torch.empty((2, dims.n_audio_ctx, dims.n_audio_state), dtype=torch.float16, device="cuda")
+    ws = torch.empty(lib.wm_encoder_workspace_bytes(h, 2), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.wm_encoder_forward(h, mel.data_ptr(), 0, out.data_ptr(), ws.data_ptr(), ws.numel(), s) != 0      # empty batch
+    assert b"empty batch" in lib.wm_last_error()
+    assert lib.wm_encoder_forward(h, mel.data_ptr(), 2, out.data_ptr(), ws.data_ptr(), 1024, s) != 0            # workspace too small
+    assert b"workspace too small" in lib.wm_last_error()
+    assert lib.wm_encoder_forward(dec.decoder_session._engine.handle, mel.data_ptr(), 2, out.data_ptr(), ws.data_ptr(), ws.numel(), s) != 0
+    assert b"not an encoder engine" in lib.wm_last_error()
+    assert lib.wm_encoder_forward(h, mel.data_ptr(), 2, out.data_ptr(), ws.data_ptr(), ws.numel(), s) == 0       # and the good call still works
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    xa = enc.get_audio_features(mel)
+    cross = dec.xa2cross_key_value(xa)
+    too_long = torch.zeros((2, dims.n_text_ctx + 1), dtype=torch.int64, device="cuda")
+    with pytest.raises(AssertionError, match="Engine execution failed"):                  # n_past + n_new > n_text_ctx
+        dec.decode(too_long, cross)
+    with pytest.raises((native.WmError, RuntimeError, AssertionError)):
+        enc.get_audio_features(mel[0:0])                                                  # empty batch through the wrapper
+    # audio front end: sample counts that are not whole hops, and clips shorter than one FFT frame
+    import whisper_utils as wu
+    with pytest.raises(native.WmError, match="multiple of the hop"):
+        wu.log_mel_spectrogram_device(torch.zeros(1, 16001, device="cuda"))
+    with pytest.raises(native.WmError, match="n_samples"):
+        wu.log_mel_spectrogram_device(torch.zeros(1, 320, device="cuda"))
