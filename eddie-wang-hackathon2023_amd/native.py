@@ -11,7 +11,7 @@ import os
 from typing import Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwhisper_mi355.so")
+LIB_PATH = os.environ.get("WM_LIBRARY_PATH") or os.path.join(_HERE, "libwhisper_mi355.so")
 
 EXPORTS = (
     "wm_version", "wm_last_error", "wm_device_count", "wm_engine_create", "wm_engine_destroy",
