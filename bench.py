@@ -222,8 +222,8 @@ def main():
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4),
                         # HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE x 1024 x 2,
-                        # the gfx950 correction for 16 B/lane streaming reads): 7,686,971 B per utterance-layer
-                        "traffic": group * 7686971, "traffic_source": "profiles/r1_pmc_cross_attn.txt",
+                        # the gfx950 correction for 16 B/lane streaming reads): 7,686,228 B per utterance-layer
+                        "traffic": group * 7686228, "traffic_source": "profiles/r1h_pmc_cross_attn.txt",
                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5),
                         "samples": int(cnt.value), "utterances_per_launch": group,
                         "note": "HIP events around the eager (language-ID pass) launches of the kernel inside the timed "
