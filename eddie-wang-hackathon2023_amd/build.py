@@ -78,6 +78,9 @@ def parse_arguments(args=None):
     parser.add_argument('--int8_kv_cache', default=False, action="store_true",
                         help='By default, we use dtype for KV cache. int8_kv_cache chooses int8 quantization for KV')
     # extensions
+    parser.add_argument('--int8_cross_kv', default=False, action="store_true",
+                        help='BEYOND the reference (which keeps them fp16): store the cross-attention K/V as int8 codes, one scale '
+                             'per layer from --quantize_dir (torch_whisper_convert.py -kv); halves the decode loop\'s HBM traffic')
     parser.add_argument('--synthetic', type=str, default=None, help='build from a seeded random-init checkpoint of this size')
     parser.add_argument('--seed', type=int, default=0)
     parser.add_argument('--gelu', type=str, default='erf', choices=['erf', 'tanh'])
@@ -119,7 +122,7 @@ def _wo(args):
 
 
 def _flags(args, int8_kv=False) -> int:
-    f = 0
+    f = W.FLAG_INT8_CROSS_KV if getattr(args, 'int8_cross_kv', False) else 0
     if args.use_weight_only:
         f |= W.FLAG_WEIGHT_ONLY_INT8
     if int8_kv:
@@ -152,10 +155,10 @@ def build_decoder(model, args):
         name=MODEL_DECODER_NAME, precision=args.dtype, tensor_parallel=1, num_layers=md['n_text_layer'],
         num_heads=md['n_text_head'], num_audio=1, num_audio_ctx=md['n_audio_ctx'], num_text_ctx=md['n_text_ctx'],
         hidden_size=md['n_text_state'], vocab_size=md['n_vocab'], max_batch_size=args.max_batch_size,
-        use_int8_kv_cache=bool(args.int8_kv_cache), int8=bool(args.int8_kv_cache), fp8=False, timing_cache=None,
+        use_int8_kv_cache=bool(args.int8_kv_cache), use_int8_cross_kv=bool(args.int8_cross_kv), int8=bool(args.int8_kv_cache), fp8=False, timing_cache=None,
         opt_level=None, use_refit=False, strongly_typed=False)
     tensors = load_decoder_weight(params, md['n_text_layer'], args.quantize_dir,
-                                  use_weight_only=_wo(args), use_int8_kv_cache=args.int8_kv_cache)
+                                  use_weight_only=_wo(args), use_int8_kv_cache=args.int8_kv_cache, use_int8_cross_kv=args.int8_cross_kv)
     blob = W.serialize_engine_blob(W.ENGINE_DECODER, _flags(args, args.int8_kv_cache), md, tensors)
     save_config(builder_config, _plugin_config(args), os.path.join(args.output_dir, 'decoder_config.json'))
     serialize_engine(blob, os.path.join(args.output_dir, get_engine_name(MODEL_DECODER_NAME, args.dtype, 1, 0)))
@@ -167,7 +170,8 @@ def build_crossattn_kv_linear(model, args):
         name=MODEL_CROSSATTN_NAME, precision='float16', tensor_parallel=1, num_layers=md['n_text_layer'],
         num_heads=md['n_text_head'], int8=False, fp8=False, timing_cache=None, opt_level=None, use_refit=False,
         strongly_typed=False, hidden_size=md['n_text_state'], num_audio_ctx=md['n_audio_ctx'])
-    tensors = load_crossattn_linear_weight(params, md['n_text_layer'], use_weight_only=_wo(args))
+    tensors = load_crossattn_linear_weight(params, md['n_text_layer'], use_weight_only=_wo(args),
+                                           use_int8_cross_kv=args.int8_cross_kv, quantize_dir=args.quantize_dir)
     blob = W.serialize_engine_blob(W.ENGINE_CROSS_KV, _flags(args), md, tensors)
     save_config(builder_config, _plugin_config(args), os.path.join(args.output_dir, 'cross_attn_config.json'))
     serialize_engine(blob, os.path.join(args.output_dir, get_engine_name(MODEL_CROSSATTN_NAME, 'float16', 1, 0)))

@@ -230,14 +230,23 @@ int launch_attn_self(const AttnSelfParams& p, hipStream_t stream) {
 // load instruction (lane -> row lane>>3, 16-byte column lane&7), 4 instructions (4 KiB) in flight per wave.
 constexpr int CROSS_MAX_KEYS = 1536;
 
-template <int L>
+// I8 (opt-in, beyond the reference: SURVEY 8f-4): K/V are int8 codes [B,2,H,Tk,64] with one scale t per layer; a row is
+// 64 B, a lane takes 16 dims (one 16-byte load), a wave-instruction covers 16 rows.  The values are exactly code * t (no
+// fp16 rounding of the dequantised tensor), so the scale factors out of both products: score = r16((q16 . code) * t *
+// d^-0.25) with v_dot2 on exact fp16 codes, out = r16(t * (p . code)) -- one VALU op per element instead of eight.
+template <int L, bool I8 = false>
 __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
+    constexpr int DPL = I8 ? 16 : 8;                     // dims per lane
+    constexpr int LPR = 64 / DPL;                        // lanes per row: 8 (fp16) / 4 (int8)
+    constexpr int RPI = 64 / LPR;                        // rows per wave-instruction: 8 / 16
+    constexpr int ESZ = I8 ? 1 : 2;                      // bytes per stored element
+    constexpr int UNR = 4;     // 8 in flight reads 2 % faster alone, but starves the other group's short kernels (12.3 vs 12.7 k tokens/s)
     __shared__ float s_sc[L][CROSS_MAX_KEYS];
     __shared__ float s_red[L][4][2];
     __shared__ float s_o[4][L][64];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int sub = lane & 7, rowi = lane >> 3;           // 16-byte column, row inside an 8-row group
+    const int sub = lane % LPR, rowi = lane / LPR;        // 16-byte column, row inside a group of RPI rows
     const int per_split = (((p.Tk + p.nsplit - 1) / p.nsplit) + 7) & ~7;
     // a workgroup walks over (head, utterance, key split) items: with fewer workgroups than items the
     // launch is persistent and leaves wave slots on every CU to the other streams' short kernels
@@ -254,68 +263,114 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
         continue;
     }
 
-    const h16* K = p.kv + (size_t)b * p.kv_bstride + ((size_t)(0 * p.H + h) * p.Tk) * 64;
-    const h16* V = p.kv + (size_t)b * p.kv_bstride + ((size_t)(1 * p.H + h) * p.Tk) * 64;
+    const unsigned char* K = (const unsigned char*)p.kv + ((size_t)b * p.kv_bstride + ((size_t)(0 * p.H + h) * p.Tk) * 64) * ESZ;
+    const unsigned char* V = (const unsigned char*)p.kv + ((size_t)b * p.kv_bstride + ((size_t)(1 * p.H + h) * p.Tk) * 64) * ESZ;
 
     const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.B * L * p.ldp;
-    // ---- q: this lane's 8 dims (sub*8 .. +8) for each of the L tokens ---------------------------
-    float qf[L][8];
+    // ---- q: this lane's DPL dims (sub * DPL .. ) for each of the L tokens -----------------------------
+    float qf[L][DPL];
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const int m = b * L + i;
-        const int col0 = h * 64 + sub * 8;
-        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+        const int col0 = h * 64 + sub * DPL;
         const float* row = p.part + (size_t)m * p.ldp + col0;
-        int s = 0;
-        for (; s + 2 <= p.ksplit; s += 2) {            // 4 independent 16-byte loads in flight
-            const float4 a0 = *(const float4*)(row + (size_t)s * sstride), b0 = *(const float4*)(row + (size_t)s * sstride + 4);
-            const float4 a1 = *(const float4*)(row + (size_t)(s + 1) * sstride), b1 = *(const float4*)(row + (size_t)(s + 1) * sstride + 4);
-            qa.x += a0.x + a1.x; qa.y += a0.y + a1.y; qa.z += a0.z + a1.z; qa.w += a0.w + a1.w;
-            qb.x += b0.x + b1.x; qb.y += b0.y + b1.y; qb.z += b0.z + b1.z; qb.w += b0.w + b1.w;
-        }
-        for (; s < p.ksplit; ++s) {
-            const float4 a0 = *(const float4*)(row + (size_t)s * sstride), b0 = *(const float4*)(row + (size_t)s * sstride + 4);
-            qa.x += a0.x; qa.y += a0.y; qa.z += a0.z; qa.w += a0.w;
-            qb.x += b0.x; qb.y += b0.y; qb.z += b0.z; qb.w += b0.w;
-        }
-        const float qs[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float q = r16(qs[e] + (p.bias ? (float)p.bias[col0 + e] : 0.f));
-            qf[i][e] = r16(q * ATTN_SCALE);
+        for (int q4 = 0; q4 < DPL / 4; ++q4) {
+            float4 qa = make_float4(0.f, 0.f, 0.f, 0.f);
+            int s = 0;
+            for (; s + 2 <= p.ksplit; s += 2) {            // independent 16-byte loads in flight
+                const float4 a0 = *(const float4*)(row + (size_t)s * sstride + q4 * 4);
+                const float4 a1 = *(const float4*)(row + (size_t)(s + 1) * sstride + q4 * 4);
+                qa.x += a0.x + a1.x; qa.y += a0.y + a1.y; qa.z += a0.z + a1.z; qa.w += a0.w + a1.w;
+            }
+            for (; s < p.ksplit; ++s) {
+                const float4 a0 = *(const float4*)(row + (size_t)s * sstride + q4 * 4);
+                qa.x += a0.x; qa.y += a0.y; qa.z += a0.z; qa.w += a0.w;
+            }
+            const float qs[4] = {qa.x, qa.y, qa.z, qa.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float q = r16(qs[e] + (p.bias ? (float)p.bias[col0 + q4 * 4 + e] : 0.f));
+                qf[i][q4 * 4 + e] = r16(q * ATTN_SCALE);
+            }
         }
     }
 
+    // int8 mode: q as fp16 pairs for v_dot2 (the values are fp16-representable by construction), scale factored out
+    half2v qh2[L][DPL / 2];
+#pragma unroll
+    for (int i = 0; i < L; ++i)
+#pragma unroll
+        for (int e = 0; e < DPL / 2; ++e) qh2[i][e] = half2v{(h16)qf[i][2 * e], (h16)qf[i][2 * e + 1]};
+    const float k_scale = p.kv_q8_scale * ATTN_SCALE;
+
+    // the lane's DPL values of one K / V row as fp32 (fp16 storage, or the int8 codes themselves)
+    auto unpack = [&](const u32x4& raw, float (&x)[DPL]) {
+        if constexpr (I8) {
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                half2v lo, hi;
+                cvt_s8x4_f16x4(w[c], lo, hi);
+                x[4 * c + 0] = (float)lo[0]; x[4 * c + 1] = (float)lo[1];
+                x[4 * c + 2] = (float)hi[0]; x[4 * c + 3] = (float)hi[1];
+            }
+        } else {
+            const half8v hv = __builtin_bit_cast(half8v, raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (float)hv[e];
+        }
+    };
+
     // ---- pass 1: scores ---------------------------------------------------------------------------
-    // a wave handles 32 rows per iteration (4 loads of 8 rows), the 4 waves stride by 128 rows
+    // a wave handles RPI * UNR rows per iteration (UNR loads in flight), the 4 waves stride by 4 * RPI * UNR rows
     float mx[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) mx[i] = -INFINITY;
-    // a wave handles 8 * UNR rows per iteration (UNR loads of 8 rows in flight), the 4 waves stride by 32 * UNR rows
-    constexpr int UNR = 4;     // 8 in flight reads 2 % faster alone, but starves the other group's short kernels (12.3 vs 12.7 k tokens/s)
-    for (int r0 = wid * (8 * UNR); r0 < nkeys; r0 += 4 * 8 * UNR) {
-        half8v kv[UNR];
+    for (int r0 = wid * (RPI * UNR); r0 < nkeys; r0 += 4 * RPI * UNR) {
+        u32x4 kv[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int r = r0 + u * 8 + rowi;
-            const int rr = min(r, nkeys - 1);
-            kv[u] = __builtin_nontemporal_load((const half8v*)(K + (size_t)(k_begin + rr) * 64 + sub * 8));
+            const int rr = min(r0 + u * RPI + rowi, nkeys - 1);
+            kv[u] = __builtin_nontemporal_load((const u32x4*)(K + ((size_t)(k_begin + rr) * 64 + sub * DPL) * ESZ));
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int r = r0 + u * 8 + rowi;
-            float ks[8];
+            const int r = r0 + u * RPI + rowi;
+            float accs[L];
+            if constexpr (I8) {
+                const uint32_t w4[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ks[e] = r16((float)kv[u][e] * ATTN_SCALE);
+                for (int i = 0; i < L; ++i) accs[i] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    half2v lo, hi;
+                    cvt_s8x4_f16x4(w4[c], lo, hi);                       // codes as exact fp16 pairs
+#pragma unroll
+                    for (int i = 0; i < L; ++i) {
+                        accs[i] = __builtin_amdgcn_fdot2(qh2[i][2 * c], lo, accs[i], false);
+                        accs[i] = __builtin_amdgcn_fdot2(qh2[i][2 * c + 1], hi, accs[i], false);
+                    }
+                }
+            } else {
+                float ks[DPL];
+                unpack(kv[u], ks);
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) ks[e] = r16(ks[e] * ATTN_SCALE);
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int e = 0; e < DPL; ++e) acc += qf[i][e] * ks[e];
+                    accs[i] = acc;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < L; ++i) {
-                float acc = 0.f;
+                float acc = accs[i];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += qf[i][e] * ks[e];
-                acc += __shfl_xor(acc, 1);
-                acc += __shfl_xor(acc, 2);
-                acc += __shfl_xor(acc, 4);
-                const float sc = r16(acc);
+                for (int x = 1; x < LPR; x <<= 1) acc += __shfl_xor(acc, x);
+                const float sc = I8 ? r16(acc * k_scale) : r16(acc);
                 if (r < nkeys) {
                     if (sub == 0) s_sc[i][r] = sc;
                     mx[i] = fmaxf(mx[i], sc);
@@ -356,47 +411,48 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     }
 
     // ---- pass 2: P.V --------------------------------------------------------------------------------
-    float o[L][8];
+    float o[L][DPL];
 #pragma unroll
     for (int i = 0; i < L; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[i][e] = 0.f;
-    for (int r0 = wid * (8 * UNR); r0 < nkeys; r0 += 4 * 8 * UNR) {
-        half8v vv[UNR];
+        for (int e = 0; e < DPL; ++e) o[i][e] = 0.f;
+    for (int r0 = wid * (RPI * UNR); r0 < nkeys; r0 += 4 * RPI * UNR) {
+        u32x4 vv[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int r = min(r0 + u * 8 + rowi, nkeys - 1);
-            vv[u] = __builtin_nontemporal_load((const half8v*)(V + (size_t)(k_begin + r) * 64 + sub * 8));
+            const int rr = min(r0 + u * RPI + rowi, nkeys - 1);
+            vv[u] = __builtin_nontemporal_load((const u32x4*)(V + ((size_t)(k_begin + rr) * 64 + sub * DPL) * ESZ));
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int r = r0 + u * 8 + rowi;
+            const int r = r0 + u * RPI + rowi;
             if (r < nkeys) {
+                float vx[DPL];
+                unpack(vv[u], vx);
 #pragma unroll
                 for (int i = 0; i < L; ++i) {
                     const float pr = s_sc[i][r];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[i][e] += pr * (float)vv[u][e];
+                    for (int e = 0; e < DPL; ++e) o[i][e] += pr * vx[e];
                 }
             }
         }
     }
-    // reduce over the 8 row-lanes sharing a column group (lane bits 3..5), then over the 4 waves
+    // reduce over the row-lanes sharing a column group (lane bits above log2(LPR)), then over the 4 waves
 #pragma unroll
     for (int i = 0; i < L; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < DPL; ++e) {
             float v = o[i][e];
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+#pragma unroll
+            for (int x = LPR; x < 64; x <<= 1) v += __shfl_xor(v, x);
             o[i][e] = v;
         }
     if (rowi == 0) {
 #pragma unroll
         for (int i = 0; i < L; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s_o[wid][i][sub * 8 + e] = o[i][e];
+            for (int e = 0; e < DPL; ++e) s_o[wid][i][sub * DPL + e] = I8 ? o[i][e] * p.kv_q8_scale : o[i][e];
     }
     __syncthreads();
     for (int idx = tid; idx < L * 64; idx += 256) {
@@ -450,7 +506,17 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
     const int n_items = p.H * p.B * p.nsplit;
     int persist_wgs = persist_env >= 0 ? persist_env : (n_items >= 4 * n_cu ? 2 * n_cu : 0);
     dim3 grid(persist_wgs > 0 && persist_wgs < n_items ? persist_wgs : n_items);
-    if (ev_start && ev_stop && p.L == 1) {
+    if (p.kv_q8_scale > 0.f) {                                   // int8 cross K/V (opt-in)
+        switch (p.L) {
+            case 1:
+                if (ev_start && ev_stop) hipExtLaunchKernelGGL((attn_cross_kernel<1, true>), grid, dim3(256), 0, stream, ev_start, ev_stop, 0, p);
+                else hipLaunchKernelGGL((attn_cross_kernel<1, true>), grid, dim3(256), 0, stream, p);
+                break;
+            case 2: hipLaunchKernelGGL((attn_cross_kernel<2, true>), grid, dim3(256), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((attn_cross_kernel<3, true>), grid, dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((attn_cross_kernel<4, true>), grid, dim3(256), 0, stream, p); break;
+        }
+    } else if (ev_start && ev_stop && p.L == 1) {
         // in-situ roofline sample (bench.py): the events take the dispatch's own begin / end timestamps, as a
         // profiler would -- events recorded around an ordinary launch add ~45 us of marker latency to a 148 us kernel
         hipExtLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, ev_start, ev_stop, 0, p);

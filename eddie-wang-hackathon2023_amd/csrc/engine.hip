@@ -73,6 +73,7 @@ struct DecLayer {
     const h16 *ln1g, *ln1b, *lncg, *lncb, *ln2g, *ln2b;
     Lin qkv, out, cq, cout, mlp1, mlp2;
     float kv_scale = 1.f;
+    float cross_scale = 0.f;      // > 0: int8 cross K/V (WM_FLAG_INT8_CROSS_KV)
 };
 
 }  // namespace wm
@@ -89,12 +90,13 @@ struct wm_engine {
     Lin conv1, conv2; const h16* enc_pos = nullptr; const h16 *lnpg = nullptr, *lnpb = nullptr;
     std::vector<EncLayer> enc;
     // cross
-    std::vector<Lin> ckv;
+    std::vector<Lin> ckv; std::vector<float> ckv_scale;
     // decoder
     const void* emb_t = nullptr; int emb_blocks = 0; const h16 *lnfg = nullptr, *lnfb = nullptr;
     std::vector<DecLayer> dec;
     bool w8() const { return flags & WM_FLAG_WEIGHT_ONLY_INT8; }
     bool i8kv() const { return flags & WM_FLAG_INT8_KV; }
+    bool i8cross() const { return flags & WM_FLAG_INT8_CROSS_KV; }
     int gelu() const { return (flags & WM_FLAG_GELU_TANH) ? 2 : 1; }
 };
 
@@ -166,6 +168,12 @@ int resolve(wm_engine* e) {
         for (int i = 0; i < d.n_text_layer; ++i) {
             snprintf(buf, sizeof(buf), "blocks.%d.kv", i);
             if (get_lin(e, buf, false, true, true, &e->ckv[i])) return 1;
+            if (e->i8cross()) {
+                snprintf(buf, sizeof(buf), "blocks.%d.cross_kv_scale", i);
+                auto it = e->scalars.find(buf);
+                if (it == e->scalars.end() || !(it->second > 0.f)) { set_error("int8 cross-K/V engine lacks a positive %s", buf); return 1; }
+                e->ckv_scale.push_back(it->second);
+            }
         }
     } else if (e->kind == WM_ENGINE_DECODER) {
         Tensor emb;
@@ -188,6 +196,11 @@ int resolve(wm_engine* e) {
                 if (it == e->scalars.end()) { set_error("int8-KV engine lacks %skv_scale", p.c_str()); return 1; }
                 L.kv_scale = it->second;
                 if (!(L.kv_scale > 0.f)) { set_error("%skv_scale must be positive", p.c_str()); return 1; }
+            }
+            if (e->i8cross()) {
+                auto it = e->scalars.find(p + "cross_kv_scale");
+                if (it == e->scalars.end() || !(it->second > 0.f)) { set_error("int8 cross-K/V engine lacks a positive %scross_kv_scale", p.c_str()); return 1; }
+                L.cross_scale = it->second;
             }
         }
     } else {
@@ -399,6 +412,7 @@ int wm_cross_kv(const wm_engine* e, const void* xa, int B, void* const* out_laye
         WM_REQUIRE(out_layers[i], "wm_cross_kv: output %d is null", i);
         GemmBigParams p{};
         p.out_mode = 1; p.hs_T = T; p.hs_H = H; p.hs_kv = -1;
+        if (e->i8cross()) p.q8_inv_scale = 1.0f / e->ckv_scale[i];     // out_layers[i] is int8 [B,2,H,T,64]
         if (big(e->ckv[i], e, (const h16*)xa, C, B * T, (h16*)out_layers[i], 0, 0, nullptr, 0, s, &p)) return 2;
     }
     return 0;
@@ -556,6 +570,7 @@ struct GroupStep {
         p.B = B; p.L = L; p.H = H; p.Tk = d.n_audio_ctx;
         WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
         p.kv = (const h16*)io->cross[i]; p.kv_bstride = (long)2 * H * d.n_audio_ctx * 64;
+        p.kv_q8_scale = e->i8cross() ? Lr.cross_scale : 0.f;
         p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
         const int slot = (L == 1) ? prof_slot(i, s) : -1;
         if (launch_attn_cross(p, s, slot >= 0 ? g_prof.start[slot] : nullptr, slot >= 0 ? g_prof.stop[slot] : nullptr)) return 2;
@@ -768,6 +783,17 @@ int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void
     AttnCrossParams p{};
     p.part = q; p.ksplit = 1; p.ldp = H * 64; p.bias = nullptr;
     p.B = B; p.L = L; p.H = H; p.Tk = Tk; p.kv = (const h16*)kv; p.kv_bstride = (long)2 * H * Tk * 64;
+    p.out = (h16*)out; p.ldo = H * 64; p.nsplit = nsplit; p.ws = ws;
+    return launch_attn_cross(p, (hipStream_t)stream);
+}
+
+int wm_attn_decode_cross_i8(const float* q, int B, int L, int H, int Tk, const void* kv_i8, float kv_scale, void* out, int nsplit,
+                            float* ws, wm_stream_t stream) {
+    WM_REQUIRE(kv_scale > 0.f, "wm_attn_decode_cross_i8: the scale must be positive");
+    AttnCrossParams p{};
+    p.part = q; p.ksplit = 1; p.ldp = H * 64; p.bias = nullptr;
+    p.B = B; p.L = L; p.H = H; p.Tk = Tk; p.kv = (const h16*)kv_i8; p.kv_bstride = (long)2 * H * Tk * 64;
+    p.kv_q8_scale = kv_scale;
     p.out = (h16*)out; p.ldo = H * 64; p.nsplit = nsplit; p.ws = ws;
     return launch_attn_cross(p, (hipStream_t)stream);
 }

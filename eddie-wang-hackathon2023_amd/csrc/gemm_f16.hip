@@ -191,6 +191,14 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
                 const int col = colw + j * 16;
                 const int kv = p.hs_kv < 0 ? col / HC : p.hs_kv, cc = p.hs_kv < 0 ? col % HC : col;
                 const size_t off = ((((size_t)bb * 2 + kv) * p.hs_H + (cc >> 6)) * p.hs_T + t) * 64 + (cc & 63);
+                if (p.q8_inv_scale > 0.f) {      // int8 cross K/V (opt-in): the fp16 result, quantised like the self-attention cache
+                    char4 q;
+                    q.x = (signed char)fminf(127.f, fmaxf(-128.f, rintf(r16(v[j][0]) * p.q8_inv_scale)));
+                    q.y = (signed char)fminf(127.f, fmaxf(-128.f, rintf(r16(v[j][1]) * p.q8_inv_scale)));
+                    q.z = (signed char)fminf(127.f, fmaxf(-128.f, rintf(r16(v[j][2]) * p.q8_inv_scale)));
+                    q.w = (signed char)fminf(127.f, fmaxf(-128.f, rintf(r16(v[j][3]) * p.q8_inv_scale)));
+                    *(char4*)((signed char*)p.C + off) = q;
+                } else
                 *(half4v*)(p.C + off) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
             }
         }

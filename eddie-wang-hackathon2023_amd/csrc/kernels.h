@@ -15,6 +15,7 @@ struct GemmBigParams {
     int colscale_n; float colscale;          // columns < colscale_n are multiplied by colscale
     int out_mode;                            // 0 row-major, 1 head-split [B,2,H,T,64]
     int hs_T, hs_H, hs_kv;                   // hs_kv < 0: N = 2*H*64, kv = col / (H*64)
+    float q8_inv_scale;                      // > 0 (head-split only): C is int8, code = sat_s8(rne(fp16 result * q8_inv_scale))
     // batched strided views (convolutions as GEMMs over a zero-padded token-major buffer):
     // row m lives at A + (m / a_rows) * a_bstride + (m % a_rows) * lda   (a_rows == 0: plain)
     int a_rows; long a_bstride;
@@ -102,7 +103,8 @@ struct AttnCrossParams {
     long part_sstride;
     const h16* bias;                         // [C]
     int B, L, H, Tk;                         // Tk = n_audio_ctx (1500)
-    const h16* kv; long kv_bstride;          // [B][2][H][Tk][64] fp16
+    const h16* kv; long kv_bstride;          // [B][2][H][Tk][64] fp16 (or int8 codes when kv_q8_scale > 0); stride in elements
+    float kv_q8_scale;                       // > 0: K/V are int8, value = fp16(code) * scale (opt-in int8 cross K/V)
     h16* out; int ldo;                       // [M][C]
     int nsplit;                              // key-range splits per (b,h)  (1 = single pass)
     float* ws;                               // [B*H*nsplit][L][66] partial (m, l, o[64]) when nsplit > 1

@@ -214,6 +214,7 @@ class WhisperDecoding:
             self.sot_index = self.initial_tokens.index(self.tokenizer.sot)
         self.sample_begin: int = len(self.initial_tokens)
         self.use_int8_kv_cache = self.decoder_config['use_int8_kv_cache']
+        self.use_int8_cross_kv = bool(self.decoder_config.get('use_int8_cross_kv', False))     # opt-in, beyond the reference
 
         pe = np.load(engine_dir / 'positional_embedding.npy')
         self.positional_embedding = torch.tensor(pe)
@@ -368,7 +369,8 @@ class WhisperDecoding:
             else:
                 add('past_key_value_' + str(i), past_key_value[i].contiguous(), kv_dtype)
         for i in range(n_layer):
-            add('cross_past_key_value_' + str(i), cross_past_key_value[i].contiguous(), 'float16')
+            add('cross_past_key_value_' + str(i), cross_past_key_value[i].contiguous(),
+                'int8' if self.use_int8_cross_kv else 'float16')
 
         output_info = self.decoder_session.infer_shapes(infos)
         assert output_info is not None, 'infer_shapes failed'
@@ -553,7 +555,8 @@ class WhisperDecoding:
         blank = list(tk.blank_tokens()) + [tk.eot] if self.options.suppress_blank else []
         st = dict(
             kv=[torch.zeros((n_batch, 2, n_head, cap, 64), dtype=kv_dtype, device=device) for _ in range(n_layer)],
-            cross=[torch.empty((n_batch, 2, n_head, cfg['num_audio_ctx'], 64), dtype=torch.float16, device=device)
+            cross=[torch.empty((n_batch, 2, n_head, cfg['num_audio_ctx'], 64),
+                               dtype=torch.int8 if self.use_int8_cross_kv else torch.float16, device=device)
                    for _ in range(n_layer)],
             cross_key=None, cross_xa=None, graphs={}, counters={},
             tokens=torch.zeros((n_batch, cap + 1), dtype=torch.int32, device=device),

@@ -29,7 +29,7 @@ from native import Engine, WmDecoderIO, check, ptr_array
 logger = logging.getLogger("whisper_mi355")
 
 ENGINE_ENCODER, ENGINE_DECODER, ENGINE_CROSS_KV = 0, 1, 2
-FLAG_WEIGHT_ONLY_INT8, FLAG_INT8_KV, FLAG_GELU_TANH = 1, 2, 4
+FLAG_WEIGHT_ONLY_INT8, FLAG_INT8_KV, FLAG_GELU_TANH, FLAG_INT8_CROSS_KV = 1, 2, 4, 16
 
 _STR_TO_TORCH = {"float16": torch.float16, "float32": torch.float32, "int32": torch.int32, "int8": torch.int8,
                  "bfloat16": torch.bfloat16}
@@ -94,6 +94,11 @@ class Session(object):
     def kv_dtype(self) -> str:
         return "int8" if self._engine.flags & FLAG_INT8_KV else "float16"
 
+    @property
+    def cross_kv_dtype(self) -> str:
+        """fp16 like the reference, or int8 codes for engines built with --int8_cross_kv (opt-in, beyond the reference)."""
+        return "int8" if self._engine.flags & FLAG_INT8_CROSS_KV else "float16"
+
     def _workspace(self, key: tuple, nbytes: int) -> torch.Tensor:
         ws = self._workspaces.get(key)
         if ws is None or ws.numel() < nbytes:
@@ -114,7 +119,7 @@ class Session(object):
                 "cache_indirection": "int32", "past_key_value_length": "int32", "sequence_length": "int32"}
         for i in range(d["n_text_layer"]):
             spec[f"past_key_value_{i}"] = self.kv_dtype
-            spec[f"cross_past_key_value_{i}"] = "float16"
+            spec[f"cross_past_key_value_{i}"] = self.cross_kv_dtype
         return spec
 
     def infer_shapes(self, inputs: List[TensorInfo], context=None) -> Optional[List[TensorInfo]]:
@@ -135,7 +140,7 @@ class Session(object):
         if self.kind == ENGINE_CROSS_KV:
             b = self._shapes["xa"][0]
             shape = (b, 2, d["n_text_head"], d["n_audio_ctx"], d["n_text_state"] // d["n_text_head"])
-            return [TensorInfo(f"cross_present_key_value_{i}", "float16", shape) for i in range(d["n_text_layer"])]
+            return [TensorInfo(f"cross_present_key_value_{i}", self.cross_kv_dtype, shape) for i in range(d["n_text_layer"])]
         b, l = self._shapes["x"]
         t = self._shapes.get("past_key_value_0", (b, 2, d["n_text_head"], 0, 64))[3]
         outs = [TensorInfo("output", "float16", (b, l, d["n_vocab"]))]

@@ -64,6 +64,34 @@ def capture_kv_activation_range(engine_dir, mels: torch.Tensor, batch: int = 8, 
     return amax.cpu().tolist()
 
 
+def capture_cross_kv_range(engine_dir, mels: torch.Tensor, batch: int = 8) -> List[float]:
+    """max(|K|, |V|) of every layer's cross-attention K/V over `mels`, from the fp16 engines in `engine_dir`: the
+    statistic the opt-in int8 cross-K/V mode (build.py --int8_cross_kv, beyond the reference) is scaled by."""
+    from decoding import WhisperDecoding
+    from encoding import WhisperEncoding
+    engine_dir = Path(engine_dir)
+    enc, dec = WhisperEncoding(engine_dir), WhisperDecoding(engine_dir)
+    assert not dec.use_int8_cross_kv, "calibrate with an fp16 cross-K/V engine"
+    amax = [0.0] * dec.decoder_config['num_layers']
+    for i in range(0, mels.shape[0], batch):
+        xa = enc.get_audio_features(mels[i:i + batch].to('cuda').type(torch.float16))
+        for l, c in enumerate(dec.xa2cross_key_value(xa)):
+            amax[l] = max(amax[l], float(c.abs().max()))
+    return amax
+
+
+def cross_scale_file_name(layer: int) -> str:
+    return f"model.decoder.blocks.{layer}.cross_attn.key_value.scale_y_quant_orig.bin"
+
+
+def write_cross_kv_scales(out_dir, amax: List[float]) -> Path:
+    saved_dir = Path(out_dir) / "1-gpu"
+    saved_dir.mkdir(parents=True, exist_ok=True)
+    for i, a in enumerate(amax):
+        np.array([np.float32(a) / np.float32(127.0)], dtype=np.float32).tofile(saved_dir / cross_scale_file_name(i))
+    return saved_dir
+
+
 def write_kv_scales(out_dir, amax: List[float], meta: Optional[dict] = None) -> Path:
     """scale_y_quant_orig = max / 127 (W/utils/convert.py:76-78,98,138-140), one fp32 per layer."""
     saved_dir = Path(out_dir) / "1-gpu"
@@ -120,9 +148,12 @@ def run_conversion(args):
         if engine_dir is None:      # the reference calibrates the un-quantised fp16 model
             engine_dir = os.path.join(tmp, "calib_engine")
             B.build_from_checkpoint(model, B.parse_arguments(["--output_dir", engine_dir, "--log_level", "error"]))
-        amax = capture_kv_activation_range(engine_dir, load_calibration_mels(args, model['dims']))
+        mels = load_calibration_mels(args, model['dims'])
+        amax = capture_kv_activation_range(engine_dir, mels)
+        cross_amax = capture_cross_kv_range(engine_dir, mels)
     out = write_kv_scales(args.out_dir, amax, {k: v for k, v in vars(args).items()})
-    print(f"wrote {len(amax)} KV scales to {out}")
+    write_cross_kv_scales(args.out_dir, cross_amax)          # for the opt-in int8 cross-K/V mode (build.py --int8_cross_kv)
+    print(f"wrote {len(amax)} KV scales (+ cross-K/V scales) to {out}")
 
 
 if __name__ == "__main__":

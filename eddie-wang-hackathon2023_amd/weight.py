@@ -36,7 +36,7 @@ import numpy as np
 import torch
 
 ENGINE_ENCODER, ENGINE_DECODER, ENGINE_CROSS_KV = 0, 1, 2
-FLAG_WEIGHT_ONLY_INT8, FLAG_INT8_KV, FLAG_GELU_TANH = 1, 2, 4
+FLAG_WEIGHT_ONLY_INT8, FLAG_INT8_KV, FLAG_GELU_TANH, FLAG_INT8_CROSS_KV = 1, 2, 4, 16
 DIM_KEYS = ("n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
             "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")
 _DTYPE_CODE = {np.dtype(np.float16): 0, np.dtype(np.int8): 1, np.dtype(np.float32): 2, np.dtype(np.int32): 3,
@@ -255,9 +255,18 @@ def read_kv_scale(quantize_dir: str, layer: int) -> float:
     return float(np.fromfile(path, dtype=np.float32).reshape(1)[0])
 
 
+def read_cross_kv_scale(quantize_dir: str, layer: int) -> float:
+    """Scale of the int8 cross-attention K/V of one layer, fp32[1] (opt-in mode; written by torch_whisper_convert.py -kv
+    next to the self-attention scales)."""
+    path = os.path.join(quantize_dir, f"model.decoder.blocks.{layer}.cross_attn.key_value.scale_y_quant_orig.bin")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: int8 cross K/V needs its calibration scales (torch_whisper_convert.py -kv)")
+    return float(np.fromfile(path, dtype=np.float32).reshape(1)[0])
+
+
 def load_decoder_weight(model_params: dict, n_layer: int, quantize_dir: Optional[str] = None,
-                        use_weight_only: bool = False, use_int8_kv_cache: bool = False
-                        ) -> "OrderedDict[str, np.ndarray]":
+                        use_weight_only: bool = False, use_int8_kv_cache: bool = False,
+                        use_int8_cross_kv: bool = False) -> "OrderedDict[str, np.ndarray]":
     """Decoder engine tensors (W/weight.py:154-339).  All Linears are tile-linear; the token
     embedding is stored once (fp16 tile-linear) and serves both the gather and the logits GEMM
     (the reference stores it twice: whisper/model.py:212,231)."""
@@ -271,6 +280,8 @@ def load_decoder_weight(model_params: dict, n_layer: int, quantize_dir: Optional
         _linear(t, o + ".out", model_params[p + ".attn.out.weight"], model_params[p + ".attn.out.bias"], use_weight_only, True)
         if use_int8_kv_cache:
             t[o + ".kv_scale"] = np.array([read_kv_scale(quantize_dir, i)], dtype=np.float32)
+        if use_int8_cross_kv:
+            t[o + ".cross_kv_scale"] = np.array([read_cross_kv_scale(quantize_dir, i)], dtype=np.float32)
         _ln(t, o + ".cross_ln", model_params, p + ".cross_attn_ln")
         _linear(t, o + ".cq", model_params[p + ".cross_attn.query.weight"], model_params[p + ".cross_attn.query.bias"],
                 use_weight_only, True)
@@ -283,7 +294,8 @@ def load_decoder_weight(model_params: dict, n_layer: int, quantize_dir: Optional
     return t
 
 
-def load_crossattn_linear_weight(model_params: dict, n_layer: int, use_weight_only: bool = False
+def load_crossattn_linear_weight(model_params: dict, n_layer: int, use_weight_only: bool = False,
+                                 use_int8_cross_kv: bool = False, quantize_dir: Optional[str] = None
                                  ) -> "OrderedDict[str, np.ndarray]":
     """Cross-attention K/V engine tensors (W/weight.py:341-375): per layer one fused [2C, C]
     projection (K rows then V rows), bias [0, v bias]."""
@@ -294,6 +306,8 @@ def load_crossattn_linear_weight(model_params: dict, n_layer: int, use_weight_on
         vb = _np(model_params[p + ".value.bias"])
         _linear(t, f"blocks.{i}.kv", torch.cat([wk, wv], dim=0),
                 np.concatenate([np.zeros_like(vb), vb], axis=0), use_weight_only, False)
+        if use_int8_cross_kv:
+            t[f"blocks.{i}.cross_kv_scale"] = np.array([read_cross_kv_scale(quantize_dir, i)], dtype=np.float32)
     return t
 
 

@@ -34,7 +34,8 @@ typedef struct wm_engine wm_engine;
 typedef void* wm_stream_t; /* hipStream_t */
 
 enum { WM_ENGINE_ENCODER = 0, WM_ENGINE_DECODER = 1, WM_ENGINE_CROSS_KV = 2 };
-enum { WM_FLAG_WEIGHT_ONLY_INT8 = 1, WM_FLAG_INT8_KV = 2, WM_FLAG_GELU_TANH = 4 };
+enum { WM_FLAG_WEIGHT_ONLY_INT8 = 1, WM_FLAG_INT8_KV = 2, WM_FLAG_GELU_TANH = 4,
+       WM_FLAG_INT8_CROSS_KV = 16 /* opt-in, beyond the reference: cross-attention K/V stored as int8 codes */ };
 
 /* Same ten fields, same order, as the OpenAI checkpoint `dims` (W/build.py:146-154). */
 typedef struct wm_dims {
@@ -165,6 +166,9 @@ int wm_attn_encoder(const void* qkv, int ld, int B, int T, int H, void* out, int
 /* Decode cross-attention: q fp32 [B*L, H*64] (un-scaled, bias included), kv fp16 [B,2,H,Tk,64]. */
 int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void* kv, void* out,
                          int nsplit, float* ws, wm_stream_t stream);
+/* the same with int8 K/V codes [B,2,H,Tk,64] and one scale (value = fp16(code) * kv_scale, rounded to fp16) */
+int wm_attn_decode_cross_i8(const float* q, int B, int L, int H, int Tk, const void* kv_i8, float kv_scale,
+                            void* out, int nsplit, float* ws, wm_stream_t stream);
 /* Decode self-attention with append: qkv fp32 [B*L, 3*H*64] (bias included); cache [B,2,H,cap,64]. */
 int wm_attn_decode_self(const float* qkv, int B, int L, int T, int H, const void* past, int past_cap,
                         void* present, int present_cap, int int8_kv, float kv_scale, void* out,

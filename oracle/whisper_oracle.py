@@ -285,6 +285,11 @@ class OracleConfig:
     weight_only: object = False       # F7: False, True (= int8) or 'int4'
     int8_kv: bool = False             # F2
     kv_scales: Optional[List[float]] = None   # t per decoder layer (F8)
+    # int8 cross-attention K/V (BEYOND the reference, which keeps them fp16; an opt-in engine mode): codes =
+    # sat_s8(rne(x / t)) of the fp16 projection output; attention uses the exact fp32 values code * t (no fp16 rounding
+    # of the dequantised K / V: scores = r16(qh . (code_k * t * d^-0.25)), out = r16(w . (code_v * t))).
+    int8_cross_kv: bool = False
+    cross_kv_scales: Optional[List[float]] = None   # t per decoder layer: max(|K|, |V|) / 127 of that layer's cross K/V
 
 
 def _gelu(x: torch.Tensor, kind: str) -> torch.Tensor:
@@ -334,14 +339,17 @@ class OracleModel:
         y = F.layer_norm(x, (x.shape[-1],), self.p[prefix + ".weight"], self.p[prefix + ".bias"], 1e-5)
         return _r(y, self.cfg.act)
 
-    def _attend(self, q, k, v, n_head, mask=None):
-        """W/torch_model.py:88-103.  q [B,Lq,C], k/v [B,Lk,C] -> [B,Lq,C]."""
+    def _attend(self, q, k, v, n_head, mask=None, k_exact=False):
+        """W/torch_model.py:88-103.  q [B,Lq,C], k/v [B,Lk,C] -> [B,Lq,C].  `k_exact`: K (already an exact product
+        code * t of the opt-in int8 cross-K/V mode) is scaled in fp32 without the fp16 rounding a stored fp16 K gets."""
         act = self.cfg.act
         B, Lq, C = q.shape
         d = C // n_head
         scale = d ** -0.25
         qh = _r(q.view(B, Lq, n_head, d).permute(0, 2, 1, 3) * scale, act)
-        kh = _r(k.view(B, -1, n_head, d).permute(0, 2, 3, 1) * scale, act)
+        kh = k.view(B, -1, n_head, d).permute(0, 2, 3, 1) * scale
+        if not k_exact:
+            kh = _r(kh, act)
         vh = v.view(B, -1, n_head, d).permute(0, 2, 1, 3)
         qk = _r(qh @ kh, act)
         if mask is not None:
@@ -395,8 +403,21 @@ class OracleModel:
             v = self._linear(xa, p + ".value.weight", p + ".value.bias")
             k = k.view(B, T, H, C // H).permute(0, 2, 1, 3)
             v = v.view(B, T, H, C // H).permute(0, 2, 1, 3)
-            out.append(torch.stack([k, v], dim=1).contiguous())
+            kv = torch.stack([k, v], dim=1).contiguous()
+            if self.cfg.int8_cross_kv:
+                kv = kv_quantize(kv, self.cfg.cross_kv_scales[i])
+            out.append(kv)
         return out
+
+    def calibrate_cross_kv_scales(self, mels: torch.Tensor) -> List[float]:
+        """t_i = max(|K_i|, |V_i|) / 127 over the cross K/V of `mels` (the rule F8 applies to the self-attention cache)."""
+        saved = self.cfg.int8_cross_kv
+        self.cfg.int8_cross_kv = False
+        try:
+            ckv = self.cross_kv(self.encoder(mels))
+        finally:
+            self.cfg.int8_cross_kv = saved
+        return [float(np.float32(float(c.abs().max())) / np.float32(127.0)) for c in ckv]
 
     # -- decoder (a3, a4, a6, a11) -----------------------------------------------------
     def decoder(self, tokens: torch.Tensor, cross_kv: List[torch.Tensor],
@@ -443,9 +464,13 @@ class OracleModel:
 
             h = self._ln(x, p + ".cross_attn_ln")
             q = self._linear(h, p + ".cross_attn.query.weight", p + ".cross_attn.query.bias")
-            ck = cross_kv[i][:, 0].float().permute(0, 2, 1, 3).reshape(B, -1, C)
-            cv = cross_kv[i][:, 1].float().permute(0, 2, 1, 3).reshape(B, -1, C)
-            a = self._attend(q, ck, cv, H)
+            if cfg.int8_cross_kv:
+                ckv_i = cross_kv[i].float() * float(np.float32(cfg.cross_kv_scales[i]))
+            else:
+                ckv_i = cross_kv[i].float()
+            ck = ckv_i[:, 0].permute(0, 2, 1, 3).reshape(B, -1, C)
+            cv = ckv_i[:, 1].permute(0, 2, 1, 3).reshape(B, -1, C)
+            a = self._attend(q, ck, cv, H, k_exact=cfg.int8_cross_kv)
             x = _r(x + self._linear(a, p + ".cross_attn.out.weight", p + ".cross_attn.out.bias"), act)
 
             x = _r(x + self._mlp(self._ln(x, p + ".mlp_ln"), p + ".mlp"), act)

@@ -211,6 +211,33 @@ def test_attn_decode_cross(lib, B, L, H, Tk, nsplit):
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("B,L,H,Tk,nsplit", [(2, 1, 2, 100, 1), (2, 3, 2, 100, 1), (1, 1, 20, 1500, 1), (3, 1, 2, 1500, 4),
+                                             (2, 4, 3, 333, 3), (1, 2, 1, 8, 1), (130, 1, 20, 64, 1)])
+def test_attn_decode_cross_int8(lib, B, L, H, Tk, nsplit):
+    """Opt-in int8 cross K/V (beyond the reference): codes = sat_s8(rne(x / t)), attention uses code * t exactly; against the
+    oracle's attention over those values.  (130 utterances x 20 heads takes the persistent-launch path.)"""
+    r = rng(7 * B + L + H + Tk)
+    C_ = H * 64
+    q = r.standard_normal((B * L, C_)).astype(np.float16).astype(np.float32)
+    kv = r.standard_normal((B, 2, H, Tk, 64)).astype(np.float16)
+    t = float(np.float32(np.abs(kv).max()) / np.float32(127.0))
+    codes = kv_quantize(torch.from_numpy(kv), t)
+    deq = codes.float() * float(np.float32(t))                       # the mode's values are exactly code * t
+    m = OracleModel(Dims(80, Tk, C_, H, 0, 8, 4, C_, H, 0), {}, OracleConfig(act="float16"))
+    kk = deq[:, 0].permute(0, 2, 1, 3).reshape(B, Tk, C_)
+    vv = deq[:, 1].permute(0, 2, 1, 3).reshape(B, Tk, C_)
+    ref = m._attend(torch.from_numpy(q).reshape(B, L, C_), kk, vv, H, k_exact=True).numpy().reshape(B * L, C_)
+    qd, cd = dev(q), codes.cuda()
+    out = torch.zeros((B * L, C_), dtype=torch.float16, device="cuda")
+    ws = torch.zeros(B * H * nsplit * L * 66, dtype=torch.float32, device="cuda")
+    native.check(lib.wm_attn_decode_cross_i8(qd.data_ptr(), B, L, H, Tk, cd.data_ptr(), t, out.data_ptr(), nsplit,
+                                             ws.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    tol = 1e-3 if nsplit == 1 else 2e-3
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+
+
 # --------------------------------------------------------------------------------- decode self-attention
 @pytest.mark.parametrize("int8_kv", [0, 1])
 @pytest.mark.parametrize("B,L,T,H,inplace", [(2, 3, 0, 2, True), (2, 1, 5, 2, True), (1, 1, 130, 3, False),
