@@ -21,6 +21,7 @@ What differs underneath:
 from __future__ import annotations
 
 import json
+import os
 import zlib
 from collections import OrderedDict
 from dataclasses import dataclass, field
@@ -241,7 +242,7 @@ class WhisperDecoding:
         self._cross_cache = None          # (key, list of cross K/V) from the last xa2cross_key_value
         self._state = {}                  # per-batch-size device buffers of the fast path
         self.poll_every = 8
-        self.micro_batches = 2            # stream-level overlap of independent utterance groups
+        self.micro_batches = None         # stream-parallel utterance groups: None = by batch size (_groups), or a fixed count
         self.lang_id_sequential = False   # bench.py: run the language pass group by group (0.2 % of a step) so that its
                                           # HIP-event kernel timings are not inflated by the other group's HBM share
         # experimental schedule (off by default): cross-attention on its own CU set
@@ -570,7 +571,18 @@ class WhisperDecoding:
         return st
 
     def _group_streams(self, n, dev):
-        """Side streams of the utterance groups (never the legacy default stream: graphs are captured on them)."""
+        """Side streams of the utterance groups (never the legacy default stream: graphs are captured on them).
+
+        Each group gets a HARDWARE QUEUE OF ITS OWN: a stream created with a full CU mask
+        (wm_stream_create_cu_mask) is never multiplexed, whereas ordinary streams share ROCm's pool of
+        GPU_MAX_HW_QUEUES (4) queues and which of them end up sharing depends on how many streams the process
+        created before.  Measured (B = 384, three groups): 18.1 ms per decode step with a queue per group, 23.5 ms when
+        two groups happen to share one -- e.g. in any process that used one more stream earlier (RCCL, a calibration
+        pass).  WM_DEDICATED_QUEUES=0 falls back to torch's stream pool."""
+        if os.environ.get("WM_DEDICATED_QUEUES", "1") != "0":
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            with torch.cuda.device(dev):
+                return [native.create_masked_stream([True] * n_cu, k) for k in range(n)]
         while len(self._streams) < n:
             self._streams.append(torch.cuda.Stream(device=dev))
         return self._streams[:n]
@@ -592,7 +604,12 @@ class WhisperDecoding:
         return self._partition[0][:n], self._partition[1]
 
     def _groups(self, n_batch):
-        n_micro = self.micro_batches if n_batch >= 8 * self.micro_batches else 1
+        # three groups from 128 utterances up (two chains of short kernels hide under the third group's K/V stream;
+        # four concurrent chains are slower again: 18.1 / 28.0 ms per step at B = 384), two from 16, else one
+        if self.micro_batches is None:
+            n_micro = 3 if n_batch >= 128 else 2 if n_batch >= 16 else 1
+        else:
+            n_micro = self.micro_batches if n_batch >= 8 * self.micro_batches else 1
         return n_micro, [(g * n_batch // n_micro, (g + 1) * n_batch // n_micro) for g in range(n_micro)]
 
     def _cross_persistent(self, xa, st):

@@ -6,6 +6,7 @@ fallback: if the HIP library is missing or fails to load, importing the engine r
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 from typing import Optional, Sequence
@@ -180,6 +181,24 @@ class Engine:
 
 
 _MASKED_STREAMS = {}
+
+
+def _destroy_masked_streams():
+    """Interpreter exit: give the dedicated hardware queues back before the HIP runtime (and any profiler
+    attached to it) tears down -- a process that exits with CU-masked queues alive crashes in rocprofv3's finaliser."""
+    if not _MASKED_STREAMS or _lib is None:
+        return
+    try:
+        import torch
+        torch.cuda.synchronize()
+    except Exception:      # noqa: BLE001 -- nothing useful to do at exit
+        pass
+    for st in _MASKED_STREAMS.values():
+        _lib.wm_stream_destroy(st.cuda_stream)
+    _MASKED_STREAMS.clear()
+
+
+atexit.register(_destroy_masked_streams)
 
 
 def create_masked_stream(cu_enabled, index: int = 0):

@@ -381,11 +381,13 @@ def test_micro_batched_streams_give_identical_tokens(tmpdir_module):
     dec.detect_language(xa)
     dec.micro_batches = 1
     t1, lp1, nsp1 = dec.main_loop(xa)
-    dec.micro_batches = 2
-    t2, lp2, nsp2 = dec.main_loop(xa)
-    assert torch.equal(t1.cpu(), t2.cpu())
-    assert torch.allclose(lp1.cpu(), lp2.cpu(), atol=1e-5)
-    assert np.allclose(nsp1, nsp2, atol=1e-6)
+    for groups in (2, None):                                       # a fixed count, and the by-batch-size default
+        dec.micro_batches = groups
+        t2, lp2, nsp2 = dec.main_loop(xa)
+        assert torch.equal(t1.cpu(), t2.cpu())
+        assert torch.allclose(lp1.cpu(), lp2.cpu(), atol=1e-5)
+        assert np.allclose(nsp1, nsp2, atol=1e-6)
+    assert dec._groups(16)[0] == 2 and dec._groups(128)[0] == 3 and dec._groups(8)[0] == 1
     assert len({tuple(r) for r in t1.cpu().tolist()}) > 1          # rows differ: the test is not vacuous
 
 
