@@ -268,32 +268,63 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 
     const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.B * L * p.ldp;
     // ---- q: this lane's DPL dims (sub * DPL .. ) for each of the L tokens -----------------------------
+    // split-K slabs + bias; the slab reads of a round are all in flight together (they are L2 hits, ~1 us each:
+    // taken two at a time they were 10 % of a persistent workgroup's time per item)
     float qf[L][DPL];
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        const int m = b * L + i;
+    {
+        constexpr int QV = DPL / 4;
+        constexpr int UQ = (8 / (L * QV)) >= 2 ? (8 / (L * QV)) : 2;        // slabs per round, even
         const int col0 = h * 64 + sub * DPL;
-        const float* row = p.part + (size_t)m * p.ldp + col0;
+        float bs[DPL];
+        if (p.bias) {
 #pragma unroll
-        for (int q4 = 0; q4 < DPL / 4; ++q4) {
-            float4 qa = make_float4(0.f, 0.f, 0.f, 0.f);
-            int s = 0;
-            for (; s + 2 <= p.ksplit; s += 2) {            // independent 16-byte loads in flight
-                const float4 a0 = *(const float4*)(row + (size_t)s * sstride + q4 * 4);
-                const float4 a1 = *(const float4*)(row + (size_t)(s + 1) * sstride + q4 * 4);
-                qa.x += a0.x + a1.x; qa.y += a0.y + a1.y; qa.z += a0.z + a1.z; qa.w += a0.w + a1.w;
-            }
-            for (; s < p.ksplit; ++s) {
-                const float4 a0 = *(const float4*)(row + (size_t)s * sstride + q4 * 4);
-                qa.x += a0.x; qa.y += a0.y; qa.z += a0.z; qa.w += a0.w;
-            }
-            const float qs[4] = {qa.x, qa.y, qa.z, qa.w};
+            for (int q8 = 0; q8 < DPL / 8; ++q8) {
+                const half8v b8 = *(const half8v*)(p.bias + col0 + q8 * 8);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float q = r16(qs[e] + (p.bias ? (float)p.bias[col0 + q4 * 4 + e] : 0.f));
-                qf[i][q4 * 4 + e] = r16(q * ATTN_SCALE);
+                for (int e = 0; e < 8; ++e) bs[q8 * 8 + e] = (float)b8[e];
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) bs[e] = 0.f;
         }
+        float4 qa[L][QV];
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int q4 = 0; q4 < QV; ++q4) qa[i][q4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < p.ksplit; s0 += UQ) {
+            float4 a[L][QV][UQ];
+#pragma unroll
+            for (int i = 0; i < L; ++i)
+#pragma unroll
+                for (int q4 = 0; q4 < QV; ++q4)
+#pragma unroll
+                    for (int u = 0; u < UQ; ++u) {
+                        const int sl = min(s0 + u, p.ksplit - 1);
+                        a[i][q4][u] = *(const float4*)(p.part + (size_t)(b * L + i) * p.ldp + col0 + (size_t)sl * sstride + q4 * 4);
+                    }
+#pragma unroll
+            for (int i = 0; i < L; ++i)
+#pragma unroll
+                for (int q4 = 0; q4 < QV; ++q4)
+#pragma unroll
+                    for (int u = 0; u < UQ; u += 2) {      // same pairing as ever: qa += (slab s + slab s+1), absent slabs add 0
+                        const bool ok0 = s0 + u < p.ksplit, ok1 = s0 + u + 1 < p.ksplit;
+                        const float4 x = a[i][q4][u], y = a[i][q4][u + 1];
+                        qa[i][q4].x += (ok0 ? x.x : 0.f) + (ok1 ? y.x : 0.f);
+                        qa[i][q4].y += (ok0 ? x.y : 0.f) + (ok1 ? y.y : 0.f);
+                        qa[i][q4].z += (ok0 ? x.z : 0.f) + (ok1 ? y.z : 0.f);
+                        qa[i][q4].w += (ok0 ? x.w : 0.f) + (ok1 ? y.w : 0.f);
+                    }
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int q4 = 0; q4 < QV; ++q4) {
+                const float qs[4] = {qa[i][q4].x, qa[i][q4].y, qa[i][q4].z, qa[i][q4].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qf[i][q4 * 4 + e] = r16(r16(qs[e] + bs[q4 * 4 + e]) * ATTN_SCALE);
+            }
     }
 
     // int8 mode: q as fp16 pairs for v_dot2 (the values are fp16-representable by construction), scale factored out
@@ -492,8 +523,8 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
     WM_REQUIRE(p.nsplit >= 1 && (p.nsplit == 1 || p.ws != nullptr), "attn_cross: split needs a workspace");
     // Persistent launch for big batches: two workgroups per CU walk over the (head, utterance, split) items instead of
     // one workgroup per item.  The kernel alone is as fast either way (6.3-6.7 TB/s), but with 8 of a CU's 32 wave slots
-    // it leaves room for the OTHER utterance group's short kernels to be dispatched while it streams: 13.2 instead of
-    // 13.9 ms per decode step at B = 256 (WM_CROSS_PERSIST_WGS overrides the workgroup count, 0 = one per item).
+    // it leaves room for the OTHER utterance groups' short kernels to be dispatched while it streams: 18.1 instead of
+    // 19.4 ms per decode step at B = 384 (WM_CROSS_PERSIST_WGS overrides the workgroup count, 0 = one per item).
     static const int persist_env = [] { const char* v = getenv("WM_CROSS_PERSIST_WGS"); return v ? atoi(v) : -1; }();
     static int n_cu = 0;
     if (n_cu == 0) {
