@@ -237,8 +237,8 @@ def main():
                                 "itself as it does under rocprofv3 (profiles/*_kernel_stats.csv: same average); the captured "
                                 f"decode graphs replay the same kernel and grid, there {n_micro} groups share the HBM.  The launch is "
                                 "persistent (2 workgroups per CU): with one workgroup per (utterance, head) the kernel alone "
-                                "reads 6.6 TB/s (0.83, profiles/r1e) but crowds out the other group's short kernels; the "
-                                "persistent launch is slower alone and 3-5 % faster for the whole step"}
+                                "reads 6.6 TB/s (0.83, profiles/r1e) but crowds out the other groups' short kernels; the "
+                                "persistent launch is slower alone and 3-7 % faster for the whole step"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
