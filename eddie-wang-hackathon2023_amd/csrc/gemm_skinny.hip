@@ -64,23 +64,43 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
             if (wave_active && t < t_end) wreg[i] = __builtin_nontemporal_load(wt + (size_t)t * 64);
         }
     };
+    // The activation chunk goes global -> registers -> LDS, and the registers of chunk c + 1 are requested before the
+    // MFMAs of chunk c: a workgroup then waits for memory once (weights and first chunk together) instead of once per
+    // chunk.  Next to a K/V stream that keeps the HBM queues full a round trip costs ~3x its unloaded time, and these
+    // kernels are nothing but a few round trips (scripts/contention_probe.py).
+    constexpr int A_VEC = MT * 16 * (KC / 8);             // 16-byte pieces of a chunk
+    constexpr int A_PER_T = (A_VEC + NW * 64 - 1) / (NW * 64);
+    uint4 areg[A_PER_T];
+    auto load_a = [&](int t0) {
+        const int k0 = t0 * KT;
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) {
+            const int c = tid + j * (NW * 64);
+            const int r = c / (KC / 8), cc = c % (KC / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);              // zero rows >= M, zero columns >= K
+            if (c < A_VEC && r < p.M && k0 + cc * 8 < p.K) v = *(const uint4*)(p.A + (size_t)r * p.lda + k0 + cc * 8);
+            areg[j] = v;
+        }
+    };
     load_w(t_begin);
+    load_a(t_begin);
 
     const int frag_row = (lane & 15) * A_ROW;
     for (int t0 = t_begin; t0 < t_end; t0 += TPC) {
-        // ---- stage A[:, t0*KT .. +KC) into LDS (zero rows >= M, zero columns >= K) ----------
-        const int k0 = t0 * KT;
-        for (int c = tid; c < MT * 16 * (KC / 8); c += NW * 64) {
-            const int r = c / (KC / 8), cc = c % (KC / 8);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r < p.M && k0 + cc * 8 < p.K) v = *(const uint4*)(p.A + (size_t)r * p.lda + k0 + cc * 8);
-            *(uint4*)(sA + r * A_ROW + cc * 16) = v;
+        // ---- A[:, t0*KT .. +KC) into LDS -----------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < A_PER_T; ++j) {
+            const int c = tid + j * (NW * 64);
+            if (c < A_VEC) *(uint4*)(sA + (c / (KC / 8)) * A_ROW + (c % (KC / 8)) * 16) = areg[j];
         }
         __syncthreads();
         u32x4 wcur[TPC];
 #pragma unroll
         for (int i = 0; i < TPC; ++i) wcur[i] = wreg[i];
-        if (t0 + TPC < t_end) load_w(t0 + TPC);       // next chunk's weights fly during the MFMAs
+        if (t0 + TPC < t_end) {                       // next chunk's weights and activations fly during the MFMAs
+            load_w(t0 + TPC);
+            load_a(t0 + TPC);
+        }
         if (wave_active) {
 #pragma unroll
             for (int i = 0; i < TPC; ++i) {
