@@ -54,6 +54,7 @@ struct RowFinishParams {
     h16* x; int ldx;
     const h16* ln_g; const h16* ln_b;
     h16* out; int ldo;
+    int eager;                                              // set by the launcher: few rows, go for latency (see launch_row_finish)
 };
 int launch_row_finish(const RowFinishParams& p, hipStream_t stream);
 
