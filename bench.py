@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=384, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=576, help="utterances per GPU per step")
     ap.add_argument("--decode-steps", type=int, default=128, help="forced greedy tokens per utterance")
     ap.add_argument("--model", type=str, default="large-v2")
     ap.add_argument("--config", type=str, default="int8", choices=list(CONFIGS))

@@ -240,21 +240,67 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     constexpr int LPR = 64 / DPL;                        // lanes per row: 8 (fp16) / 4 (int8)
     constexpr int RPI = 64 / LPR;                        // rows per wave-instruction: 8 / 16
     constexpr int ESZ = I8 ? 1 : 2;                      // bytes per stored element
-    constexpr int UNR = 4;     // 8 in flight reads 2 % faster alone, but starves the other group's short kernels (12.3 vs 12.7 k tokens/s)
+    constexpr int UNR = 4;     // loads per block; two blocks are in flight (see `pipeline`)
     __shared__ float s_sc[L][CROSS_MAX_KEYS];
     __shared__ float s_red[L][4][2];
     __shared__ float s_o[4][L][64];
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar loop control
     const int sub = lane % LPR, rowi = lane / LPR;        // 16-byte column, row inside a group of RPI rows
     const int per_split = (((p.Tk + p.nsplit - 1) / p.nsplit) + 7) & ~7;
+    constexpr int STRIDE = 4 * RPI * UNR;                 // rows per iteration of the workgroup
+    const int first = wid * (RPI * UNR);                  // this wave's first row of an item
     // a workgroup walks over (head, utterance, key split) items: with fewer workgroups than items the
     // launch is persistent and leaves wave slots on every CU to the other streams' short kernels
     const int n_items = p.H * p.B * p.nsplit;
+
+    struct Item { int h, b, sp, k_begin, nkeys; const unsigned char* K; const unsigned char* V; };
+    auto geometry = [&](int item) {
+        Item it;
+        it.h = item % p.H; it.b = (item / p.H) % p.B; it.sp = item / (p.H * p.B);
+        it.k_begin = it.sp * per_split;
+        it.nkeys = max(0, min(p.Tk, it.k_begin + per_split) - it.k_begin);
+        it.K = (const unsigned char*)p.kv + ((size_t)it.b * p.kv_bstride + ((size_t)(0 * p.H + it.h) * p.Tk) * 64) * ESZ;
+        it.V = (const unsigned char*)p.kv + ((size_t)it.b * p.kv_bstride + ((size_t)(1 * p.H + it.h) * p.Tk) * 64) * ESZ;
+        return it;
+    };
+    // UNR 16-byte loads of this wave's rows r0 .. of one K or V matrix (rows past the end re-read the last row)
+    auto issue = [&](u32x4 (&dst)[UNR], const unsigned char* base, int k_begin, int nkeys, int r0) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int rr = min(r0 + u * RPI + rowi, nkeys - 1);
+            dst[u] = __builtin_nontemporal_load((const u32x4*)(base + ((size_t)(k_begin + rr) * 64 + sub * DPL) * ESZ));
+        }
+        __builtin_amdgcn_sched_barrier(0);     // the requests go out BEFORE the work on the rows already here (the scheduler hoists that work otherwise)
+    };
+
+    // Software pipeline inside each pass: while a wave works on one block of rows (UNR loads), the next block is in flight
+    // in a second register buffer (the buffers swap roles, a copy would have to wait for the prefetch it copies).  The first
+    // K block is requested before the q prologue and the first V block before the softmax, so a workgroup meets the HBM
+    // latency ~3 times per item instead of 24 times -- a persistent launch has only 8 waves per CU to hide it with:
+    // 142 us instead of 174 per launch of 128 utterances (6.9 TB/s).  Nothing is carried across items: that version
+    // (scripts/lab/attn_cross_pipelined.patch) needs 175 VGPRs instead of 92 and is no faster.
+    auto pipeline = [&](u32x4 (&X)[UNR], u32x4 (&Y)[UNR], int nb, auto&& fetch, auto&& consume) {
+        // X holds block 0.  No exit test between the halves of a pair and no branch around a fetch: either leaves a path
+        // on which a buffer "may be pending" and the compiler drains the stream at the loop head.
+        int k = 0;
+        for (; k + 2 < nb; k += 2) {
+            fetch(Y, k + 1);
+            consume(X, k);
+            fetch(X, k + 2);
+            consume(Y, k + 1);
+        }
+        if (nb - k == 2) {
+            fetch(Y, k + 1);
+            consume(X, k);
+            consume(Y, k + 1);
+        } else {
+            consume(X, k);
+        }
+    };
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int h = item % p.H, b = (item / p.H) % p.B, sp = item / (p.H * p.B);
-    const int k_begin = sp * per_split, k_end = min(p.Tk, k_begin + per_split);
-    const int nkeys = max(0, k_end - k_begin);
+    const Item it = geometry(item);
+    const int h = it.h, b = it.b, sp = it.sp, k_begin = it.k_begin, nkeys = it.nkeys;
     if (nkeys == 0) {          // empty split (only possible when nsplit > 1): neutral element
         for (int idx = tid; idx < L * 66; idx += 256) {
             float* w = p.ws + ((((size_t)b * p.H + h) * p.nsplit + sp) * L) * 66;
@@ -262,9 +308,11 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
         }
         continue;
     }
-
-    const unsigned char* K = (const unsigned char*)p.kv + ((size_t)b * p.kv_bstride + ((size_t)(0 * p.H + h) * p.Tk) * 64) * ESZ;
-    const unsigned char* V = (const unsigned char*)p.kv + ((size_t)b * p.kv_bstride + ((size_t)(1 * p.H + h) * p.Tk) * 64) * ESZ;
+    const unsigned char* K = it.K;
+    const unsigned char* V = it.V;
+    const int nb = (nkeys + STRIDE - 1) / STRIDE;         // blocks of this item; every wave takes all of them (rows past the end are clamped, weigh 0)
+    u32x4 bufA[UNR], bufB[UNR];
+    issue(bufA, K, k_begin, nkeys, first);
 
     const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.B * L * p.ldp;
     // ---- q: this lane's DPL dims (sub * DPL .. ) for each of the L tokens -----------------------------
@@ -354,23 +402,19 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     };
 
     // ---- pass 1: scores ---------------------------------------------------------------------------
-    // a wave handles RPI * UNR rows per iteration (UNR loads in flight), the 4 waves stride by 4 * RPI * UNR rows
+    // a wave handles RPI * UNR rows per iteration, the 4 waves stride by 4 * RPI * UNR rows
     float mx[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) mx[i] = -INFINITY;
-    for (int r0 = wid * (RPI * UNR); r0 < nkeys; r0 += 4 * RPI * UNR) {
-        u32x4 kv[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int rr = min(r0 + u * RPI + rowi, nkeys - 1);
-            kv[u] = __builtin_nontemporal_load((const u32x4*)(K + ((size_t)(k_begin + rr) * 64 + sub * DPL) * ESZ));
-        }
+    auto fetch1 = [&](u32x4 (&dst)[UNR], int k) { issue(dst, K, k_begin, nkeys, first + k * STRIDE); };
+    auto consume1 = [&](const u32x4 (&cur)[UNR], int k) {
+        const int r0 = first + k * STRIDE;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int r = r0 + u * RPI + rowi;
             float accs[L];
             if constexpr (I8) {
-                const uint32_t w4[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+                const uint32_t w4[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
 #pragma unroll
                 for (int i = 0; i < L; ++i) accs[i] = 0.f;
 #pragma unroll
@@ -385,7 +429,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
                 }
             } else {
                 float ks[DPL];
-                unpack(kv[u], ks);
+                unpack(cur[u], ks);
 #pragma unroll
                 for (int e = 0; e < DPL; ++e) ks[e] = r16(ks[e] * ATTN_SCALE);
 #pragma unroll
@@ -408,7 +452,9 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
                 }
             }
         }
-    }
+    };
+    pipeline(bufA, bufB, nb, fetch1, consume1);
+    issue(bufA, V, k_begin, nkeys, first);               // first V block: in flight across the softmax
 #pragma unroll
     for (int i = 0; i < L; ++i) {
         const float m = wave_max(mx[i]);
@@ -447,28 +493,32 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     for (int i = 0; i < L; ++i)
 #pragma unroll
         for (int e = 0; e < DPL; ++e) o[i][e] = 0.f;
-    for (int r0 = wid * (RPI * UNR); r0 < nkeys; r0 += 4 * RPI * UNR) {
-        u32x4 vv[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int rr = min(r0 + u * RPI + rowi, nkeys - 1);
-            vv[u] = __builtin_nontemporal_load((const u32x4*)(V + ((size_t)(k_begin + rr) * 64 + sub * DPL) * ESZ));
-        }
+    auto fetch2 = [&](u32x4 (&dst)[UNR], int k) { issue(dst, V, k_begin, nkeys, first + k * STRIDE); };
+    auto consume2 = [&](const u32x4 (&cur)[UNR], int k) {
+        const int r0 = first + k * STRIDE;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int r = r0 + u * RPI + rowi;
-            if (r < nkeys) {
-                float vx[DPL];
-                unpack(vv[u], vx);
+            // no branch around the use of cur[u]: a path that skips it leaves its load pending at the loop head, and the
+            // next prefetch into those registers would have to wait for it (rows past the end weigh 0; their data is the last row's)
+            float vx[DPL];
+            unpack(cur[u], vx);
 #pragma unroll
-                for (int i = 0; i < L; ++i) {
-                    const float pr = s_sc[i][r];
+            for (int i = 0; i < L; ++i) {
+                const float pr = r < nkeys ? s_sc[i][min(r, nkeys - 1)] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < DPL; ++e) o[i][e] += pr * vx[e];
-                }
+                for (int e = 0; e < DPL; ++e) o[i][e] += pr * vx[e];
             }
         }
-    }
+        // pin the accumulators here: pure arithmetic is free to sink below the NEXT prefetch otherwise, which turns the
+        // pipeline into "request two groups, then wait for both"
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) asm volatile("" : "+v"(o[i][e]) : : "memory");
+        }
+    };
+    pipeline(bufA, bufB, nb, fetch2, consume2);
     // reduce over the row-lanes sharing a column group (lane bits above log2(LPR)), then over the 4 waves
 #pragma unroll
     for (int i = 0; i < L; ++i)
@@ -523,8 +573,8 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
     WM_REQUIRE(p.nsplit >= 1 && (p.nsplit == 1 || p.ws != nullptr), "attn_cross: split needs a workspace");
     // Persistent launch for big batches: two workgroups per CU walk over the (head, utterance, split) items instead of
     // one workgroup per item.  The kernel alone is as fast either way (6.3-6.7 TB/s), but with 8 of a CU's 32 wave slots
-    // it leaves room for the OTHER utterance groups' short kernels to be dispatched while it streams: 18.1 instead of
-    // 19.4 ms per decode step at B = 384 (WM_CROSS_PERSIST_WGS overrides the workgroup count, 0 = one per item).
+    // it leaves room for the OTHER utterance group's short kernels to be dispatched while it streams: 13.2 instead of
+    // 13.9 ms per decode step at B = 256 (WM_CROSS_PERSIST_WGS overrides the workgroup count, 0 = one per item).
     static const int persist_env = [] { const char* v = getenv("WM_CROSS_PERSIST_WGS"); return v ? atoi(v) : -1; }();
     static int n_cu = 0;
     if (n_cu == 0) {

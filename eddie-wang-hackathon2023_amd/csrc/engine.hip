@@ -453,7 +453,7 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
     w.x = c.take<h16>(M * C); w.xn = c.take<h16>(M * C); w.ctx = c.take<h16>(M * C); w.hid = c.take<h16>(M * 4 * C);
     // split-K slabs: the widest product is ksplit * N over the six Linears; ksplit <= 24 by construction
     size_t widest = 0;
-    const int Mc = (int)(M < 128 ? M : 128);
+    const int Mc = (int)(M < SKINNY_MAX_M ? M : SKINNY_MAX_M);
     const int q = e->dec.empty() ? (e->w8() ? 1 : 0) : e->dec[0].qkv.wcode;     // every Linear of an engine shares one encoding
     const int Ns[6] = {(int)(3 * C), (int)C, (int)C, (int)C, (int)(4 * C), (int)C};
     const int Ks[6] = {(int)C, (int)C, (int)C, (int)C, (int)C, (int)(4 * C)};
@@ -469,13 +469,13 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
     return w;
 }
 
-// skinny GEMM over all M rows in chunks of 64; slabs laid out [ksplit][M_total][ldp]
+// skinny GEMM over all M rows in chunks of SKINNY_MAX_M; slabs laid out [ksplit][M_total][ldp]
 int skinny_all(const Lin& l, const h16* A, int lda, int M, float* part, int* ksplit_out, hipStream_t s) {
-    const int Mc = M < 128 ? M : 128;
+    const int Mc = M < SKINNY_MAX_M ? M : SKINNY_MAX_M;
     const int ks = skinny_default_ksplit(Mc, l.K, l.n_blocks, l.wcode);
-    for (int r0 = 0; r0 < M; r0 += 128) {
+    for (int r0 = 0; r0 < M; r0 += SKINNY_MAX_M) {
         GemmSkinnyParams p{};
-        p.A = A + (size_t)r0 * lda; p.lda = lda; p.M = (M - r0) < 128 ? (M - r0) : 128; p.K = l.K;
+        p.A = A + (size_t)r0 * lda; p.lda = lda; p.M = (M - r0) < SKINNY_MAX_M ? (M - r0) : SKINNY_MAX_M; p.K = l.K;
         p.Wt = l.w; p.n_blocks = l.n_blocks; p.w8 = l.wcode; p.scale = l.s; p.ksplit = ks;
         p.part = part + (size_t)r0 * l.N; p.part_sstride = (long)M * l.N;
         if (launch_gemm_skinny(p, s)) return 2;
@@ -594,9 +594,9 @@ struct GroupStep {
     // logits = ln(x) . E^T (fp16 out, whisper/model.py:288-290)
     int end(hipStream_t s) {
         const wm_dims& d = e->dims;
-        for (int r0 = 0; r0 < M; r0 += 128) {
+        for (int r0 = 0; r0 < M; r0 += SKINNY_MAX_M) {
             GemmSkinnyParams p{};
-            p.A = w.xn + (size_t)r0 * C; p.lda = C; p.M = (M - r0) < 128 ? (M - r0) : 128; p.K = C;
+            p.A = w.xn + (size_t)r0 * C; p.lda = C; p.M = (M - r0) < SKINNY_MAX_M ? (M - r0) : SKINNY_MAX_M; p.K = C;
             p.Wt = e->emb_t; p.n_blocks = e->emb_blocks; p.w8 = 0; p.ksplit = 1;
             p.out = (h16*)io->logits + (size_t)r0 * d.n_vocab; p.ldc = d.n_vocab; p.n_valid = d.n_vocab;
             if (launch_gemm_skinny(p, s)) return 2;

@@ -182,7 +182,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
     }
 }
 
-constexpr int SKINNY_MAX_M = 128;   // rows per launch
 
 static inline int skinny_kt(int w8) { return w8 == 4 ? 128 : (w8 ? 64 : 32); }    // w8: 0 fp16, 1 int8, 4 packed int4
 
@@ -197,11 +196,14 @@ int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
     s = min(s, max(1, kt_total / min_tiles));
     // the fp32 slabs (s * rows * N * 4 B) are written and re-read through L2 / Infinity Cache: keep them under
     // ~16 MB at the largest row count a launch takes, so that they stay on-die
-    const long slab = (long)SKINNY_MAX_M * n_blocks * 16 * 4;
+    const long slab = 128L * n_blocks * 16 * 4;          // sized for 128 rows whatever the launch takes: the split must not depend on M
     s = min(s, (int)max(1L, (16L << 20) / slab));
-    // every slab is re-read by the row kernel (and its latency chain grows with the slab count);
-    // measured (scripts/bench_skinny.py): 8 slices are already at the latency floor for every decode shape
-    s = min(s, 8);
+    // every slab is written and re-read (by the row kernel) as fp32: with 8 slices that is 115 MB per layer for 128 rows,
+    // 12 % of what the cross-attention kernel streams -- and next to that kernel the chain of short kernels is
+    // throughput-bound, not latency-bound.  4 slices: 26.0 instead of 26.9 ms per decode step at B = 576 (8 are 5 % faster
+    // for a kernel running alone, scripts/bench_skinny.py).  WM_KSPLIT_CAP overrides (experiments).
+    static const int cap_env = [] { const char* v = getenv("WM_KSPLIT_CAP"); return v ? atoi(v) : 4; }();
+    s = min(s, cap_env);
     return max(1, s);
 }
 
@@ -215,7 +217,9 @@ static int launch_mt(const GemmSkinnyParams& p, hipStream_t stream) {
         case 3: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 3, 8>), dim3(g8), dim3(512), 0, stream, p); break;
         case 4: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 4, 8>), dim3(g8), dim3(512), 0, stream, p); break;
         case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 6, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 8, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        case 7: case 8: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 8, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        case 9: case 10: case 11: case 12: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 12, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 16, 8>), dim3(g8), dim3(512), 0, stream, p); break;
     }
     return 0;
 }

@@ -37,6 +37,7 @@ struct GemmSkinnyParams {
     long part_sstride;                       // elements between K-slice slabs (0: M * n_blocks * 16)
     h16* out; int ldc; int n_valid;          // direct fp16 output instead of partials (ksplit == 1)
 };
+constexpr int SKINNY_MAX_M = 256;   // rows per launch of the weight-streaming GEMM (16 MFMA row tiles)
 int launch_gemm_skinny(const GemmSkinnyParams& p, hipStream_t stream);
 int skinny_default_ksplit(int M, int K, int n_blocks, int w8);
 

@@ -151,7 +151,7 @@ int wm_step_advance(int32_t* counter, wm_stream_t stream);
 int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, const void* scale,
             const void* bias, const void* residual, int ldr, int act, void* C, int ldc,
             wm_stream_t stream);
-/* Weight-streaming GEMM, M <= 128, W in tile-linear layout (weight.py: tile_linear*).  w8: 0 = fp16
+/* Weight-streaming GEMM, M <= 256, W in tile-linear layout (weight.py: tile_linear*).  w8: 0 = fp16
  * tiles, 1 = int8 tiles, 4 = packed int4 tiles (tile_linear_int4; K a multiple of 128).  `part` must
  * hold ksplit*M*n_blocks*16 floats; result[m][n] = sum_s part[s][m][n].  Replaces
  * weight_only_gemv_launcher (weightOnlyMatrixVectorMultiplication.cu:136-277,371-378).             */

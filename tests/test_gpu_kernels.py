@@ -122,6 +122,9 @@ def _run_skinny(lib, A, Wmat, w8, ksplit):
     # packed int4 tiles (K a multiple of 128): M = 1 GEMV, ragged N, every MT variant, split-K
     (1, 272, 384, 4, 1), (3, 272, 384, 4, 3), (17, 128, 1280, 4, 5), (40, 1280, 1280, 4, 2), (64, 3840, 1280, 4, 10),
     (90, 1280, 5120, 4, 8), (128, 5120, 1280, 4, 6),
+    # 9 .. 16 row tiles per launch (decode groups of up to 256 utterances)
+    (130, 1280, 1280, 1, 8), (192, 3840, 1280, 1, 8), (256, 1280, 5120, 1, 8), (200, 272, 256, 0, 2), (256, 1280, 1280, 0, 4),
+    (256, 5120, 1280, 4, 6), (177, 1280, 1280, 4, 5),
 ])
 def test_gemm_skinny(lib, M, N, K, w8, ksplit):
     r = rng(M * 7 + N + K + w8)
