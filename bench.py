@@ -228,17 +228,16 @@ def main():
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4),
                         # HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE x 1024 x 2,
-                        # the gfx950 correction for 16 B/lane streaming reads): 7,686,228 B per utterance-layer
-                        "traffic": (group * 7686228 if kv_bytes == 2 else None), "traffic_source": "profiles/r1h_pmc_cross_attn.txt",
+                        # the gfx950 correction for 16 B/lane streaming reads): 7,686,860 B per utterance-layer
+                        "traffic": (group * 7686860 if kv_bytes == 2 else None), "traffic_source": "profiles/r1j_pmc_cross_attn.txt",
                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5),
                         "samples": int(cnt.value), "utterances_per_launch": group,
                         "note": "HIP events around the eager (language-ID pass) launches of the kernel inside the timed "
                                 "steps, the utterance groups taking turns for that pass so that the kernel has the HBM to "
                                 "itself as it does under rocprofv3 (profiles/*_kernel_stats.csv: same average); the captured "
                                 f"decode graphs replay the same kernel and grid, there {n_micro} groups share the HBM.  The launch is "
-                                "persistent (2 workgroups per CU): with one workgroup per (utterance, head) the kernel alone "
-                                "reads 6.6 TB/s (0.83, profiles/r1e) but crowds out the other groups' short kernels; the "
-                                "persistent launch is slower alone and 3-7 % faster for the whole step"}
+                                "persistent (<= 2 workgroups per CU, every workgroup the same number of items) and software-"
+                                "pipelined: with 8 of a CU's 32 wave slots it leaves room for the other groups' short kernels"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -585,7 +585,14 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int n_items = p.H * p.B * p.nsplit;
-    int persist_wgs = persist_env >= 0 ? persist_env : (n_items >= 4 * n_cu ? 2 * n_cu : 0);
+    // default: at most 2 workgroups per CU, and every workgroup the same number of items (3840 items on 512 workgroups
+    // would be 8 for some and 7 for the rest: the launch ends with half the chip idle; 480 x 8 does not)
+    int persist_wgs = 0;
+    if (persist_env >= 0) persist_wgs = persist_env;
+    else if (n_items >= 4 * n_cu) {
+        const int per = (n_items + 2 * n_cu - 1) / (2 * n_cu);
+        persist_wgs = (n_items + per - 1) / per;
+    }
     dim3 grid(persist_wgs > 0 && persist_wgs < n_items ? persist_wgs : n_items);
     if (p.kv_q8_scale > 0.f) {                                   // int8 cross K/V (opt-in)
         switch (p.L) {
