@@ -135,6 +135,51 @@ def test_gemm_skinny(lib, M, N, K, w8, ksplit):
     assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("w8", [0, 1, 4])
+def test_gemm_skinny_rows_do_not_depend_on_the_launch(lib, w8):
+    """A row's slabs are the same bits whether it is computed alone (1 MFMA row tile, 4 waves), in a group of 40 or of 130
+    (6 / 12 tiles) or of 256 (16 tiles, 70 KB of LDS): the variants differ in schedule, never in arithmetic.  This is
+    what lets the decode loop choose its group size freely."""
+    r = rng(91 + w8)
+    K, N, ksplit = 1280, 1280, 4
+    A = (r.standard_normal((256, K)) * 0.5).astype(np.float16)
+    Wf = (r.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    if w8 == 4:
+        q, s = symmetric_quantize_int4(Wf); tiles = W.tile_linear_int4(q)
+    elif w8:
+        q, s = symmetric_quantize_int8(Wf); tiles = W.tile_linear(q)
+    else:
+        s, tiles = None, W.tile_linear(Wf)
+    t_dev, s_dev = dev(tiles.view(np.uint8)), (dev(s) if s is not None else None)
+    a_dev = dev(A)
+    def run(M):
+        part = torch.zeros((ksplit, M, N), dtype=torch.float32, device="cuda")
+        native.check(lib.wm_gemm_skinny(a_dev.data_ptr(), K, M, K, t_dev.data_ptr(), N // 16, w8,
+                                        s_dev.data_ptr() if s_dev is not None else None, ksplit, part.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        return part
+    full = run(256)
+    for M in (1, 3, 40, 100, 130, 200):
+        assert torch.equal(run(M), full[:, :M]), M
+
+
+def test_attn_decode_cross_rows_do_not_depend_on_the_launch(lib):
+    """One workgroup per (utterance, head) for 12 utterances, the persistent balanced launch for 64: same bits per row."""
+    r = rng(123)
+    H, Tk = 20, 1500
+    q = r.standard_normal((64, H * 64)).astype(np.float32)
+    kv = torch.from_numpy(r.standard_normal((64, 2, H, Tk, 64)).astype(np.float16)).cuda()
+    qd = dev(q)
+    def run(B):
+        out = torch.zeros((B, H * 64), dtype=torch.float16, device="cuda")
+        native.check(lib.wm_attn_decode_cross(qd.data_ptr(), B, 1, H, Tk, kv.data_ptr(), out.data_ptr(), 1, None, stream()))
+        torch.cuda.synchronize()
+        return out
+    big = run(64)                                                     # 1280 items >= 4 per CU: persistent
+    assert torch.equal(run(12), big[:12])                             # 240 items: one workgroup each
+    assert len({tuple(row) for row in big[:4].float().cpu().numpy().round(3).tolist()}) > 1
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1024, 4096), (64, 1536, 4096)])
 def test_weight_only_matmul_reference_spec(lib, M, N, K):
     """The reference's own known-answer test (test_weight_only_quant_matmul.py:94-119): uniform

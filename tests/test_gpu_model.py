@@ -391,6 +391,38 @@ def test_micro_batched_streams_give_identical_tokens(tmpdir_module):
     assert len({tuple(r) for r in t1.cpu().tolist()}) > 1          # rows differ: the test is not vacuous
 
 
+def test_big_batch_rows_equal_smaller_batch_rows(tmpdir_module):
+    """The big-batch machinery -- three groups on hardware queues of their own, GEMM launches of 256 rows in two chunks
+    per group, the persistent balanced cross-attention launch -- gives every utterance the tokens AND the log-probabilities
+    it gets in a batch half the size (one chunk per group, one workgroup per cross-attention item), bit for bit.
+    (Both batches are big enough for the single-pass cross-attention: below 512 (utterance, head) items per group the
+    key range is split over several workgroups and the softmax is combined from partial results, which rounds differently
+    in the last bit -- the one place where a row's arithmetic depends on the size of the group it is in.)"""
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3, weight_only=True, int8_kv=True,
+                       kv_scales=[0.05] * dims.n_text_layer)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    dec.sample_len = 8
+    per_group = 1024 // dims.n_text_head                                # persistent launch from 1024 items per group on
+    n = 3 * per_group
+    mel = synthetic_mel(24, 2 * dims.n_audio_ctx, dims.n_mels, 77).cuda().repeat(n // 24, 1, 1)     # 24 distinct clips
+    xa = enc.get_audio_features(mel)
+    assert torch.equal(xa[:24], xa[n - 24:])                            # encoder: a row does not see its batch
+    dec.detect_language(xa)
+    assert dec._groups(n)[0] == 3
+    t_big, lp_big, _ = dec.main_loop(xa)
+    half = WhisperDecoding(eng)
+    half.sample_len = 8
+    xh = xa[:n // 2].contiguous()
+    half.detect_language(xh)
+    t_half, lp_half, _ = half.main_loop(xh)
+    w = min(t_big.shape[1], t_half.shape[1])
+    for lo in (0, n // 2 - n // 2 % 24, n - 24):                         # rows of the first, the middle and the last group
+        assert torch.equal(t_big[lo:lo + 24, :w].cpu(), t_half[:24, :w].cpu())
+        assert torch.equal(lp_big[lo:lo + 24].cpu(), lp_half[:24].cpu())
+    assert len({tuple(r) for r in t_half[:24].cpu().tolist()}) > 1
+
+
 @pytest.mark.parametrize("n_groups,int8", [(2, False), (2, True), (3, True)])
 def test_cu_partitioned_schedule_gives_identical_tokens(tmpdir_module, n_groups, int8):
     """wm_decoder_step_multi (cross-attention on its own CU set, short kernels on CU-masked streams, eager,
