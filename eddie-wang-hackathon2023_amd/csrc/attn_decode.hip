@@ -240,7 +240,12 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     constexpr int LPR = 64 / DPL;                        // lanes per row: 8 (fp16) / 4 (int8)
     constexpr int RPI = 64 / LPR;                        // rows per wave-instruction: 8 / 16
     constexpr int ESZ = I8 ? 1 : 2;                      // bytes per stored element
-    constexpr int UNR = 4;     // loads per block; two blocks are in flight (see `pipeline`)
+#ifndef CROSS_UNR
+#define CROSS_UNR 4
+#endif
+    // loads per block; two blocks are in flight (see `pipeline`).  2 / 3 / 4 / 6: 6.52 / 6.74 / 6.88 / 6.46 TB/s alone,
+    // 24.9 / 25.1 / 25.4 / 26.4 ms per decode step at B = 576 (a gentler stream costs the other groups' chains less)
+    constexpr int UNR = CROSS_UNR;
     __shared__ float s_sc[L][CROSS_MAX_KEYS];
     __shared__ float s_red[L][4][2];
     __shared__ float s_o[4][L][64];
