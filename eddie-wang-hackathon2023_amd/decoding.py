@@ -254,6 +254,7 @@ class WhisperDecoding:
         self._partition = None            # (light streams, heavy stream), created on first use
         self.use_graphs = True            # replay one captured decode step per token (hipGraph)
         self._streams = []
+        self._no_dedicated_queues = False
 
     # ---- configuration / sessions -----------------------------------------------------------------
     def get_config(self, engine_dir):
@@ -579,10 +580,14 @@ class WhisperDecoding:
         created before.  Measured (B = 384, three groups): 18.1 ms per decode step with a queue per group, 23.5 ms when
         two groups happen to share one -- e.g. in any process that used one more stream earlier (RCCL, a calibration
         pass).  WM_DEDICATED_QUEUES=0 falls back to torch's stream pool."""
-        if os.environ.get("WM_DEDICATED_QUEUES", "1") != "0":
+        if os.environ.get("WM_DEDICATED_QUEUES", "1") != "0" and not self._no_dedicated_queues:
             n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-            with torch.cuda.device(dev):
-                return [native.create_masked_stream([True] * n_cu, k) for k in range(n)]
+            try:
+                with torch.cuda.device(dev):
+                    return [native.create_masked_stream([True] * n_cu, k) for k in range(n)]
+            except native.WmError as e:       # a scheduling nicety, not part of the compute path: fall back to pooled streams
+                logger.warning("dedicated hardware queues unavailable (%s): utterance groups use pooled streams", e)
+                self._no_dedicated_queues = True
         while len(self._streams) < n:
             self._streams.append(torch.cuda.Stream(device=dev))
         return self._streams[:n]
