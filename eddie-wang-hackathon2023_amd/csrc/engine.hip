@@ -499,6 +499,15 @@ size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new) {
 namespace {
 // One utterance group's decode step, cut into the phases between which the cross-attention kernel sits, so
 // that several groups can be interleaved layer by layer (wm_decoder_step_multi).
+// diagnostic timeline (wm_debug_timeline)
+long long* g_timeline = nullptr;
+int g_timeline_cap = 0;
+__global__ void stamp_kernel(long long* tl, int cap, long long tag, long long what) {
+    if (threadIdx.x != 0) return;
+    const int i = atomicAdd((int*)tl, 1);
+    if (i < cap) { tl[1 + 3 * i] = tag; tl[2 + 3 * i] = what; tl[3 + 3 * i] = wall_clock64(); }
+}
+
 struct GroupStep {
     const wm_engine* e; const wm_decoder_io* io; DecWs w;
     int B, L, T, C, H, M;
@@ -563,6 +572,14 @@ struct GroupStep {
 
     // the HBM-bound kernel: K and V of every utterance of the group, once
     int cross(int i, hipStream_t s) {
+        if (!g_timeline) return cross_launch(i, s);
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, g_timeline, g_timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i));
+        const int rc = cross_launch(i, s);
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, g_timeline, g_timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i + 1));
+        return rc;
+    }
+
+    int cross_launch(int i, hipStream_t s) {
         const DecLayer& Lr = e->dec[i];
         const wm_dims& d = e->dims;
         AttnCrossParams p{};
@@ -717,6 +734,12 @@ int wm_profile_configure(int enabled, int layer_stride, int max_samples) {
         WM_CHECK_HIP(hipEventCreate(&g_prof.stop[i]));
     }
     g_prof.enabled = true;
+    return 0;
+}
+
+int wm_debug_timeline(void* buf, int capacity) {
+    g_timeline = (long long*)buf;
+    g_timeline_cap = buf ? capacity : 0;
     return 0;
 }
 

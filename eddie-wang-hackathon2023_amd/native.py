@@ -21,7 +21,7 @@ EXPORTS = (
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
     "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
-    "wm_flac_info", "wm_flac_decode", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8",
+    "wm_flac_info", "wm_flac_decode", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
 )
 
 
@@ -128,6 +128,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_flac_info.argtypes = [vp, sz, C.POINTER(WmFlacStreamInfo)]
     lib.wm_flac_decode.argtypes = [vp, sz, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.wm_step_advance.argtypes = [vp, vp]
+    lib.wm_debug_timeline.argtypes = [vp, i32]
     lib.wm_profile_configure.argtypes = [i32, i32, i32]
     lib.wm_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     _lib = lib

@@ -210,6 +210,11 @@ int wm_flac_decode(const void* data, size_t bytes, int32_t* pcm, int64_t capacit
  * off by default, not thread-safe (one host thread per GPU).                                        */
 int wm_profile_configure(int enabled, int layer_stride, int max_samples);
 int wm_profile_read(double* total_ms, int64_t* count, int reset);
+/* Diagnostic: a device-side timeline of the decode step.  `buf` = int64 [1 + 3 * capacity] device words (NULL switches it
+ * off): word 0 counts entries, entry i = {group tag (the step's logits pointer), 2 * layer + (0 = before, 1 = after the
+ * cross-attention launch), wall clock (100 MHz)}, written by 1-thread kernels on the step's stream (graph-capturable; each
+ * costs a launch, so the timeline perturbs what it shows by a few us per layer).  scripts/timeline_probe.py draws it. */
+int wm_debug_timeline(void* buf, int capacity);
 
 #ifdef __cplusplus
 }

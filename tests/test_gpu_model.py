@@ -720,6 +720,35 @@ def test_summarize_pipeline_on_flac(tmpdir_module, golden_dir, tmp_path):
     np.testing.assert_allclose(dev.numpy(), wu.log_mel_spectrogram(audio).numpy(), atol=5e-4)
 
 
+def test_debug_timeline_records_the_cross_attention_launches(tmpdir_module):
+    """wm_debug_timeline: two stamps per layer per decoder call, clocks in order, tokens unchanged by the stamps."""
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    dec.sample_len = 4
+    xa = enc.get_audio_features(synthetic_mel(4, 2 * dims.n_audio_ctx, dims.n_mels, 9).cuda())
+    dec.detect_language(xa)
+    t0, _, _ = dec.main_loop(xa)
+    lib = native.load_library()
+    cap = 4096
+    buf = torch.zeros(1 + 3 * cap, dtype=torch.int64, device="cuda")
+    native.check(lib.wm_debug_timeline(buf.data_ptr(), cap))
+    try:
+        probe = WhisperDecoding(eng)                       # fresh graphs: the stamps are captured with them
+        probe.sample_len = 4
+        probe.tokens = dec.tokens.clone()
+        t1, _, _ = probe.main_loop(xa)
+        torch.cuda.synchronize()
+    finally:
+        native.check(lib.wm_debug_timeline(None, 0))
+    n = int(buf[0].item()) & 0xffffffff
+    ev = buf[1:1 + 3 * n].view(-1, 3).cpu().numpy()
+    assert n > 0 and n % (2 * dims.n_text_layer) == 0
+    assert set(ev[:, 1].tolist()) == set(range(2 * dims.n_text_layer))
+    assert (np.diff(ev[:, 2]) >= 0).all()                  # one group, one stream: stamps in program order
+    assert torch.equal(t0.cpu(), t1.cpu())
+
+
 def test_empty_and_invalid_calls_fail_cleanly(tmpdir_module):
     """Empty batches, undersized workspaces and out-of-range lengths come back as errors with a message (the C ABI
     never aborts and never touches memory for them); the session layer turns them into exceptions / False."""
