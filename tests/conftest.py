@@ -18,6 +18,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The C-ABI library is built in-tree (git-ignored); a fresh checkout builds it once before the first test
+    (hipcc cross-compiles gfx950 without a GPU), exactly as __graft_entry__.build() does."""
+    if not os.path.exists(os.path.join(PKG, "libwhisper_mi355.so")):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
