@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int rr = min(r0 + u * RPI + rowi, nkeys - 1);
+            // non-temporal: with plain loads the kernel reads 5.9 instead of 6.6 TB/s alone and the decode step takes 27.3 instead of 25.3 ms
             dst[u] = __builtin_nontemporal_load((const u32x4*)(base + ((size_t)(k_begin + rr) * 64 + sub * DPL) * ESZ));
         }
         __builtin_amdgcn_sched_barrier(0);     // the requests go out BEFORE the work on the rows already here (the scheduler hoists that work otherwise)
