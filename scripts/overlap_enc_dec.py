@@ -33,16 +33,23 @@ def wall(f):
     torch.cuda.synchronize(); t = time.perf_counter(); f(); torch.cuda.synchronize(); return (time.perf_counter() - t) * 1e3
 ta = wall(lambda: stage_a(0)); tb = wall(lambda: stage_b(1))
 print(f"B={B} T={T}: stage A (encoder + cross-KV + lang-id) alone {ta:.1f} ms, stage B (decode loop) alone {tb:.1f} ms, sum {ta+tb:.1f}")
-for prio in (False, True):
-    se = torch.cuda.Stream(priority=0) if not prio else torch.cuda.Stream(priority=0)
-    if prio:
-        for d in decs:
-            d._streams = [torch.cuda.Stream(priority=-1) for _ in range(2)]   # decode groups on high-priority streams
-            d._state.clear()
-        for i in (0, 1): stage_a(i); stage_b(i)
-        torch.cuda.synchronize()
+import native
+n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+masks = {"all CUs": [True] * n_cu,
+         "encoder on CUs 0..127": [i < 128 for i in range(n_cu)], "encoder on CUs 0..159": [i < 160 for i in range(n_cu)],
+         "encoder on 16 of every 32": [(i % 32) < 16 for i in range(n_cu)], "encoder on 24 of every 32": [(i % 32) < 24 for i in range(n_cu)]}
+for k, (name, mask) in enumerate(masks.items()):
+    se = native.create_masked_stream(mask, 5 + k)               # a queue of its own, confined to the mask
+    stage_a(0, se)                                             # warm
+    torch.cuda.synchronize()
+    ta_m = wall(lambda: stage_a(0, se))
+    sb = torch.cuda.Stream()          # NOT the legacy default stream: it synchronises implicitly with every blocking stream (the masked ones are)
     def both():
         th = threading.Thread(target=stage_a, args=(0, se))
-        th.start(); stage_b(1); th.join()
+        th.start()
+        with torch.cuda.stream(sb):
+            stage_b(1)
+        th.join()
+    both(); torch.cuda.synchronize()
     t = wall(both)
-    print(f"  concurrent (decode streams high-priority={prio}): {t:.1f} ms  -> overlap saves {ta+tb-t:.1f} ms")
+    print(f"  {name}: stage A alone on that stream {ta_m:.1f} ms; A and B together {t:.1f} ms (A alone + B alone = {ta_m + tb:.1f}, full-chip sum {ta + tb:.1f})", flush=True)
