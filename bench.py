@@ -142,12 +142,46 @@ def cpu_baseline(args, decode_steps: int):
     }
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as FRESH child processes (one per GPU) through
+    torch.distributed.run and relay rank 0's JSON line.  Nothing in this process has touched the GPU yet
+    (torch.cuda.device_count() does not initialise it on this image), and the children are started with subprocess,
+    never exec'ed from a GPU-initialised process."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node shows {n_dev} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in proc.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if proc.returncode == 0 and lines:
+        print(lines[-1], flush=True)
+        return 0
+    print(f"bench.py: the {args.gpus}-rank job failed (rc={proc.returncode})", file=sys.stderr)
+    return proc.returncode or 1
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a different GPU count", file=sys.stderr)
+        sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; before anything initialises the GPU
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     torch.cuda.set_device(local_rank)

@@ -25,6 +25,8 @@
 //   softmax is the exact two-pass one (no online rescaling), then V is streamed the same way.
 #include <hip/hip_ext.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -582,13 +584,17 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
     // it leaves room for the OTHER utterance group's short kernels to be dispatched while it streams: 13.2 instead of
     // 13.9 ms per decode step at B = 256 (WM_CROSS_PERSIST_WGS overrides the workgroup count, 0 = one per item).
     static const int persist_env = [] { const char* v = getenv("WM_CROSS_PERSIST_WGS"); return v ? atoi(v) : -1; }();
-    static int n_cu = 0;
+    // CU count of the device this launch goes to, cached per device (a process may drive several GPUs from several threads)
+    static std::atomic<int> n_cu_dev[64];
+    int dev = 0;
+    WM_CHECK_HIP(hipGetDevice(&dev));
+    const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+    int n_cu = n_cu_dev[slot].load(std::memory_order_relaxed);
     if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        WM_CHECK_HIP(hipGetDevice(&dev));
-        WM_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int v = 0;
+        WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+        n_cu_dev[slot].store(n_cu, std::memory_order_relaxed);
     }
     const int n_items = p.H * p.B * p.nsplit;
     // default: at most 2 workgroups per CU, and every workgroup the same number of items (3840 items on 512 workgroups

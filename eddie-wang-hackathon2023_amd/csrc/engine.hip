@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,8 @@ int post_launch_check(hipStream_t s, const char* what) {
     static int sync_check = -1;
     if (sync_check < 0) { const char* v = getenv("WM_SYNC_CHECK"); sync_check = (v && v[0] == '1') ? 1 : 0; }
     if (sync_check) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;       // a synchronise would invalidate a capture in progress
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) { set_error("kernel %s faulted: %s", what, hipGetErrorString(e)); return 2; }
     }
@@ -80,10 +83,30 @@ struct DecLayer {
 
 using namespace wm;
 
+namespace wm {
+// events that order a group's light stream against the shared heavy stream (wm_decoder_step_multi):
+// [group][layer][0: q ready, 1: ctx ready].  Owned by the engine, i.e. created on the engine's device; the mutex
+// makes concurrent calls on one engine (threads driving different streams) safe.
+struct EventPool {
+    std::mutex mu;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t get(size_t idx) {
+        std::lock_guard<std::mutex> lock(mu);
+        while (ev.size() <= idx) {
+            hipEvent_t x = nullptr;
+            if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ev.push_back(x);
+        }
+        return ev[idx];
+    }
+    ~EventPool() { for (hipEvent_t x : ev) (void)hipEventDestroy(x); }
+};
+}  // namespace wm
+
 struct wm_engine {
     int kind = 0; uint32_t flags = 0; wm_dims dims{}; int device = 0;
+    mutable wm::EventPool events;
     unsigned char* dev = nullptr; size_t dev_bytes = 0;
-    std::vector<void*> expanded;               // fp16 expansions of int8 row-major weights (big-M GEMMs)
     std::map<std::string, Tensor> t;
     std::map<std::string, float> scalars;      // host copies of 4-byte fp32 tensors (kv scales)
     // encoder
@@ -118,7 +141,9 @@ int get_lin(const wm_engine* e, const std::string& base, bool tiled, bool quanti
     Tensor w, s, b;
     if (find(e, base + (tiled ? ".t" : ".w"), &w)) return 1;
     l->w = w.ptr;
-    const bool q = quantisable && e->w8();
+    // row-major (non-tiled) matrices belong to the M >> 16 stages: a weight-only blob's int8 copies of them were
+    // expanded to fp16 while the engine was created (upload_expanding), so only tiled matrices are still quantised
+    const bool q = quantisable && e->w8() && tiled;
     const bool packed4 = w.dtype == 4;
     if ((w.dtype == 1 || packed4) != q || (packed4 && !tiled)) {
         set_error("tensor %s: dtype does not match the engine's weight-only flag", base.c_str());
@@ -210,28 +235,78 @@ int resolve(wm_engine* e) {
     return 0;
 }
 
-// Weight-only engines: the M >> 16 stages are MFMA-bound, so their int8 [N][K] matrices are expanded
-// once to fp16(fp16(q) * scale) (the reference kernels' per-element dequantisation) and the fp16
-// GEMM serves both precisions.  Costs N*K*2 bytes of the 288 GB; the blob on disk stays int8.
-int expand_lin(wm_engine* e, Lin* l) {
-    if (!l->s) return 0;
-    void* buf = nullptr;
-    WM_CHECK_HIP(hipMalloc(&buf, (size_t)l->N * l->K * sizeof(h16)));
-    e->expanded.push_back(buf);
-    if (launch_dequant_w8((const int8_t*)l->w, l->s, (h16*)buf, l->N, l->K, 0)) return 2;
-    l->w = buf; l->s = nullptr;
-    return 0;
-}
-int expand_row_major_int8(wm_engine* e) {
-    for (auto& L : e->enc)
-        if (expand_lin(e, &L.qkv) || expand_lin(e, &L.out) || expand_lin(e, &L.mlp1) || expand_lin(e, &L.mlp2)) return 2;
-    for (auto& l : e->ckv)
-        if (expand_lin(e, &l)) return 2;
-    WM_CHECK_HIP(hipDeviceSynchronize());
-    return 0;
-}
-
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Device residency of a blob's tensors.  Decoder engines (tile-linear weights, streamed as stored) and fp16
+// engines: one allocation, one copy.  Weight-only ENCODER / CROSS-K/V engines: their row-major int8 matrices feed
+// MFMA-bound GEMMs (M = 1500 x batch), which multiply fp16(fp16(q) * scale) -- the reference kernels' per-element
+// dequantisation -- so each is expanded ONCE, here, and only the expansion stays resident: the blob is staged in a
+// temporary buffer, every other tensor is copied next to the expansions, the int8 codes and their scales are dropped.
+// (Round 1 kept both copies: a weight-only encoder then held MORE memory than an fp16 one.)
+int upload(wm_engine* e, const BlobHeader* h, const BlobTensor* tt, const unsigned char* data) {
+    auto name_of = [&](uint32_t i) { char nm[65]; memcpy(nm, tt[i].name, 64); nm[64] = 0; return std::string(nm); };
+    const bool expanding = (e->kind == WM_ENGINE_ENCODER || e->kind == WM_ENGINE_CROSS_KV) && (e->flags & WM_FLAG_WEIGHT_ONLY_INT8);
+    if (!expanding) {
+        WM_CHECK_HIP(hipMalloc((void**)&e->dev, h->data_bytes ? h->data_bytes : 256));
+        WM_CHECK_HIP(hipMemcpy(e->dev, data, h->data_bytes, hipMemcpyHostToDevice));
+        e->dev_bytes = h->data_bytes;
+        for (uint32_t i = 0; i < h->n_tensors; ++i) {
+            Tensor t;
+            t.ptr = e->dev + tt[i].offset; t.dtype = tt[i].dtype; t.nbytes = tt[i].nbytes;
+            memcpy(t.shape, tt[i].shape, sizeof(t.shape));
+            e->t[name_of(i)] = t;
+        }
+        return 0;
+    }
+    std::map<std::string, uint32_t> index;
+    for (uint32_t i = 0; i < h->n_tensors; ++i) index[name_of(i)] = i;
+    auto is_code = [&](uint32_t i) { return tt[i].dtype == 1 && tt[i].ndim == 2; };
+    auto scale_of = [&](const std::string& w_name) {          // "x.w" -> index of "x.s", or -1
+        auto it = index.find(w_name.substr(0, w_name.size() - 2) + ".s");
+        return it == index.end() ? -1 : (int)it->second;
+    };
+    std::vector<char> dropped(h->n_tensors, 0);
+    std::vector<size_t> new_off(h->n_tensors, 0);
+    for (uint32_t i = 0; i < h->n_tensors; ++i)
+        if (is_code(i)) {
+            const std::string nm = name_of(i);
+            const int si = nm.size() > 2 && nm.compare(nm.size() - 2, 2, ".w") == 0 ? scale_of(nm) : -1;
+            WM_REQUIRE(si >= 0, "weight-only tensor %s has no scales", nm.c_str());
+            dropped[si] = 1;
+        }
+    size_t total = 0;
+    for (uint32_t i = 0; i < h->n_tensors; ++i) {
+        if (dropped[i]) continue;
+        new_off[i] = total;
+        total = align_up(total + (is_code(i) ? tt[i].nbytes * sizeof(h16) : tt[i].nbytes));
+    }
+    unsigned char* stage = nullptr;
+    WM_CHECK_HIP(hipMalloc((void**)&e->dev, total ? total : 256));
+    hipError_t err = hipMalloc((void**)&stage, h->data_bytes ? h->data_bytes : 256);
+    if (err == hipSuccess) err = hipMemcpy(stage, data, h->data_bytes, hipMemcpyHostToDevice);
+    int rc = 0;
+    for (uint32_t i = 0; i < h->n_tensors && err == hipSuccess && rc == 0; ++i) {
+        if (dropped[i]) continue;
+        Tensor t;
+        t.ptr = e->dev + new_off[i]; t.dtype = tt[i].dtype; t.nbytes = tt[i].nbytes;
+        memcpy(t.shape, tt[i].shape, sizeof(t.shape));
+        if (is_code(i)) {
+            const int si = scale_of(name_of(i));
+            rc = launch_dequant_w8((const int8_t*)(stage + tt[i].offset), (const h16*)(stage + tt[si].offset), (h16*)(e->dev + new_off[i]),
+                                   (int)tt[i].shape[0], (int)tt[i].shape[1], 0);
+            t.dtype = 0; t.nbytes = tt[i].nbytes * sizeof(h16);
+        } else {
+            err = hipMemcpy(e->dev + new_off[i], stage + tt[i].offset, tt[i].nbytes, hipMemcpyDeviceToDevice);
+        }
+        e->t[name_of(i)] = t;
+    }
+    if (err == hipSuccess && rc == 0) err = hipDeviceSynchronize();
+    if (stage) (void)hipFree(stage);
+    if (rc) return rc;
+    WM_CHECK_HIP(err);
+    e->dev_bytes = total;
+    return 0;
+}
 
 struct Carver {            // bump allocator over the caller's workspace
     unsigned char* base; size_t cap; size_t off = 0;
@@ -265,10 +340,11 @@ int big(const Lin& l, const wm_engine* e, const h16* A, int lda, int M, h16* Cou
         const h16* residual, int ldr, hipStream_t s, GemmBigParams* custom = nullptr) {
     GemmBigParams p{};
     if (custom) p = *custom;
-    p.A = A; p.lda = lda; p.M = M; p.K = l.K; p.W = l.w; p.N = l.N; p.w8 = l.s != nullptr;
-    p.scale = l.s; p.bias = l.b; p.C = Cout; p.ldc = ldc; p.act = act;
+    WM_REQUIRE(l.s == nullptr, "big GEMM: int8 weights must have been expanded at engine creation");
+    p.A = A; p.lda = lda; p.M = M; p.K = l.K; p.W = l.w; p.N = l.N;
+    p.bias = l.b; p.C = Cout; p.ldc = ldc; p.act = act;
     if (!custom) { p.residual = residual; p.ldr = ldr; }
-    return p.w8 ? launch_gemm_big(p, s) : launch_gemm_f16(p, s);
+    return launch_gemm_f16(p, s);        // int8 [N][K] weights were expanded at engine creation (expand_lin)
 }
 
 }  // namespace
@@ -293,34 +369,27 @@ int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** ou
     wm_engine* e = new wm_engine();
     e->kind = (int)h->kind; e->flags = h->flags; e->device = device;
     memcpy(&e->dims, h->dims, sizeof(wm_dims));
-    hipError_t err = hipSetDevice(device);
-    if (err == hipSuccess) err = hipMalloc((void**)&e->dev, h->data_bytes ? h->data_bytes : 256);
-    if (err == hipSuccess) err = hipMemcpy(e->dev, (const unsigned char*)blob + h->data_offset, h->data_bytes, hipMemcpyHostToDevice);
-    if (err != hipSuccess) {
-        set_error("wm_engine_create: device %d: %s", device, hipGetErrorString(err));
-        if (e->dev) (void)hipFree(e->dev);
-        delete e;
-        return 2;
-    }
-    e->dev_bytes = h->data_bytes;
     const BlobTensor* tt = (const BlobTensor*)((const unsigned char*)blob + sizeof(BlobHeader));
-    for (uint32_t i = 0; i < h->n_tensors; ++i) {
-        Tensor t;
+    for (uint32_t i = 0; i < h->n_tensors; ++i)
         if (tt[i].offset + tt[i].nbytes > h->data_bytes) {
             set_error("tensor %.64s exceeds the blob", tt[i].name);
-            (void)hipFree(e->dev); delete e; return 1;
+            delete e; return 1;
         }
-        t.ptr = e->dev + tt[i].offset; t.dtype = tt[i].dtype; t.nbytes = tt[i].nbytes;
-        memcpy(t.shape, tt[i].shape, sizeof(t.shape));
-        char nm[65]; memcpy(nm, tt[i].name, 64); nm[64] = 0;
-        e->t[nm] = t;
-        if (t.dtype == 2 && t.nbytes == 4) {
+    hipError_t err = hipSetDevice(device);
+    if (err != hipSuccess) { set_error("wm_engine_create: device %d: %s", device, hipGetErrorString(err)); delete e; return 2; }
+    if (int rc = upload(e, h, tt, (const unsigned char*)blob + h->data_offset)) {
+        if (e->dev) (void)hipFree(e->dev);
+        delete e;
+        return rc;
+    }
+    for (uint32_t i = 0; i < h->n_tensors; ++i)
+        if (tt[i].dtype == 2 && tt[i].nbytes == 4) {
+            char nm[65]; memcpy(nm, tt[i].name, 64); nm[64] = 0;
             float v;
             memcpy(&v, (const unsigned char*)blob + h->data_offset + tt[i].offset, 4);
             e->scalars[nm] = v;
         }
-    }
-    if (resolve(e) || expand_row_major_int8(e)) { (void)hipFree(e->dev); for (void* x : e->expanded) (void)hipFree(x); delete e; return 1; }
+    if (resolve(e)) { (void)hipFree(e->dev); delete e; return 1; }
     *out = e;
     return 0;
 }
@@ -328,7 +397,6 @@ int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** ou
 void wm_engine_destroy(wm_engine* e) {
     if (!e) return;
     if (e->dev) { (void)hipSetDevice(e->device); (void)hipFree(e->dev); }
-    for (void* x : e->expanded) (void)hipFree(x);
     delete e;
 }
 
@@ -422,17 +490,31 @@ int wm_cross_kv(const wm_engine* e, const void* xa, int B, void* const* out_laye
 namespace {
 // ---- in-situ kernel timing for the roofline report (bench.py): HIP event pairs around sampled
 // launches of the decode cross-attention kernel, on the stream it is launched on ------------------
+// One sampler and one diagnostic timeline PER DEVICE (one process may drive several GPUs, each from its own
+// thread): wm_profile_* / wm_debug_timeline act on the calling thread's current device, the decode step on its
+// engine's device; the mutex covers slot allocation.
+constexpr int MAX_DEVICES = 64;
 struct Profiler {
     bool enabled = false; int layer_stride = 1;
     std::vector<hipEvent_t> start, stop; size_t used = 0;
-} g_prof;
+    long long* timeline = nullptr; int timeline_cap = 0;
+};
+std::mutex g_prof_mu;
+Profiler g_prof_dev[MAX_DEVICES];
+int current_device_index() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    return dev;
+}
 
 // a free sample slot for an eager launch of layer `layer`, or -1; the launch itself stamps the slot's events
-int prof_slot(int layer, hipStream_t s) {
-    if (!g_prof.enabled || layer % g_prof.layer_stride != 0 || g_prof.used >= g_prof.start.size()) return -1;
+int prof_slot(Profiler& pr, int layer, hipStream_t s) {
+    if (!pr.enabled) return -1;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (layer % pr.layer_stride != 0 || pr.used >= pr.start.size()) return -1;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;   // eager launches only
-    return (int)g_prof.used++;
+    return (int)pr.used++;
 }
 
 struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total; };
@@ -499,9 +581,7 @@ size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new) {
 namespace {
 // One utterance group's decode step, cut into the phases between which the cross-attention kernel sits, so
 // that several groups can be interleaved layer by layer (wm_decoder_step_multi).
-// diagnostic timeline (wm_debug_timeline)
-long long* g_timeline = nullptr;
-int g_timeline_cap = 0;
+// diagnostic timeline (wm_debug_timeline): Profiler::timeline of the engine's device
 __global__ void stamp_kernel(long long* tl, int cap, long long tag, long long what) {
     if (threadIdx.x != 0) return;
     const int i = atomicAdd((int*)tl, 1);
@@ -512,8 +592,11 @@ struct GroupStep {
     const wm_engine* e; const wm_decoder_io* io; DecWs w;
     int B, L, T, C, H, M;
 
+    Profiler* prof = nullptr;
+
     int init(const wm_engine* e_, const wm_decoder_io* io_) {
         e = e_; io = io_;
+        prof = &g_prof_dev[e->device >= 0 && e->device < MAX_DEVICES ? e->device : 0];
         WM_REQUIRE(io && io->tokens && io->positional_embedding && io->present && io->cross && io->logits && io->workspace,
                    "wm_decoder_step: null argument");
         const wm_dims& d = e->dims;
@@ -521,6 +604,8 @@ struct GroupStep {
         WM_REQUIRE(B >= 1 && L >= 1 && L <= 4 && T >= 0, "wm_decoder_step: bad batch/n_new/n_past (%d, %d, %d)", B, L, T);
         WM_REQUIRE(T + L <= d.n_text_ctx, "wm_decoder_step: T+L=%d exceeds n_text_ctx=%d", T + L, d.n_text_ctx);
         WM_REQUIRE(T == 0 || io->past, "wm_decoder_step: n_past > 0 needs past buffers");
+        WM_REQUIRE(T == 0 || io->past_capacity >= T, "wm_decoder_step: past capacity %d < n_past %d", io->past_capacity, T);
+        WM_REQUIRE(io->present_capacity >= T + L, "wm_decoder_step: present capacity %d < n_past + n_new = %d", io->present_capacity, T + L);
         WM_REQUIRE(!io->n_past_dev || (L == 1 && io->past), "wm_decoder_step: a device step counter needs n_new == 1 and past buffers");
         WM_REQUIRE(C == H * 64, "head size must be 64");
         w = carve_decoder(e, B, L, io->workspace);
@@ -572,10 +657,10 @@ struct GroupStep {
 
     // the HBM-bound kernel: K and V of every utterance of the group, once
     int cross(int i, hipStream_t s) {
-        if (!g_timeline) return cross_launch(i, s);
-        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, g_timeline, g_timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i));
+        if (!prof->timeline) return cross_launch(i, s);
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, prof->timeline, prof->timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i));
         const int rc = cross_launch(i, s);
-        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, g_timeline, g_timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i + 1));
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, prof->timeline, prof->timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i + 1));
         return rc;
     }
 
@@ -589,8 +674,8 @@ struct GroupStep {
         p.kv = (const h16*)io->cross[i]; p.kv_bstride = (long)2 * H * d.n_audio_ctx * 64;
         p.kv_q8_scale = e->i8cross() ? Lr.cross_scale : 0.f;
         p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
-        const int slot = (L == 1) ? prof_slot(i, s) : -1;
-        if (launch_attn_cross(p, s, slot >= 0 ? g_prof.start[slot] : nullptr, slot >= 0 ? g_prof.stop[slot] : nullptr)) return 2;
+        const int slot = (L == 1) ? prof_slot(*prof, i, s) : -1;
+        if (launch_attn_cross(p, s, slot >= 0 ? prof->start[slot] : nullptr, slot >= 0 ? prof->stop[slot] : nullptr)) return 2;
         return 0;
     }
 
@@ -622,18 +707,6 @@ struct GroupStep {
     }
 };
 
-// events that order a group's light stream against the shared heavy stream: [group][layer][0: q ready, 1: ctx ready]
-struct EventPool {
-    std::vector<hipEvent_t> ev;
-    hipEvent_t get(size_t idx) {
-        while (ev.size() <= idx) {
-            hipEvent_t x = nullptr;
-            if (hipEventCreateWithFlags(&x, hipEventDisableTiming) != hipSuccess) return nullptr;
-            ev.push_back(x);
-        }
-        return ev[idx];
-    }
-} g_events;
 }  // namespace
 
 int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream_) {
@@ -691,7 +764,7 @@ int wm_decoder_step_multi(const wm_engine* e, int n_groups, const wm_decoder_io*
     for (int i = 0; i < n_layer; ++i) {
         for (int k = 0; k < n_groups; ++k) {
             hipStream_t ls = (hipStream_t)light_streams[k];
-            hipEvent_t q_ready = g_events.get(((size_t)k * n_layer + i) * 2), ctx_ready = g_events.get(((size_t)k * n_layer + i) * 2 + 1);
+            hipEvent_t q_ready = e->events.get(((size_t)k * n_layer + i) * 2), ctx_ready = e->events.get(((size_t)k * n_layer + i) * 2 + 1);
             WM_REQUIRE(q_ready && ctx_ready, "wm_decoder_step_multi: hipEventCreate failed");
             if (g[k].pre_cross(i, ls)) return 2;
             WM_CHECK_HIP(hipEventRecord(q_ready, ls));
@@ -724,6 +797,8 @@ int wm_stream_destroy(wm_stream_t stream) {
 // ================================================================================================ profiling
 int wm_profile_configure(int enabled, int layer_stride, int max_samples) {
     WM_REQUIRE(layer_stride >= 1 && max_samples >= 0, "wm_profile_configure: bad arguments");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    Profiler& g_prof = g_prof_dev[current_device_index()];
     g_prof.enabled = false;
     for (size_t i = 0; i < g_prof.start.size(); ++i) { (void)hipEventDestroy(g_prof.start[i]); (void)hipEventDestroy(g_prof.stop[i]); }
     g_prof.start.clear(); g_prof.stop.clear(); g_prof.used = 0; g_prof.layer_stride = layer_stride;
@@ -738,13 +813,17 @@ int wm_profile_configure(int enabled, int layer_stride, int max_samples) {
 }
 
 int wm_debug_timeline(void* buf, int capacity) {
-    g_timeline = (long long*)buf;
-    g_timeline_cap = buf ? capacity : 0;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    Profiler& pr = g_prof_dev[current_device_index()];
+    pr.timeline = (long long*)buf;
+    pr.timeline_cap = buf ? capacity : 0;
     return 0;
 }
 
 int wm_profile_read(double* total_ms, int64_t* count, int reset) {
     WM_REQUIRE(total_ms && count, "wm_profile_read: null argument");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    Profiler& g_prof = g_prof_dev[current_device_index()];
     double sum = 0.0;
     for (size_t i = 0; i < g_prof.used; ++i) {
         float ms = 0.f;
@@ -774,12 +853,40 @@ int wm_step_advance(int32_t* counter, wm_stream_t stream) { return launch_step_a
 
 // ================================================================================================ kernel-level
 int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, const void* scale,
-            const void* bias, const void* residual, int ldr, int act, void* C, int ldc, wm_stream_t stream) {
+            const void* bias, const void* residual, int ldr, int act, void* C, int ldc,
+            void* workspace, size_t workspace_bytes, wm_stream_t stream) {
     GemmBigParams p{};
-    p.A = (const h16*)A; p.lda = lda; p.M = M; p.K = K; p.W = W; p.N = N; p.w8 = w8;
-    p.scale = (const h16*)scale; p.bias = (const h16*)bias; p.C = (h16*)C; p.ldc = ldc;
+    p.A = (const h16*)A; p.lda = lda; p.M = M; p.K = K; p.W = W; p.N = N;
+    p.bias = (const h16*)bias; p.C = (h16*)C; p.ldc = ldc;
     p.residual = (const h16*)residual; p.ldr = ldr; p.act = act;
-    return w8 ? launch_gemm_big(p, (hipStream_t)stream) : launch_gemm_f16(p, (hipStream_t)stream);
+    if (w8) {
+        // exactly what the engines do with a weight-only matrix of an M >> 16 stage (expand_lin): one expansion to
+        // fp16(fp16(q) * scale), then the fp16 MFMA GEMM -- here into the caller's workspace, per call
+        WM_REQUIRE(scale && workspace, "wm_gemm: int8 weights need their scales and a workspace for the fp16 expansion");
+        WM_REQUIRE(workspace_bytes >= (size_t)N * K * sizeof(h16), "wm_gemm: workspace too small: %zu < %zu", workspace_bytes, (size_t)N * K * sizeof(h16));
+        if (launch_dequant_w8((const int8_t*)W, (const h16*)scale, (h16*)workspace, N, K, (hipStream_t)stream)) return 2;
+        p.W = workspace;
+    }
+    return launch_gemm_f16(p, (hipStream_t)stream);
+}
+
+int wm_conv1d_gelu(const void* x_pad, int B, int T_in, int C_in, const void* W, int K, const void* bias, int C_out,
+                   int stride, int gelu, void* out, wm_stream_t stream) {
+    WM_REQUIRE(x_pad && W && out && B >= 1 && T_in >= 1, "wm_conv1d_gelu: null argument or empty input");
+    WM_REQUIRE(stride == 1 || stride == 2, "wm_conv1d_gelu: stride %d (1 or 2)", stride);
+    WM_REQUIRE(T_in % stride == 0 && K >= 3 * C_in, "wm_conv1d_gelu: T_in=%d, K=%d < 3*C_in=%d", T_in, K, 3 * C_in);
+    const int T_out = T_in / stride;
+    GemmBigParams p{};
+    // output row t of utterance b = GELU(W . [x_pad[b][s*t], x_pad[b][s*t+1], x_pad[b][s*t+2]] + bias): a strided view
+    p.A = (const h16*)x_pad; p.lda = stride * C_in; p.M = B * T_out; p.K = K; p.W = W; p.N = C_out;
+    p.a_rows = T_out; p.a_bstride = (long)(T_in + 2) * C_in;
+    p.bias = (const h16*)bias; p.C = (h16*)out; p.ldc = C_out; p.act = gelu;
+    return launch_gemm_f16(p, (hipStream_t)stream);
+}
+
+int wm_argmax(const void* logits, int64_t row_stride, int batch, int n_vocab, int32_t* ids, wm_stream_t stream) {
+    WM_REQUIRE(logits && ids && batch >= 1 && n_vocab >= 1, "wm_argmax: null argument or empty input");
+    return launch_argmax((const h16*)logits, (long)row_stride, batch, n_vocab, ids, (hipStream_t)stream);
 }
 
 int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_blocks, int w8,

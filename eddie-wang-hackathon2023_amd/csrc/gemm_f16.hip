@@ -207,7 +207,6 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
 
 int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream) {
     using namespace f16gemm;
-    WM_REQUIRE(!p.w8, "gemm_f16: int8 weights must be expanded first");
     WM_REQUIRE(p.N % 128 == 0, "gemm_f16: N=%d must be a multiple of 128", p.N);
     WM_REQUIRE(p.K % BK == 0, "gemm_f16: K=%d must be a multiple of %d", p.K, BK);
     WM_REQUIRE(p.lda % 8 == 0, "gemm_f16: lda=%d must be a multiple of 8 (16-byte loads)", p.lda);

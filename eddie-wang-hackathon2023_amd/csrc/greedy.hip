@@ -153,6 +153,25 @@ int launch_greedy(const GreedyParams& p, hipStream_t stream) {
     return 0;
 }
 
+// plain arg-max of fp16 rows, first index wins ties (torch.argmax's convention; the kernel-level entry wm_argmax)
+__global__ __launch_bounds__(GREEDY_THREADS) void argmax_kernel(const h16* logits, long ld_row, int V, int32_t* ids) {
+    __shared__ AM s_am[GREEDY_THREADS / 64];
+    const h16* lg = logits + (size_t)blockIdx.x * ld_row;
+    AM a{-INFINITY, 0x7fffffff};
+    for (int n = threadIdx.x; n < V; n += GREEDY_THREADS) {
+        const float x = (float)lg[n];
+        if (x > a.v) a = AM{x, n};
+    }
+    a = block_reduce(a, am_merge, s_am);
+    if (threadIdx.x == 0) ids[blockIdx.x] = a.i;
+}
+
+int launch_argmax(const h16* logits, long ld_row, int B, int V, int32_t* ids, hipStream_t stream) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(GREEDY_THREADS), 0, stream, logits, ld_row, V, ids);
+    WM_LAUNCH_CHECK(stream, "argmax");
+    return 0;
+}
+
 __global__ void step_advance_kernel(int32_t* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1; }
 
 int launch_step_advance(int32_t* counter, hipStream_t stream) {

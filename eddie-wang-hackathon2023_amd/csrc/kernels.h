@@ -4,11 +4,11 @@
 
 namespace wm {
 
-// ---------------------------------------------------------------- gemm_big.hip
+// ---------------------------------------------------------------- gemm_f16.hip
 struct GemmBigParams {
     const h16* A; int lda; int M; int K;
-    const void* W; int N; int w8;            // W [N][K] row-major fp16, or int8 when w8
-    const h16* scale; const h16* bias;       // per output channel (scale only with w8); may be null
+    const void* W; int N;                    // W [N][K] row-major fp16 (int8 matrices are expanded first: launch_dequant_w8)
+    const h16* bias;                         // per output channel; may be null
     h16* C; int ldc;
     const h16* residual; int ldr; int res_mod;   // v += residual[row % res_mod (or row)][col]
     int act;                                 // 0 none, 1 exact-erf GELU, 2 tanh GELU
@@ -21,8 +21,7 @@ struct GemmBigParams {
     int a_rows; long a_bstride;
     int c_rows; long c_bstride;              // same for C (out_mode 0 only)
 };
-int launch_gemm_big(const GemmBigParams& p, hipStream_t stream);      // 128x128 tile, register staged; int8 or fp16 W
-int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // 256x128 tile, LDS-DMA ring; fp16 W (gemm_f16.hip)
+int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // 256x256 (256x128) tile, LDS-DMA ring
 int launch_dequant_w8(const int8_t* q, const h16* scale, h16* out, int N, int K, hipStream_t stream);
 
 // ---------------------------------------------------------------- gemm_skinny.hip
@@ -128,6 +127,7 @@ struct GreedyParams {
 };
 int launch_greedy(const GreedyParams& p, hipStream_t stream);
 int launch_step_advance(int32_t* counter, hipStream_t stream);
+int launch_argmax(const h16* logits, long ld_row, int B, int V, int32_t* ids, hipStream_t stream);
 
 // ---------------------------------------------------------------- frontend.hip
 size_t log_mel_workspace_bytes(int batch, int n_samples, int n_mels);

@@ -295,8 +295,12 @@ class WhisperDecoding:
         return tuple(sorted(set(suppress_tokens)))
 
     def get_tokenizer(self, multilingual: bool, language: Optional[str] = None, task: Optional[str] = None) -> Tokenizer:
-        if self.vocab_path:
-            return Tokenizer.from_vocab(self.vocab_path, multilingual, language, task)
+        path = self.vocab_path
+        if not path:      # the vendored vocabulary (assets/ASSETS.md), like the reference's assets/ (W/decoding.py:423-431)
+            bundled = Path(__file__).resolve().parent / 'assets' / ('multilingual.tiktoken' if multilingual else 'gpt2.tiktoken')
+            path = str(bundled) if bundled.exists() else None
+        if path:
+            return Tokenizer.from_vocab(path, multilingual, language, task)
         return Tokenizer.ids_only(multilingual, language, task)
 
     def _get_initial_tokens(self) -> Tuple[int]:
@@ -313,9 +317,19 @@ class WhisperDecoding:
         return tuple(tokens)
 
     # ---- engine calls with the reference's by-name protocol ------------------------------------------
+    @staticmethod
+    def _features_key(xa):
+        """Identity of an audio-features tensor's CONTENT, or None when it cannot be known: the generation number
+        the encoder stamped on it (encoding.stamp_generation) plus pointer, shape and torch's version counter.
+        Pointer and version alone are not enough -- the engine writes through raw pointers, so a second batch
+        encoded into the same buffer looks unchanged to torch.  A tensor without a stamp (a slice, a clone, a
+        tensor from elsewhere) is never assumed to be one seen before."""
+        gen = getattr(xa, 'wm_generation', None)
+        return None if gen is None else (gen, xa.data_ptr(), tuple(xa.shape), xa._version)
+
     def xa2cross_key_value(self, xa):
-        key = (xa.data_ptr(), tuple(xa.shape), xa._version)
-        if self._cross_cache is not None and self._cross_cache[0] == key:
+        key = self._features_key(xa)
+        if key is not None and self._cross_cache is not None and self._cross_cache[0] == key:
             return self._cross_cache[1]
         inputs = OrderedDict()
         xa16 = xa.type(torch.float16).contiguous()
@@ -543,6 +557,14 @@ class WhisperDecoding:
         st = self._state.get(n_batch)
         if st is not None:
             return st
+        # One buffer set at a time: a set holds the KV cache, the persistent cross K/V (245.76 MB per utterance at
+        # large-v2: 141 GB at B = 576) and the captured graphs that point into them; a ragged last batch must not
+        # allocate a second set next to the first.  Graphs go first (they reference the buffers).
+        for old in self._state.values():
+            old['graphs'].clear()
+        self._state.clear()
+        if device.type == 'cuda':
+            torch.cuda.empty_cache()
         cfg = self.decoder_config
         n_layer, n_head, cap, V = cfg['num_layers'], cfg['num_heads'], cfg['num_text_ctx'], cfg['vocab_size']
         kv_dtype = torch.int8 if self.use_int8_kv_cache else torch.float16
@@ -619,10 +641,10 @@ class WhisperDecoding:
 
     def _cross_persistent(self, xa, st):
         """Cross K/V of `xa` in the state's persistent buffers (stable addresses: the captured decode
-        graphs point at them).  Computed once per audio-features tensor; `xa` is kept alive so that the
-        (pointer, version) key cannot alias a recycled allocation."""
-        key = (xa.data_ptr(), tuple(xa.shape), xa._version)
-        if st['cross_key'] != key:
+        graphs point at them).  Computed once per encoder run (`_features_key`: detect_language and main_loop
+        on the same encoder output share them; anything else is recomputed)."""
+        key = self._features_key(xa)
+        if key is None or st['cross_key'] != key:
             xa16 = xa.type(torch.float16).contiguous()
             self.cross_attn_session.cross_kv(xa16, st['cross'], torch.cuda.current_stream().cuda_stream)
             st['cross_key'], st['cross_xa'] = key, xa

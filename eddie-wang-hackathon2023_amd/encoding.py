@@ -7,6 +7,7 @@ hard-wired to `[1, 80, 3000]`; any batch works here) and returns fp16
 """
 from __future__ import annotations
 
+import itertools
 import json
 from collections import OrderedDict
 
@@ -14,6 +15,18 @@ import torch
 
 from build import get_engine_name
 from session import Session, TensorInfo, str_dtype_to_trt, trt_dtype_to_torch, logger
+
+
+# Every encoder run stamps its output tensor with a fresh generation number (`audio_features.wm_generation`).
+# The engine writes through a raw pointer, which torch's `_version` counter never sees, so (pointer, shape,
+# version) alone cannot tell two batches encoded into the same buffer apart; WhisperDecoding re-uses cross K/V
+# only for a tensor that carries the generation it cached.
+_GENERATION = itertools.count(1)
+
+
+def stamp_generation(audio_features):
+    audio_features.wm_generation = next(_GENERATION)
+    return audio_features
 
 
 class WhisperEncoding:
@@ -65,7 +78,7 @@ class WhisperEncoding:
         ok = self.session.run(inputs=inputs, outputs=outputs, stream=stream.cuda_stream)
         assert ok, 'Engine execution failed'
         stream.synchronize()
-        return outputs['output']
+        return stamp_generation(outputs['output'])
 
     def get_audio_features_async(self, mel, out=None):
         """Fast path: no dictionaries, no synchronisation; enqueued on the current stream."""
@@ -74,4 +87,4 @@ class WhisperEncoding:
         if out is None:
             out = torch.empty((mel.shape[0], d['n_audio_ctx'], d['n_audio_state']), dtype=torch.float16, device=mel.device)
         self.session.encoder_forward(mel, out, torch.cuda.current_stream().cuda_stream)
-        return out
+        return stamp_generation(out)

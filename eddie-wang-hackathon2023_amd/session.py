@@ -178,14 +178,14 @@ class Session(object):
         lib = self._engine.lib
         b = mel.shape[0]
         nbytes = lib.wm_encoder_workspace_bytes(self._engine.handle, b)
-        ws = self._workspace(("enc", b), nbytes)
+        ws = self._workspace(("enc",), nbytes)        # one buffer, grown on demand: 26 GB at B = 576
         check(lib.wm_encoder_forward(self._engine.handle, mel.data_ptr(), b, out.data_ptr(), ws.data_ptr(),
                                      ws.numel(), stream), "wm_encoder_forward")
 
     def cross_kv(self, xa: torch.Tensor, outs: Sequence[torch.Tensor], stream: int):
         lib = self._engine.lib
         b = xa.shape[0]
-        ws = self._workspace(("ckv", b), lib.wm_cross_kv_workspace_bytes(self._engine.handle, b))
+        ws = self._workspace(("ckv",), lib.wm_cross_kv_workspace_bytes(self._engine.handle, b))
         check(lib.wm_cross_kv(self._engine.handle, xa.data_ptr(), b, ptr_array(outs), ws.data_ptr(), ws.numel(),
                               stream), "wm_cross_kv")
 

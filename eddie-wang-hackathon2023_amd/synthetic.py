@@ -23,6 +23,8 @@ DIMS = {
                      n_vocab=51865, n_text_ctx=448, n_text_state=1280, n_text_head=20, n_text_layer=32),
     "tiny.en": dict(n_mels=80, n_audio_ctx=1500, n_audio_state=384, n_audio_head=6, n_audio_layer=4,
                     n_vocab=51864, n_text_ctx=448, n_text_state=384, n_text_head=6, n_text_layer=4),
+    "tiny": dict(n_mels=80, n_audio_ctx=1500, n_audio_state=384, n_audio_head=6, n_audio_layer=4,
+                 n_vocab=51865, n_text_ctx=448, n_text_state=384, n_text_head=6, n_text_layer=4),
     "micro": dict(n_mels=80, n_audio_ctx=64, n_audio_state=128, n_audio_head=2, n_audio_layer=2,
                   n_vocab=1024, n_text_ctx=32, n_text_state=128, n_text_head=2, n_text_layer=2),
     "micro-fullvocab": dict(n_mels=80, n_audio_ctx=64, n_audio_state=128, n_audio_head=2, n_audio_layer=2,

@@ -16,9 +16,10 @@ self-attention kernel itself keeps the running maximum (wm_decoder_io.qkv_amax, 
 so calibration runs at engine speed.  Q outputs are included on purpose -- that is what the
 reference's merged q/k/v range does (W/torch_whisper_convert.py:145-167).
 
-Calibration input: `--dataset_dir` with `.npy` log-mels `[80, 3000]` (the reference decodes FLAC with
-ffmpeg, which is not on these boxes; audio front-end = SURVEY section 8f row 1), or
-`--synthetic_clips N` seeded synthetic mels.
+Calibration input: `--dataset_dir` as the reference uses it (W/torch_whisper_convert.py:121-216 over
+`LibriSpeech/valid-clean`): every `.flac` below the directory, decoded by wm_flac_decode, padded / trimmed to
+30 s and turned into log-mels by wm_log_mel on the GPU (the reference shells out to ffmpeg, W/whisper_utils.py:17-54);
+`.npy` log-mels `[80, 3000]` are accepted too; or `--synthetic_clips N` seeded synthetic mels.
 """
 from __future__ import annotations
 
@@ -38,10 +39,11 @@ def scale_file_name(layer: int) -> str:
 
 
 def capture_kv_activation_range(engine_dir, mels: torch.Tensor, batch: int = 8, sample_len: Optional[int] = None,
-                                ignore_eot: bool = False) -> List[float]:
+                                ignore_eot: bool = False, token_log: Optional[list] = None) -> List[float]:
     """max(|q|,|k|,|v|) per decoder layer while the engines in `engine_dir` (fp16 KV) decode `mels`
     [N, n_mels, 2*n_audio_ctx].  Mirror of capture_activation_range (W/smoothquant.py:117-175)
-    restricted to what `-kv` consumes."""
+    restricted to what `-kv` consumes.  `token_log` (tests): receives, per batch, the token rows the loop
+    decoded (int64 [b, n]) and the length of the start sequence, i.e. the exact token path the statistic saw."""
     from decoding import WhisperDecoding
     from encoding import WhisperEncoding
     engine_dir = Path(engine_dir)
@@ -57,7 +59,9 @@ def capture_kv_activation_range(engine_dir, mels: torch.Tensor, batch: int = 8, 
             mel = mels[i:i + batch].to('cuda').type(torch.float16)
             xa = enc.get_audio_features(mel)
             dec.detect_language(xa)
-            dec.main_loop(xa, ignore_eot=ignore_eot)
+            tokens, _, _ = dec.main_loop(xa, ignore_eot=ignore_eot)
+            if token_log is not None:
+                token_log.append((tokens.cpu(), dec.initial_token_length, dec.tokenizer.sot if dec.is_multilingual else None))
         torch.cuda.synchronize()
     finally:
         dec.decoder_session.qkv_amax = None
@@ -130,9 +134,18 @@ def load_calibration_mels(args, dims) -> torch.Tensor:
     import synthetic
     if args.synthetic_clips > 0:
         return synthetic.synthetic_mel(args.synthetic_clips, 2 * dims['n_audio_ctx'], dims['n_mels'], 4321)
-    files = sorted(p for p in Path(args.dataset_dir).iterdir() if p.suffix == '.npy')
+    root = Path(args.dataset_dir)
+    flacs = sorted(root.rglob('*.flac'))
+    if flacs:
+        import whisper_utils as wu
+        mels = []
+        for f in flacs:
+            audio = torch.from_numpy(wu.pad_or_trim(wu.load_audio(str(f)))).cuda()
+            mels.append(wu.log_mel_spectrogram_device(audio, n_mels=dims['n_mels'], dtype=torch.float16).cpu())
+        return torch.stack(mels)
+    files = sorted(p for p in root.rglob('*.npy'))
     if not files:
-        raise FileNotFoundError(f"no .npy log-mels in {args.dataset_dir} (FLAC decoding is next-scope, SURVEY 8f-1)")
+        raise FileNotFoundError(f"no .flac audio or .npy log-mels below {args.dataset_dir}")
     return torch.stack([torch.from_numpy(np.load(f)).half() for f in files])
 
 

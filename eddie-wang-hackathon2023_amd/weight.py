@@ -216,20 +216,24 @@ def _qkv(params, prefix):
     return w, b
 
 
+def conv_weight_as_gemm(w: np.ndarray) -> np.ndarray:
+    """Conv1d weight [C_out, C_in, 3] -> the GEMM matrix [C_out, K] the engine multiplies token-major rows with:
+    K index = tap * C_in + c_in, zero columns up to a multiple of 64 (the GEMM's K tile)."""
+    c_out, c_in, taps = w.shape
+    g = np.asarray(w, dtype=np.float16).transpose(0, 2, 1).reshape(c_out, taps * c_in)
+    kpad = (taps * c_in + 63) // 64 * 64
+    return np.ascontiguousarray(np.concatenate([g, np.zeros((c_out, kpad - taps * c_in), dtype=np.float16)], axis=1))
+
+
 def load_encoder_weight(model_metadata: dict, model_params: dict, n_layer: int,
                         use_weight_only: bool = False) -> "OrderedDict[str, np.ndarray]":
     """Encoder engine tensors (W/weight.py:35-152)."""
     t: "OrderedDict[str, np.ndarray]" = OrderedDict()
     C, n_mels = model_metadata["n_audio_state"], model_metadata["n_mels"]
     # convolutions as GEMMs over token-major rows: K index = tap * C_in + c_in
-    w1 = _np(model_params["encoder.conv1.weight"]).astype(np.float16)          # [C, n_mels, 3]
-    w1 = w1.transpose(0, 2, 1).reshape(C, 3 * n_mels)
-    kpad = (3 * n_mels + 63) // 64 * 64
-    w1 = np.concatenate([w1, np.zeros((C, kpad - 3 * n_mels), dtype=np.float16)], axis=1)
-    t["conv1.w"] = np.ascontiguousarray(w1)
+    t["conv1.w"] = conv_weight_as_gemm(_np(model_params["encoder.conv1.weight"]))      # [C, n_mels, 3] -> [C, 256]
     t["conv1.b"] = _np(model_params["encoder.conv1.bias"]).astype(np.float16)
-    w2 = _np(model_params["encoder.conv2.weight"]).astype(np.float16)          # [C, C, 3]
-    t["conv2.w"] = np.ascontiguousarray(w2.transpose(0, 2, 1).reshape(C, 3 * C))
+    t["conv2.w"] = conv_weight_as_gemm(_np(model_params["encoder.conv2.weight"]))      # [C, C, 3] -> [C, 3C]
     t["conv2.b"] = _np(model_params["encoder.conv2.bias"]).astype(np.float16)
     t["pos"] = sinusoids(model_metadata["n_audio_ctx"], C)
     for i in range(n_layer):

@@ -147,10 +147,25 @@ int wm_step_advance(int32_t* counter, wm_stream_t stream);
 /* ---- kernel-level entry points (parity tests, micro-benchmarks, roofline measurement) -----------*/
 /* C[M,N] = act(A[M,K] x W[N,K]^T * scale + bias) (+ residual); W fp16 or int8 (w8) row-major [N][K].
  * act: 0 none, 1 erf-GELU, 2 tanh-GELU.  Replaces CutlassFpAIntBGemmRunner::gemm /
- * the TRT MatMul (fpA_intB_gemm_template.h:47-140).                                                */
+ * the TRT MatMul (fpA_intB_gemm_template.h:47-140).  w8: the engines' own path for a weight-only
+ * matrix of an M >> 16 stage -- W is expanded to fp16(fp16(q) * scale) (the reference kernels'
+ * per-element dequantisation) into `workspace` (>= N*K*2 bytes), then the fp16 MFMA GEMM runs on it.
+ * N a multiple of 128, K a multiple of 64.                                                         */
 int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, const void* scale,
             const void* bias, const void* residual, int ldr, int act, void* C, int ldc,
-            wm_stream_t stream);
+            void* workspace, size_t workspace_bytes, wm_stream_t stream);
+/* 1-D convolution, kernel 3, padding 1, stride 1 or 2, + GELU (gelu: 1 erf, 2 tanh), as the encoder
+ * engine runs it (Conv1d, R/tensorrt_llm/layers/conv.py:52-94; W/torch_model.py:152-156): a GEMM over a
+ * strided view of the zero-padded token-major input, no im2col.  x_pad fp16 [B][T_in+2][C_in] with rows 0
+ * and T_in+1 of every utterance zero, followed by >= 512 finite elements of slack (the K padding is read
+ * and multiplied by zero weights); W fp16 [C_out][K], K index = tap*C_in + c_in, zero columns up to a
+ * multiple of 64 (weight.py: conv_weight_as_gemm); C_out a multiple of 128, C_in of 8.
+ * out fp16 [B][T_in/stride][C_out].                                                                 */
+int wm_conv1d_gelu(const void* x_pad, int B, int T_in, int C_in, const void* W, int K, const void* bias,
+                   int C_out, int stride, int gelu, void* out, wm_stream_t stream);
+/* ids[b] = arg-max of row b of fp16 logits (first index wins ties).  The decode loop itself uses
+ * wm_greedy_step, which fuses this with Whisper's logit rules (apply_rules = 0: plain arg-max + append). */
+int wm_argmax(const void* logits, int64_t row_stride, int batch, int n_vocab, int32_t* ids, wm_stream_t stream);
 /* Weight-streaming GEMM, M <= 256, W in tile-linear layout (weight.py: tile_linear*).  w8: 0 = fp16
  * tiles, 1 = int8 tiles, 4 = packed int4 tiles (tile_linear_int4; K a multiple of 128).  `part` must
  * hold ksplit*M*n_blocks*16 floats; result[m][n] = sum_s part[s][m][n].  Replaces

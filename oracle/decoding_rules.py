@@ -76,8 +76,10 @@ def log_softmax_f32(x: np.ndarray) -> np.ndarray:
         return (x - m) - np.log(np.exp(x - m).sum(axis=-1, keepdims=True, dtype=np.float32))
 
 
-def apply_filters(logits: np.ndarray, tokens: np.ndarray, rules: RuleSet) -> np.ndarray:
-    """logits [B, V] (modified copy is returned), tokens [B, cur_len] = the whole context so far."""
+def apply_filters(logits: np.ndarray, tokens: np.ndarray, rules: RuleSet, dominance_out: Optional[list] = None) -> np.ndarray:
+    """logits [B, V] (modified copy is returned), tokens [B, cur_len] = the whole context so far.
+    `dominance_out` (tests): receives, per row, log P(any timestamp) - max log P(text token), the quantity whose sign
+    decides the last rule -- a near-zero value is a near-tie of that rule, not of two logits."""
     lg = logits.astype(np.float32).copy()
     ids = rules.ids
     B, cur = tokens.shape
@@ -115,6 +117,8 @@ def apply_filters(logits: np.ndarray, tokens: np.ndarray, rules: RuleSet) -> np.
         m = row.max()
         with np.errstate(divide="ignore", invalid="ignore"):
             ts_lp = m + np.log(np.exp(row - m).sum(dtype=np.float32)) if np.isfinite(m) else NEG_INF
+        if dominance_out is not None:
+            dominance_out.append(float(ts_lp - lp[k, :tb].max()))
         if ts_lp > lp[k, :tb].max():
             lg[k, :tb] = NEG_INF
     return lg

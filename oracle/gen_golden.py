@@ -107,6 +107,38 @@ def gen_model_fixture(tm):
           "min margin", float(fix["f32_margins"].min()))
 
 
+def gen_tiny_en_shape_fixture(tm):
+    """One fixture at a REAL Whisper shape (SURVEY 8c "one tiny.en-shaped case"): 384 wide, 6 heads, 1500 audio
+    positions (mel 3000 frames), gpt2 vocabulary of 51 864, 448 text positions -- depth cut to 2 + 2 layers so that
+    the reference's CPU run and the oracle's stay in seconds.  Kept small: every 10th row of the encoder output and of
+    layer 0's cross K / V, the top-64 logits (values + ids) per step, greedy ids and margins."""
+    dims = Dims(80, 1500, 384, 6, 2, 51864, 448, 384, 6, 2)
+    seed, mel_seed, B, n_steps = 33, 777, 1, 5
+    prompt = [50257, 50362, 1169]                   # <|startoftranscript|>, <|notimestamps|> of the gpt2 vocabulary, a text token
+    sd = synthetic_state_dict(dims, seed)
+    mel = synthetic_mel(B, 2 * dims.n_audio_ctx, dims.n_mels, mel_seed)
+    rows = np.arange(0, dims.n_audio_ctx, 10)
+    fix = {"dims": np.array(list(dims.to_dict().values()), dtype=np.int64),
+           "dims_keys": np.array(list(dims.to_dict().keys())),
+           "seed": seed, "mel_seed": mel_seed, "batch": B, "prompt": np.array(prompt), "n_steps": n_steps, "rows": rows}
+    for tag, half in (("f32", False), ("f16", True)):
+        r = run_reference_model(tm, dims, sd, mel, prompt, n_steps, half)
+        store = np.float32 if tag == "f32" else np.float16      # fp16-mode outputs ARE fp16 values
+        fix[f"{tag}_xa"] = r["xa"][:, rows].astype(store)
+        fix[f"{tag}_cross_k0"] = r["cross_k0"][:, rows].astype(store)
+        fix[f"{tag}_cross_v0"] = r["cross_v0"][:, rows].astype(store)
+        fix[f"{tag}_cross_vL"] = r["cross_vL"][:, rows].astype(store)
+        last = np.concatenate([r["prefill_logits"][:, -1:], r["step_logits"]], axis=1)        # [B, n_steps, V]
+        top = np.argsort(-last, axis=-1, kind="stable")[..., :64]
+        fix[f"{tag}_top_ids"] = top.astype(np.int32)
+        fix[f"{tag}_top_logits"] = np.take_along_axis(last, top, axis=-1).astype(np.float32)
+        fix[f"{tag}_logit_checksum"] = np.abs(last).sum(axis=-1, dtype=np.float64)
+        fix[f"{tag}_ids"], fix[f"{tag}_margins"] = r["ids"], r["margins"].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "model_tiny_en_shape.npz"), **fix)
+    print("model_tiny_en_shape.npz: ids f32", fix["f32_ids"].tolist(), "f16", fix["f16_ids"].tolist(),
+          "min margin", float(fix["f32_margins"].min()), os.path.getsize(os.path.join(OUT, "model_tiny_en_shape.npz")), "bytes")
+
+
 def gen_op_fixtures(tm):
     """Per-op pins: attention core (the identity-weights trick of R/tests/test_layer.py:616-625 is
     unnecessary here because qkv_attention is callable on its own), LayerNorm, conv1d, GELU."""
@@ -224,7 +256,11 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     tm = import_reference_model()
+    if "--only-tiny" in sys.argv:
+        gen_tiny_en_shape_fixture(tm)
+        sys.exit(0)
     gen_model_fixture(tm)
+    gen_tiny_en_shape_fixture(tm)
     gen_op_fixtures(tm)
     gen_mel_fixture()
     dec = import_reference_decoding()

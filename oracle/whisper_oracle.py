@@ -514,6 +514,40 @@ class OracleModel:
         return [float(np.float32(a) / np.float32(127.0)) for a in amax]
 
 
+def kv_amax_on_token_path(model: OracleModel, mels: torch.Tensor, passes: List[List[torch.Tensor]]) -> List[float]:
+    """The calibration statistic of `OracleModel.calibrate_kv_scales` (max |q|, |k|, |v| outputs of every decoder
+    self-attention layer, W/smoothquant.py:117-175) over a GIVEN token path: `passes` is a list of decoder passes, each
+    a list of token blocks [B, L] fed one after the other to a cache that starts empty (language-ID pass = [[sot]],
+    main loop = [start sequence, token, token, ...]).  Teacher-forcing the path the engine decoded removes the one
+    thing a calibration comparison must not depend on: which way a near-tie fell."""
+    d = model.dims
+    amax = [0.0] * d.n_text_layer
+    saved = (model.cfg.int8_kv, model.cfg.kv_scales)
+    model.cfg.int8_kv, model.cfg.kv_scales = False, None
+    orig_linear = model._linear
+
+    def spy(x, wkey, bkey=None):
+        y = orig_linear(x, wkey, bkey)
+        if wkey.startswith("decoder.blocks.") and ".attn." in wkey and ".cross_attn." not in wkey \
+                and wkey.split(".")[4] in ("query", "key", "value"):
+            i = int(wkey.split(".")[2])
+            amax[i] = max(amax[i], float(y.abs().max()))
+        return y
+
+    model._linear = spy
+    try:
+        with torch.no_grad():
+            ckv = model.cross_kv(model.encoder(mels))
+            for blocks in passes:
+                kv = None
+                for tok in blocks:
+                    _, kv = model.decoder(tok, ckv, kv)
+    finally:
+        model._linear = orig_linear
+        model.cfg.int8_kv, model.cfg.kv_scales = saved
+    return amax
+
+
 def greedy_reference_run(model: OracleModel, mel: torch.Tensor, prompt: List[int], n_steps: int):
     """Plain greedy decode without Whisper's logit rules: encoder -> cross K/V -> prefill ->
     n_steps single-token steps.  Returns dict of everything a parity test compares."""

@@ -19,7 +19,7 @@ for (N, K, act, res) in [(3840, 1280, 0, 0), (1280, 1280, 0, 1), (5120, 1280, 1,
     s = torch.cuda.current_stream().cuda_stream
     def run():
         native.check(lib.wm_gemm(A.data_ptr(), K, M, K, W.data_ptr(), N, 0, None, bias.data_ptr(),
-                                 R.data_ptr() if res else None, N, act, C.data_ptr(), N, s))
+                                 R.data_ptr() if res else None, N, act, C.data_ptr(), N, None, 0, s))
     REPS = int(os.environ.get('REPS', '10'))
     for _ in range(3): run()
     torch.cuda.synchronize()

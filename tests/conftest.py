@@ -18,12 +18,35 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_BUILD_ERROR = None
+
+
 def pytest_sessionstart(session):
-    """The C-ABI library is built in-tree (git-ignored); a fresh checkout builds it once before the first test
-    (hipcc cross-compiles gfx950 without a GPU), exactly as __graft_entry__.build() does."""
-    if not os.path.exists(os.path.join(PKG, "libwhisper_mi355.so")):
-        import subprocess
-        subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL)
+    """The C-ABI library is built in-tree (git-ignored).  `make` runs on every session: a timestamp no-op when the
+    library is current, a rebuild after any edit of csrc/ (a stale .so would let the GPU suite pass for kernels
+    that no longer exist).  hipcc cross-compiles gfx950 without a GPU, exactly as __graft_entry__.build() does.
+    Without hipcc, or when the build fails, only the tests that need the library fail or are skipped -- the oracle
+    and host-logic tests still run."""
+    global _BUILD_ERROR
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        if not os.path.exists(os.path.join(PKG, "libwhisper_mi355.so")):
+            _BUILD_ERROR = "hipcc not found and libwhisper_mi355.so is not built"
+        return
+    r = subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        _BUILD_ERROR = "building libwhisper_mi355.so failed:\n" + r.stdout[-2000:]
+
+
+def pytest_collection_modifyitems(config, items):
+    if _BUILD_ERROR is None:
+        return
+    skip = pytest.mark.skip(reason=_BUILD_ERROR)
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -76,3 +76,34 @@ def test_single_process_passthrough():
     out, lp = dp.gather_results(toks, torch.tensor([0.5, 1.5]), 2, 5, pad_value=9)
     assert out.tolist() == [[1, 2, 3, 9, 9], [4, 5, 6, 9, 9]] and lp.tolist() == [0.5, 1.5]
     assert dp.max_over_ranks(3.25, "cpu") == 3.25
+
+
+def test_bench_launches_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher starts N fresh ranks through torch.distributed.run (never an exec of
+    a GPU-initialised process), relays rank 0's JSON line and its exit code; with too few GPUs it refuses loudly
+    instead of measuring one GPU and calling it N."""
+    import argparse
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        line = '{"metric": "decode tokens/s", "value": 1.0, "n_gpus": 4}'
+        return subprocess.CompletedProcess(cmd, 0, stdout="noise from a rank\n" + line + "\n")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    assert bench.launch_ranks(argparse.Namespace(gpus=4)) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "decode tokens/s", "value": 1.0, "n_gpus": 4}' and "noise from a rank" in out.err
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench.launch_ranks(argparse.Namespace(gpus=4)) == 2
+    assert "shows 1 GPU" in capsys.readouterr().err

@@ -71,14 +71,75 @@ def test_gemm_big(lib, M, N, K, w8, act, resid):
     a_dev, b_dev = dev(A), dev(bias)
     r_dev = dev(res) if resid else None
     out = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+    # w8: the engines' own path for a weight-only matrix of an M >> 16 stage (expansion to fp16(fp16(q) * scale), fp16 MFMA GEMM)
+    ws = torch.empty(N * K * 2 if w8 else 256, dtype=torch.uint8, device="cuda")
     native.check(lib.wm_gemm(a_dev.data_ptr(), K, M, K, w_dev.data_ptr(), N, w8,
                              s_dev.data_ptr() if s_dev is not None else None, b_dev.data_ptr(),
-                             r_dev.data_ptr() if resid else None, N, act, out.data_ptr(), N, stream()))
+                             r_dev.data_ptr() if resid else None, N, act, out.data_ptr(), N, ws.data_ptr(), ws.numel(), stream()))
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()
     # one fp16 ulp of the output magnitude (fp32 accumulation order is the only other difference)
     tol = 2.0 ** -10 * max(1.0, np.abs(ref).max())
+    if w8:
+        # the product path multiplies fp16(fp16(q) * scale) like the reference kernels (weightOnlyMatrixVectorMultiplication.cu:
+        # 44-53); against the reference TEST's ground truth (x @ q) * scale that is the tolerance the reference accepts
+        # (R/tests/quantization/_utils.py:66-88), and against the same arithmetic restated it is one ulp
+        deq = (q.astype(np.float16) * s[:, None]).astype(np.float16).astype(np.float32)
+        ref2 = (A.astype(np.float32) @ deq.T + bias.astype(np.float32)).astype(np.float16).astype(np.float32)
+        if act == 1:
+            ref2 = torch.nn.functional.gelu(torch.from_numpy(ref2)).half().float().numpy()
+        if resid:
+            ref2 = (ref2 + res.astype(np.float32)).astype(np.float16).astype(np.float32)
+        assert np.abs(got - ref2).max() <= tol, (np.abs(got - ref2).max(), tol)
+        tol = max(tol, 1.5 * np.abs(ref).max() / 128.0)
     assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), tol)
+
+
+def test_conv1d_gelu_matches_reference_golden(lib, golden_dir):
+    """wm_conv1d_gelu against the reference's own Conv1d + GELU outputs (tests/golden/ops.npz: conv1 k3 s1 p1, conv2 k3 s2 p1,
+    produced by W/torch_model.py's Conv1d in fp32): the encoder's strided-view GEMM, alone."""
+    import os
+    ops = np.load(os.path.join(golden_dir, "ops.npz"))
+    x = ops["conv_x"]                                           # [2, 8, 20]
+    B, Cin, T = x.shape
+
+    def run(x_bct, w, b, stride):
+        Bn, Ci, Tn = x_bct.shape
+        pad = np.zeros((Bn * (Tn + 2) * Ci + 512,), dtype=np.float16)
+        pad[:Bn * (Tn + 2) * Ci].reshape(Bn, Tn + 2, Ci)[:, 1:Tn + 1] = x_bct.transpose(0, 2, 1)
+        Cout = w.shape[0]
+        wg = np.zeros((128, W.conv_weight_as_gemm(w).shape[1]), dtype=np.float16)      # C_out padded to the GEMM's 128-column tile
+        wg[:Cout] = W.conv_weight_as_gemm(w)
+        bg = np.zeros(128, dtype=np.float16)
+        bg[:Cout] = b
+        To = Tn // stride
+        out = torch.zeros((Bn, To, 128), dtype=torch.float16, device="cuda")
+        xd, wd, bd = dev(pad), dev(wg), dev(bg)
+        native.check(lib.wm_conv1d_gelu(xd.data_ptr(), Bn, Tn, Ci, wd.data_ptr(), wg.shape[1], bd.data_ptr(), 128, stride, 1,
+                                        out.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        assert float(out[:, :, Cout:].abs().max()) == 0.0       # GELU(0 . x + 0) = 0 in the padding channels
+        return out[:, :, :Cout].float().cpu().numpy().transpose(0, 2, 1)          # back to [B, C, T]
+
+    y1 = run(x.astype(np.float16), ops["conv1_w"], ops["conv1_b"], 1)
+    assert np.abs(y1 - ops["conv1_out"]).max() < 4e-3           # fp16 inputs / weights / output against the fp32 reference
+    y2 = run(ops["conv1_out"].astype(np.float16), ops["conv2_w"], ops["conv2_b"], 2)
+    assert y2.shape == ops["conv2_out"].shape and np.abs(y2 - ops["conv2_out"]).max() < 4e-3
+
+
+def test_argmax_first_index_wins(lib):
+    r = rng(3)
+    V = 51865
+    lg = (r.standard_normal((5, V)) * 2).astype(np.float16)
+    lg[1, 777] = lg[1, 40000] = np.float16(30.0)                # a tie: the first index wins (torch.argmax)
+    lg[2, V - 1] = np.float16(31.0)
+    lg[3, :] = np.float16(-np.inf); lg[3, 9] = np.float16(-5.0)
+    d = dev(lg)
+    ids = torch.full((5,), -1, dtype=torch.int32, device="cuda")
+    native.check(lib.wm_argmax(d.data_ptr(), V, 5, V, ids.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    want = torch.from_numpy(lg.astype(np.float32)).argmax(-1).tolist()
+    assert ids.tolist() == want and want[1] == 777 and want[2] == V - 1 and want[3] == 9
 
 
 # --------------------------------------------------------------------------------------- skinny GEMM

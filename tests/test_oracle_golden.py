@@ -195,3 +195,41 @@ def test_int8_kv_and_weight_only_model_close_to_fp16(fx):
     assert r1["self_kv"][0].dtype == torch.int8
     d = max(float((a - b).abs().max()) for a, b in zip(r0["logits"], r1["logits"]))
     assert d < 0.5, d          # quantisation noise, not garbage (logit std is ~1.5)
+
+
+# ---- a REAL Whisper shape (tiny.en width / heads / 1500 audio positions / gpt2 vocabulary), from the reference ---------
+@pytest.fixture(scope="module")
+def fx_tiny(golden_dir):
+    return np.load(os.path.join(golden_dir, "model_tiny_en_shape.npz"))
+
+
+def _run_tiny(fx, act):
+    dims = _dims(fx)
+    sd = synthetic_state_dict(dims, int(fx["seed"]))
+    mel = synthetic_mel(int(fx["batch"]), 2 * dims.n_audio_ctx, dims.n_mels, int(fx["mel_seed"]))
+    with torch.no_grad():
+        r = greedy_reference_run(OracleModel(dims, sd, OracleConfig(act=act)), mel, fx["prompt"].tolist(), int(fx["n_steps"]))
+    last = np.stack([l[:, -1].numpy() for l in r["logits"]], axis=1)            # [B, n_steps, V]
+    return dims, r, last
+
+
+@pytest.mark.parametrize("tag,act,tol_x,tol_l", [("f32", "float32", 1e-4, 2e-4), ("f16", "float16", 2e-2, 3e-2)])
+def test_tiny_en_shape_matches_reference(fx_tiny, tag, act, tol_x, tol_l):
+    """1500 keys, 6 heads, 384 wide, 51 864 tokens: the shapes the MICRO fixture cannot reach.  The reference
+    (W/torch_model.py) produced the rows / top-64 logits stored here; the oracle must reproduce them."""
+    fx = fx_tiny
+    dims, r, last = _run_tiny(fx, act)
+    assert (dims.n_audio_ctx, dims.n_audio_head, dims.n_audio_state, dims.n_vocab) == (1500, 6, 384, 51864)
+    rows = fx["rows"]
+    assert np.abs(r["xa"].numpy()[:, rows] - fx[f"{tag}_xa"].astype(np.float32)).max() < tol_x
+    for key, layer, kv in (("cross_k0", 0, 0), ("cross_v0", 0, 1), ("cross_vL", -1, 1)):
+        got = _heads_to_flat(r["cross_kv"][layer][:, kv]).numpy()[:, rows]
+        assert np.abs(got - fx[f"{tag}_{key}"].astype(np.float32)).max() < tol_x, key
+    top = fx[f"{tag}_top_ids"].astype(np.int64)
+    got_top = np.take_along_axis(last, top, axis=-1)
+    assert np.abs(got_top - fx[f"{tag}_top_logits"]).max() < tol_l
+    # nothing outside the stored top-64 overtakes them, and the whole row agrees in aggregate
+    assert (np.sort(last, axis=-1)[..., -64:].min(-1) >= fx[f"{tag}_top_logits"].min(-1) - tol_l).all()
+    np.testing.assert_allclose(np.abs(last).sum(-1, dtype=np.float64), fx[f"{tag}_logit_checksum"], rtol=2e-4 if tag == "f32" else 5e-3)
+    assert r["ids"].tolist() == fx[f"{tag}_ids"].tolist()
+    assert float(fx[f"{tag}_margins"].min()) > 2 * tol_l          # the ids are not near-ties: the equality above is meaningful

@@ -212,3 +212,29 @@ def test_summarize_dataset_discovery_and_scoring(golden_dir, tmp_path):
     assert S.score(["HE COULD WAIT NO LONGER"], ["HE COULD WEIGHT NO LONGER"]) == pytest.approx(0.2)
     args = S.parse_arguments(["--test_trt_llm", "--engine_dir", "e", "--dataset_dir", "d"])
     assert args.test_trt_llm and not args.test_torch and args.data_type == "fp16" and args.checkpoint_file == "./large-v2.pt"
+
+
+# ---- BPE against an implementation that is not ours ---------------------------------------------------------------------
+def test_bpe_encode_matches_independent_implementation_and_known_gpt2_ids(golden_dir):
+    """tokenizer.py's byte-pair encoder on the vendored Whisper vocabularies (assets/ASSETS.md) against
+    (1) ids produced by HuggingFace `tokenizers` loaded with the same ranks (oracle/gen_golden_bpe.py: an
+    independent BPE -- byte-level pre-tokeniser, merges by priority), 440 strings per vocabulary (LibriSpeech
+    transcripts in three casings, hand-written punctuation / unicode / whitespace cases, seeded random strings);
+    (2) published GPT-2 encodings (the English-only vocabulary IS GPT-2's) written down by hand.
+    The reference delegates this to the tiktoken wheel (W/tokenizer.py:125-317)."""
+    import json
+    import tokenizer as T
+    assets = os.path.join(os.path.dirname(os.path.abspath(T.__file__)), "assets")
+    with open(os.path.join(golden_dir, "tokenizer_bpe.json"), encoding="utf-8") as f:
+        fx = json.load(f)
+    for name, multilingual in (("multilingual", True), ("gpt2", False)):
+        tk = T.Tokenizer.from_vocab(os.path.join(assets, name + ".tiktoken"), multilingual)
+        assert tk.n_base == (50257 if multilingual else 50256)
+        bad = [(text, tk.encode(text), ids) for text, ids in fx[name] if tk.encode(text) != ids]
+        assert not bad, bad[:3]
+        for text, ids in fx[name][:60]:
+            assert tk.decode(ids) == text
+    gp = T.Tokenizer.from_vocab(os.path.join(assets, "gpt2.tiktoken"), False)
+    for text, ids in fx["gpt2_known"]:
+        assert gp.encode(text) == ids, text
+    assert sum(len(ids) for _, ids in fx["multilingual"]) > 10000          # not a vacuous fixture
