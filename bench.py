@@ -95,51 +95,113 @@ def build_engines(args, out_dir: Path):
     return time.time() - t0
 
 
-def cpu_baseline(args, decode_steps: int):
-    """The oracle (kind "port": our CPU restatement of the reference's PyTorch path, pinned to the
-    reference by tests/golden) timed on the host cores, fp32 mode, batch 1, on a BOUNDED sample:
-    a model of the same width with 4 encoder and 8 decoder layers is run and the per-layer time is
-    scaled to the full depth (layers are identical in cost; the depth-independent logits matmul is
-    timed separately and counted once)."""
-    from oracle.whisper_oracle import Dims, OracleConfig, OracleModel, synthetic_mel
+def cpu_baseline(args, decode_steps: int, time_cap_s: float = 150.0):
+    """The oracle (kind "port": our CPU restatement of the reference's PyTorch path, pinned to the reference by
+    tests/golden) timed on the host cores: ONE clip through the whole path at FULL depth in the reference's fp16-input
+    mode (fp32-stored parameters, fp16 activations, W/torch_model.py:25-45 -- how W/summarize.py:81-84,121 runs it) --
+    encoder, cross K/V, language-ID pass, 3-token prefill and the greedy steps.  The decode loop is timed for as many
+    of the `decode_steps` tokens as fit in the time cap (every step costs the same: the per-token time of the measured
+    steps is applied to the rest, and `sample` says how many were measured)."""
+    from oracle.whisper_oracle import Dims, OracleConfig, OracleModel
     import synthetic
-    full = dict(synthetic.DIMS[args.model])
-    ne, nd = min(4, full["n_audio_layer"]), min(8, full["n_text_layer"])
+    d = dict(synthetic.DIMS[args.model])
     cores = min(os.cpu_count() or 1, 32)      # torch's CPU kernels stop scaling (and regress) far below 256 threads
     torch.set_num_threads(cores)
-    d = dict(full, n_audio_layer=ne, n_text_layer=nd)
     dims = Dims(**d)
-    model = OracleModel(dims, synthetic.synthetic_state_dict(d, args.seed), OracleConfig(act="float32"))
-    mel = synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 1234)
-    emb = model.p["decoder.token_embedding.weight"]
+    # same distributions as the engines' weights, drawn on the GPU (seconds instead of minutes for 1.5e9 values), moved to the host
+    sd = synthetic.synthetic_state_dict(d, args.seed, device="cuda" if torch.cuda.is_available() else None)
+    sd = {k: v.cpu() for k, v in sd.items()}
+    model = OracleModel(dims, sd, OracleConfig(act="float16"))
+    del sd
+    mel = synthetic.synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 1234)
+    t_start = time.perf_counter()
     with torch.no_grad():
         t = time.perf_counter(); xa = model.encoder(mel); t_enc = time.perf_counter() - t
         t = time.perf_counter(); ckv = model.cross_kv(xa); t_ckv = time.perf_counter() - t
-        tok = torch.tensor([[50258, 50259, 50359]]) % dims.n_vocab
-        t = time.perf_counter(); logits, kv = model.decoder(tok, ckv, None); t_pre = time.perf_counter() - t
-        n_meas = 4
-        t = time.perf_counter()
-        for _ in range(n_meas):
+        sot = dims.n_vocab - 1607                          # <|startoftranscript|> of either vocabulary
+        t = time.perf_counter(); model.decoder(torch.tensor([[sot]]), ckv, None); t_lang = time.perf_counter() - t
+        t = time.perf_counter(); logits, kv = model.decoder(torch.tensor([[sot, sot + 1, sot + 101]]), ckv, None); t_pre = time.perf_counter() - t
+        n_meas, t_loop = 0, 0.0
+        while n_meas < decode_steps - 1 and (n_meas < 4 or time.perf_counter() - t_start < time_cap_s):
+            t = time.perf_counter()
             logits, kv = model.decoder(logits[:, -1:].argmax(-1), ckv, kv)
-        t_step = (time.perf_counter() - t) / n_meas
-        x1 = torch.randn(1, 1, dims.n_text_state)
-        t = time.perf_counter()
-        for _ in range(n_meas):
-            _ = x1 @ emb.t()
-        t_logits = (time.perf_counter() - t) / n_meas
-    se, sd = full["n_audio_layer"] / ne, full["n_text_layer"] / nd
-    t_enc_full, t_ckv_full = t_enc * se, t_ckv * sd
-    t_step_full = max(t_step - t_logits, 0.0) * sd + t_logits
-    t_pre_full = max(t_pre - 3 * t_logits, 0.0) * sd + 3 * t_logits
-    total = t_enc_full + t_ckv_full + t_pre_full + t_step_full + decode_steps * t_step_full   # + 1-token language-ID pass
+            t_loop += time.perf_counter() - t
+            n_meas += 1
+    t_step = t_loop / max(n_meas, 1)
+    total = t_enc + t_ckv + t_lang + t_pre + (decode_steps - 1) * t_step
     return {
         "value": round(decode_steps / total, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
         "rtf": round(total / 30.0, 3),
-        "sample": (f"oracle fp32, batch 1, {args.model} width: {ne}/{full['n_audio_layer']} encoder layers "
-                   f"({t_enc:.2f}s), {nd}/{full['n_text_layer']} cross-K/V + decoder layers (cross-K/V {t_ckv:.2f}s, "
-                   f"prefill {t_pre:.2f}s, {n_meas} decode steps at {t_step:.3f}s, logits matmul {t_logits:.3f}s), "
-                   f"per-layer time scaled to full depth and to {decode_steps} tokens"),
+        "sample": (f"oracle, fp16-input mode, batch 1, {args.model} at full depth ({dims.n_audio_layer}+{dims.n_text_layer} layers): "
+                   f"encoder {t_enc:.2f}s, cross-K/V {t_ckv:.2f}s, language-ID pass {t_lang:.2f}s, prefill {t_pre:.2f}s, "
+                   f"{n_meas} of {decode_steps - 1} greedy steps measured at {t_step:.3f}s each"
+                   + ("" if n_meas == decode_steps - 1 else f" (time cap {time_cap_s:.0f}s; the rest priced at that rate)")),
     }
+
+
+def pmc_traffic(group: int, kv_bytes: int) -> dict:
+    """`roofline.traffic`: HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE pass whose summary is committed under
+    profiles/ (newest profiles/*_pmc_cross_attn.json: {"fetch_bytes_per_utterance_layer": ..., "source": ...})."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_cross_attn.json")))
+    if not files or kv_bytes != 2:
+        return {"traffic": None, "traffic_source": None}
+    with open(files[-1]) as f:
+        rec = json.load(f)
+    return {"traffic": int(round(group * rec["fetch_bytes_per_utterance_layer"])), "traffic_source": os.path.relpath(files[-1], ROOT)}
+
+
+def in_situ_probe(dec, lib, xa, B: int, n_micro: int, algo_bytes: int, steps: int = 20) -> dict:
+    """Durations of the cross-attention launches as the decode loop runs them: replayed from the captured graphs, the
+    utterance groups' launches and short-kernel chains sharing the chip.  A 1-thread stamp kernel before and after every
+    launch writes the device wall clock (wm_debug_timeline); the graphs are re-captured with the stamps for this probe
+    and dropped afterwards."""
+    import native
+    st = dec._state[B]
+    st["graphs"].clear()
+    cap = n_micro * 2 * dec.decoder_config["num_layers"] * (steps + 4)
+    buf = torch.zeros(1 + 3 * cap, dtype=torch.int64, device=xa.device)
+    keep = dec.sample_len
+    native.check(lib.wm_debug_timeline(buf.data_ptr(), cap))
+    try:
+        dec.sample_len = steps
+        dec.main_loop(xa, ignore_eot=True)
+        torch.cuda.synchronize()
+    finally:
+        native.check(lib.wm_debug_timeline(None, 0))
+        dec.sample_len = keep
+        st["graphs"].clear()
+    n = min(int(buf[0].item()) & 0xffffffff, cap)
+    ev = buf[1:1 + 3 * n].view(-1, 3).cpu().numpy()
+    durs, gaps, spans = [], [], []
+    skip = 2 * dec.decoder_config["num_layers"]            # the eager prefill and the captured step
+    for tag in sorted(set(ev[:, 0].tolist())):
+        e = ev[ev[:, 0] == tag]
+        e = e[np.argsort(e[:, 2], kind="stable")]
+        starts, ends = e[e[:, 1] % 2 == 0][:, 2], e[e[:, 1] % 2 == 1][:, 2]
+        m = min(len(starts), len(ends))
+        starts, ends = starts[skip:m], ends[skip:m]
+        if len(starts) < 2:
+            continue
+        durs.append((ends - starts) / 100.0)               # wall_clock64 ticks of 10 ns -> us
+        gaps.append((starts[1:] - ends[:-1]) / 100.0)
+        spans += [(int(t), 1) for t in starts] + [(int(t), -1) for t in ends]
+    if not durs:
+        return {}
+    spans.sort()
+    level, prev, acc = 0, None, {}
+    for t, d in spans:
+        if prev is not None:
+            acc[level] = acc.get(level, 0) + (t - prev)
+        level, prev = level + d, t
+    tot = float(sum(acc.values())) or 1.0
+    dur_us = float(np.mean(np.concatenate(durs)))
+    return {"in_situ_launch_ms": round(dur_us * 1e-3, 5),
+            "in_situ_frac": round(algo_bytes / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "in_situ_chain_between_launches_ms": round(float(np.mean(np.concatenate(gaps))) * 1e-3, 5),
+            "in_situ_launches_in_flight": {str(k): round(v / tot, 3) for k, v in sorted(acc.items())},
+            "in_situ_note": f"graph-replayed launches, {n_micro} utterance groups sharing the chip; device-clock stamps around each launch "
+                            f"({int(sum(len(d) for d in durs))} launches over {steps} extra untimed decode steps)"}
 
 
 def launch_ranks(args) -> int:
@@ -223,10 +285,18 @@ def main():
     del mels
     width = dec.initial_token_length + T
 
+    loop_events = []            # (start, end) of every decode loop: torch events on the current stream, which main_loop
+    last = {}                   # joins with its group streams before it returns
+
     def step():
         xa = enc.get_audio_features_async(mel)
         dec.detect_language(xa)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         tokens, sum_lp, _ = dec.main_loop(xa, ignore_eot=True)
+        e1.record()
+        loop_events.append((e0, e1))
+        last["xa"] = xa
         return dp.gather_results(tokens, sum_lp, n_total, width, dec.tokenizer.eot)
 
     for _ in range(args.warmup):
@@ -237,6 +307,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    loop_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -245,6 +316,10 @@ def main():
         dist.barrier()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
 
+    decode_loop_ms = float(np.mean([a.elapsed_time(b) for a, b in loop_events])) if loop_events else None
+    weight_bytes = sum(sess.engine.weight_bytes for sess in (enc.session, dec.decoder_session, dec.cross_attn_session))
+    torch_bytes = torch.cuda.memory_allocated(dev)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
     roofline = None
     if not args.no_roofline:
         ms, cnt = C.c_double(), C.c_int64()
@@ -261,9 +336,9 @@ def main():
             roofline = {"kernel": "attn_cross_kernel (decode cross-attention)", "bound": "hbm",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        # HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE x 1024 x 2,
-                        # the gfx950 correction for 16 B/lane streaming reads): 7,686,860 B per utterance-layer
-                        "traffic": (group * 7686860 if kv_bytes == 2 else None), "traffic_source": "profiles/r1j_pmc_cross_attn.txt",
+                        # HBM bytes per launch: read from the PMC pass committed under profiles/ (FETCH_SIZE x 1024 x 2, the
+                        # gfx950 correction for 16 B/lane streaming reads, MI355X_MICROARCH.md), per utterance-layer
+                        **pmc_traffic(group, kv_bytes),
                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5),
                         "samples": int(cnt.value), "utterances_per_launch": group,
                         "note": "HIP events around the eager (language-ID pass) launches of the kernel inside the timed "
@@ -272,6 +347,15 @@ def main():
                                 f"decode graphs replay the same kernel and grid, there {n_micro} groups share the HBM.  The launch is "
                                 "persistent (<= 2 workgroups per CU, every workgroup the same number of items) and software-"
                                 "pipelined: with 8 of a CU's 32 wave slots it leaves room for the other groups' short kernels"}
+            # ---- the same kernel IN SITU: graph-replayed launches, the groups sharing the HBM (device-side stamps around
+            # every launch, wm_debug_timeline; measured on extra, untimed decode steps after the timed region) ----
+            roofline.update(in_situ_probe(dec, lib, last["xa"], B, n_micro, algo_bytes))
+            if decode_loop_ms is not None:
+                step_ms = decode_loop_ms / T
+                cross_bytes = B * dims["n_text_layer"] * H * 2 * Tk * 64 * kv_bytes          # B x 245.76 MB at large-v2
+                roofline.update({"decode_loop_ms": round(decode_loop_ms, 2), "decode_step_ms": round(step_ms, 3),
+                                 "decode_step_frac": round(cross_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "decode_step_note": "cross-K/V bytes of one token step for the whole batch / (decode loop time / tokens) / 8 TB/s"})
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -290,6 +374,12 @@ def main():
                        "batch_per_gpu": B, "decode_steps": T, "parallelism": f"dp{world} (utterance sharding, no "
                                                                             f"data-path collective)"},
             "engine_build_s": round(build_s, 1),
+            # what sits in HBM while the job runs: engine weights (hipMalloc'ed by the library: weight-only encoder / cross-K/V
+            # matrices are resident ONCE, as their fp16 expansion), everything torch allocated for the path (mel, encoder output,
+            # KV cache, cross K/V, logits, workspaces), and the device-level figure the reference's memory chart reports
+            # (README.md:178-180: 9.3-11.3 GB at batch 1 on an A10)
+            "hbm_bytes_resident": {"engine_weights": int(weight_bytes), "buffers": int(torch_bytes),
+                                   "device_in_use": int(total_b - free_b), "batch_per_gpu": B},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
