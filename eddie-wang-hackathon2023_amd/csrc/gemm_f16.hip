@@ -20,6 +20,8 @@
 // are 128 B; the 16-byte chunk c of row r is stored at position c ^ ((r >> 1) & 7) -- applied on
 // the per-lane SOURCE address, since the DMA writes LDS linearly -- which makes every
 // ds_read_b128 fragment read (16 rows x one chunk) hit 64 distinct banks.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -207,6 +209,10 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
 
 int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream) {
     using namespace f16gemm;
+    // every large-v2 shape (N a multiple of 256) takes the persistent kernel of gemm_f16p.hip: same arithmetic, bit for bit
+    // (scripts/lab/gemm_lab3.hip compares the two element by element); WM_GEMM_ROUND1=1 keeps this file's kernel (A/B runs)
+    static const bool round1 = [] { const char* v = getenv("WM_GEMM_ROUND1"); return v && v[0] == '1'; }();
+    if (!round1 && gemm_f16p_supports(p)) return launch_gemm_f16p(p, stream);
     WM_REQUIRE(p.N % 128 == 0, "gemm_f16: N=%d must be a multiple of 128", p.N);
     WM_REQUIRE(p.K % BK == 0, "gemm_f16: K=%d must be a multiple of %d", p.K, BK);
     WM_REQUIRE(p.lda % 8 == 0, "gemm_f16: lda=%d must be a multiple of 8 (16-byte loads)", p.lda);

@@ -1,0 +1,354 @@
+// fp16 x fp16 -> fp16 GEMM for the compute-bound stages, round-2 structure: PERSISTENT workgroups walking over
+// 256 x 256 output tiles with one continuous operand stream.
+//
+//   C = epilogue(A[M,K] . W[N,K]^T)      M = 1500 * batch rows, N % 256 == 0, K % 64 == 0
+//
+// Same arithmetic, same epilogues and the same callers as gemm_f16.hip (which stays for N % 256 != 0): TRT MatMul /
+// CutlassFpAIntBGemmRunner::gemm of the reference (fpA_intB_gemm_template.h:47-140), convolutions as strided views.
+//
+// Why a second structure.  On the encoder's shapes (K = 1280: 20 K-tiles of 64 per output tile) the round-1 kernel
+// spent 20-30 % of a tile outside its K loop (every workgroup started cold and ended with an epilogue nothing overlapped),
+// and inside the loop its matrix pipes idled half the time: the two waves of a SIMD ran the same program in step, so they
+// also read LDS, requested DMA and waited at the barrier in step, with nobody issuing MFMAs meanwhile.  Here:
+//   * one workgroup per CU lives for the whole launch and takes tiles from a static, XCD-aware list (each XCD owns a
+//     contiguous band of the tile list, its 32 workgroups work on 32 consecutive tiles: an A row panel is fetched from
+//     HBM once and re-used from that XCD's L2 by the N / 256 tiles of its row);
+//   * the operand stream is ONE sequence of 32-deep K stages (A 256 x 32 and W 256 x 32 halves = 32 KB) through a ring
+//     of 4 slots filled by global_load_lds (16 B per lane, 1 KiB per wave instruction).  The stream does not stop at
+//     a tile boundary: while a tile's last K steps and its epilogue run, the first stages of the NEXT tile are already
+//     in flight, so a tile never starts cold;
+//   * THE TWO WAVES OF A SIMD ALTERNATE.  A stage is multiplied in two halves of a wave's channels; each half is one
+//     "load" interval (fragments LDS -> registers, two DMA requests, the stage wait) and one "multiply" interval (16 MFMAs,
+//     nothing else), separated by raw s_barriers.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave
+//     multiplies while its partner loads, and the workgroup's barriers are the clock of that alternation;
+//   * waits are COUNTED: s_waitcnt vmcnt(6) -- everything but this wave's 6 youngest DMA pieces has landed -- once per
+//     stage, never 0 inside a tile; a stage is requested 7 intervals before its first read;
+//   * the epilogue's stores are fire-and-forget: all its global loads (the residual rows) are requested before its first
+//     store, the bias is read from LDS (copied there once per launch), and the first stage wait of the next tile allows the
+//     32 stores to stay in flight on top of the 6 DMA pieces -- the next tile's K loop starts at once.
+// Measured on MI355X, M = 192 000, random data, interleaved rounds in one process (scripts/lab/gemm_lab3.hip; results equal
+// the round-1 kernel's bit for bit): qkv (N 3840, K 1280, q/k scaling) 1008 vs 932 TFLOP/s, out (1280, 1280, residual)
+// 840 vs 764, mlp1 (5120, 1280, GELU) 839 vs 830, mlp2 (1280, 5120, residual) 1102 vs 1036; 8192 x 4096 x 4096: 1208 vs
+// 1122.  What did NOT help on the way (same harness): the deep ring alone, with both waves of a SIMD in step (one barrier
+// per stage, fragments software-pipelined through registers, 4 or 5 stages) was 4-8 % SLOWER than round 1 -- prefetch depth
+// was never the limit, the idle matrix pipe during the common load phase was.
+// LDS image of a stage: rows of 64 B (32 halves); the 16-byte chunk c of row r sits at position c ^ sw(r) with
+// sw(r) = (0, 3, 2, 1)[(r >> 2) & 3] -- applied to the per-lane SOURCE address, the DMA writes LDS linearly -- which makes
+// every ds_read_b128 fragment read (16 rows x one chunk per 16-lane group) conflict-free on the 64 banks.
+// MFMA operands are swapped (D = W . A^T) as in gemm_f16.hip: a lane ends up with 4 consecutive output channels of
+// one token row, so bias / GELU / residual / stores work on 8-byte pieces straight from the accumulator layout.
+#include <stdlib.h>
+
+#include <atomic>
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace wm {
+
+namespace f16p {
+constexpr int BM = 256, BN = 256, BK = 32, NWAVE = 8;
+constexpr int A_PART = BM * BK * 2, STAGE = (BM + BN) * BK * 2;      // 16 KB + 16 KB
+
+constexpr int MAX_N = 8192;                                          // the bias vector sits in LDS behind the ring: 16 KB
+}  // namespace f16p
+
+template <int STAGES, int ACT>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU
+__global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
+    using namespace f16p;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int WAIT = 4 * STAGES - 10;            // DMA pieces of this wave that may still be in flight when stage s + 1 must have landed
+    constexpr int N_STORES = 32;                     // store instructions of one wave's epilogue (8 pieces x 4)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;           // 4 (M) x 2 (N) waves, each 64 rows x 128 channels
+    const int g = lane >> 4;
+
+    // ---- this workgroup's tiles: XCD x owns the contiguous band [lo, hi) of the tile list (channel tile fastest) -----
+    const int nt_n = p.N / BN, nt_m = (p.M + BM - 1) / BM, n_tiles = nt_n * nt_m;
+    const int per_xcd = gridDim.x >> 3;              // gridDim.x is a multiple of 8
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
+    const int band = (n_tiles + 7) >> 3;
+    const int lo = min(n_tiles, xcd * band), hi = min(n_tiles, lo + band);
+    const int my_tiles = (hi - lo - j0 + per_xcd - 1) > 0 ? (hi - lo - j0 + per_xcd - 1) / per_xcd : 0;
+    if (my_tiles == 0) return;
+    const int nk = p.K / BK;                         // stages per tile
+    const int total_stages = my_tiles * nk;
+
+    // ---- loader: per stage this wave requests 2 A pieces and 2 W pieces of 16 rows x 64 B, as two "halves" (one A and one
+    // W piece each).  Addresses are a wave-uniform base per tile (advanced by 64 B per stage) plus a 32-bit lane offset ---
+    const unsigned char* a_base = nullptr;           // row `row0` of the tile, at the stage's K offset
+    const unsigned char* w_base = nullptr;
+    uint32_t a_lane[2], w_lane[2];
+    auto row_offset = [&](int gr) -> size_t {        // element offset of row gr of A (plain or a strided view)
+        return p.a_rows > 0 ? (size_t)(gr / p.a_rows) * p.a_bstride + (size_t)(gr % p.a_rows) * p.lda : (size_t)gr * p.lda;
+    };
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = (wid + NWAVE * q) * 16 + (lane >> 2);                       // row inside the 256-row part
+        const int c = (lane & 3) ^ ((4 - ((r >> 2) & 3)) & 3);                    // source chunk for this LDS slot
+        w_lane[q] = (uint32_t)r * (uint32_t)p.K * 2u + c * 16;
+    }
+    auto set_tile = [&](int t) {                     // loader -> tile number t of this workgroup, K offset 0
+        const int tile = lo + j0 + t * per_xcd;
+        const int tm = tile / nt_n, tn = tile - tm * nt_n;
+        const size_t off0 = row_offset(tm * BM);
+        a_base = (const unsigned char*)(p.A + off0);
+        w_base = (const unsigned char*)p.W + (size_t)tn * BN * p.K * 2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = (wid + NWAVE * q) * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((4 - ((r >> 2) & 3)) & 3);
+            int gr = tm * BM + r;
+            if (gr > p.M - 1) gr = p.M - 1;          // rows past the end re-read the last row (never stored)
+            a_lane[q] = (uint32_t)((row_offset(gr) - off0) * 2) + c * 16;
+        }
+    };
+    int load_ks = 0, load_tile = 0, issued = 0;      // stage whose pieces are requested next (issued = its stream number)
+    auto issue_half = [&](int half) {                // this wave's A piece and W piece number `half` of stream stage `issued`
+        if (issued >= total_stages) return;
+        unsigned char* slot = smem + (issued % STAGES) * STAGE + (wid + NWAVE * half) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
+                                         (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_lane[half]),
+                                         (__attribute__((address_space(3))) void*)(slot + A_PART), 16, 0, 0);
+        if (half == 1) {
+            a_base += BK * 2; w_base += BK * 2;
+            ++issued;
+            if (++load_ks == nk) { load_ks = 0; ++load_tile; if (load_tile < my_tiles) set_tile(load_tile); }
+        }
+    };
+    set_tile(0);
+    // what the steady-state schedule below assumes was requested before the first stage is multiplied: stages 0 .. STAGES - 3
+    // complete and the first half of stage STAGES - 2
+#pragma unroll 1
+    for (int s2 = 0; s2 < 2 * (STAGES - 2) + 1; ++s2) issue_half(s2 & 1);
+
+    // ---- fragment addresses inside a stage --------------------------------------------------------------------------
+    const int sw = (4 - ((lane >> 2) & 3)) & 3;                                   // the rows a lane reads have (r >> 2) & 3 = (lane >> 2) & 3
+    const int a_off = (wr * 64 + (lane & 15)) * 64 + ((g ^ sw) << 4);
+    const int b_off = A_PART + (wc * 128 + (lane & 15)) * 64 + ((g ^ sw) << 4);
+
+    float4v acc[4][8];
+    half8v af[4], bx[4];                             // A rows (4 blocks); W channels, first or second 64 of this wave (4 blocks)
+
+    // the whole bias vector (N <= 8192 channels, zeros without one) behind the ring: the epilogues read it with LDS loads,
+    // which do not go through the global-memory counter the DMA pipeline and the stores are timed with
+    {
+        h16* bias_lds0 = (h16*)(smem + STAGES * STAGE);
+        for (int c = tid; c < p.N; c += 512) bias_lds0[c] = p.bias ? p.bias[c] : (h16)0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // The two waves of a SIMD (w and w + 4) alternate: while one multiplies (16 MFMAs, nothing else), the other reads its next
+    // fragments from LDS, requests DMA pieces and waits -- the matrix pipe always has one wave feeding it.  The workgroup's
+    // barriers are the clock of that alternation; waves 4-7 run one barrier behind waves 0-3.
+    if (wid >= 4) __builtin_amdgcn_s_barrier();
+
+    int cons = 0;                                    // stream stage being multiplied
+    int ks = 0, t = 0;
+    bool after_epilogue = false;                     // the next stage wait has this wave's epilogue stores in its queue
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    for (;;) {
+        const unsigned char* st = smem + (cons % STAGES) * STAGE;
+        // ---- first half of the channels: fragments, DMA requests | barrier | 16 MFMAs | barrier ------------------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + j * 1024);
+        issue_half(1);                               // completes stage cons + STAGES - 2
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- second half ------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + (4 + j) * 1024);
+        issue_half(0);                               // opens stage cons + STAGES - 1
+        // Stage cons + 1 is read by waves 0-3 two barriers from here (one for waves 4-7): this wave's pieces of it must have
+        // landed before the next barrier.  Its last pieces were requested STAGES - 3 stages ago; WAIT younger requests may stay
+        // in flight -- plus, on the first stage after an epilogue, the epilogue's stores, which sit behind those pieces in the
+        // queue and must not be waited for here (they drain while the next stage is multiplied).
+        if (issued >= total_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT + N_STORES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT) : "memory");
+        after_epilogue = false;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx[j], af[i], acc[i][4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        ++cons;
+        if (++ks < nk) continue;
+
+        // ================================ epilogue (as gemm_f16.hip) =====================================================
+        const int tile = lo + j0 + t * per_xcd;
+        const int tm = tile / nt_n, tn = tile - tm * nt_n;
+        const int row0 = tm * BM, col0 = tn * BN;
+        // every lane-dependent quantity of the epilogue is derived from `le`, which the compiler cannot see through: nothing
+        // of the epilogue's address arithmetic is hoisted out of the tile loop into registers the K loop needs
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int ge = le >> 4, rl = le & 15;
+        const bool scale_cols = p.colscale_n > 0;
+        const int colw = col0 + wc * 128 + ge * 4;                      // this lane's first column
+        // Every global LOAD of the epilogue precedes every STORE: the memory counter is in order, so a load requested behind a
+        // piece's stores could only be waited for together with them.  The bias comes from LDS (copied there once per launch),
+        // the residual rows (64 registers) are all requested up front; then nothing but arithmetic and stores, piece by piece
+        // (one piece = one 16-row block x 64 channels: few temporaries alive at a time).
+        const h16* bias_lds = (const h16*)(smem + STAGES * STAGE) + col0 + wc * 128 + ge * 4;
+        auto finish = [&](auto res_tag) {
+            constexpr bool RES = decltype(res_tag)::value;
+            half4v r4[RES ? 4 : 1][RES ? 8 : 1];
+            if constexpr (RES) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + wr * 64 + i * 16 + rl;
+                    const int rowc = row < p.M ? row : p.M - 1;
+                    const h16* rrow = p.residual + (size_t)(p.res_mod > 0 ? rowc % p.res_mod : rowc) * p.ldr + colw;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r4[i][j] = *(const half4v*)(rrow + j * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + wr * 64 + i * 16 + rl;
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    const int colp = colw + jh * 64;
+                    float v[4][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const half4v b4 = *(const half4v*)(bias_lds + jh * 64 + j * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[j][r] = r16(acc[i][jh * 4 + j][r] + (float)b4[r]);      // the Linear's fp16 output
+                    }
+                    if (ACT == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[j][r] = r16(gelu_erf(v[j][r]));
+                    } else if (ACT == 2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[j][r] = r16(gelu_tanh(v[j][r]));
+                    }
+                    if (scale_cols) {                                           // q, k * d^-0.25 (torch_model.py:93-95)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float sc = (colp + j * 16 < p.colscale_n) ? p.colscale : 1.0f;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[j][r] = r16(v[j][r] * sc);
+                        }
+                    }
+                    if constexpr (RES) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[j][r] += (float)r4[i][jh * 4 + j][r];
+                    }
+                    if (row < p.M) {
+                        if (p.out_mode == 0) {
+                            h16* crow = p.C + (p.c_rows > 0 ? (size_t)(row / p.c_rows) * p.c_bstride + (size_t)(row % p.c_rows) * p.ldc
+                                                            : (size_t)row * p.ldc) + colp;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                *(half4v*)(crow + j * 16) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
+                        } else {       // head-split [B, 2, H, T, 64] (whisper/model.py:519); a lane's 4 channels stay inside one head
+                            const int HC = p.hs_H * 64;
+                            const int bb = row / p.hs_T, tt = row % p.hs_T;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int col = colp + j * 16;
+                                const int kv = p.hs_kv < 0 ? col / HC : p.hs_kv, cc = p.hs_kv < 0 ? col % HC : col;
+                                const size_t off = ((((size_t)bb * 2 + kv) * p.hs_H + (cc >> 6)) * p.hs_T + tt) * 64 + (cc & 63);
+                                if (p.q8_inv_scale > 0.f) {      // int8 cross K/V (opt-in): the fp16 result, quantised like the self-attention cache
+                                    char4 q;
+                                    q.x = (signed char)fminf(127.f, fmaxf(-128.f, rintf(r16(v[j][0]) * p.q8_inv_scale)));
+                                    q.y = (signed char)fminf(127.f, fmaxf(-128.f, rintf(r16(v[j][1]) * p.q8_inv_scale)));
+                                    q.z = (signed char)fminf(127.f, fmaxf(-128.f, rintf(r16(v[j][2]) * p.q8_inv_scale)));
+                                    q.w = (signed char)fminf(127.f, fmaxf(-128.f, rintf(r16(v[j][3]) * p.q8_inv_scale)));
+                                    *(char4*)((signed char*)p.C + off) = q;
+                                } else {
+                                    *(half4v*)(p.C + off) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if (p.residual) finish(std::true_type{}); else finish(std::false_type{});
+        // the store count the next stage wait adds is exact only for a tile without an M tail (rows past M skip their stores)
+        if (row0 + BM <= p.M) after_epilogue = true; else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ks = 0;
+        if (++t == my_tiles) break;
+        zero_acc();
+    }
+    if (wid < 4) __builtin_amdgcn_s_barrier();       // waves 4-7 ran one barrier behind
+}
+
+bool gemm_f16p_supports(const GemmBigParams& p) {
+    return p.N % f16p::BN == 0 && p.N <= f16p::MAX_N && p.K % 64 == 0 && p.K >= 128;
+}
+
+int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
+    using namespace f16p;
+    WM_REQUIRE(p.N % BN == 0 && p.N <= MAX_N, "gemm_f16p: N=%d must be a multiple of %d, <= %d", p.N, BN, MAX_N);
+    WM_REQUIRE(p.K % 64 == 0 && p.K >= 128, "gemm_f16p: K=%d must be a multiple of 64, >= 128", p.K);
+    WM_REQUIRE(p.lda % 8 == 0, "gemm_f16p: lda=%d must be a multiple of 8 (16-byte loads)", p.lda);
+    WM_REQUIRE(p.ldc % 4 == 0 && p.ldr % 4 == 0, "gemm_f16p: ldc/ldr must be multiples of 4 (8-byte epilogue accesses)");
+    WM_REQUIRE(p.M > 0, "gemm_f16p: empty M");
+    WM_REQUIRE(p.act >= 0 && p.act <= 2, "gemm_f16p: act=%d", p.act);
+    constexpr int STAGES = 4;                        // 128 KB ring + 16 KB bias of the CU's 160 KB (5 stages measured no faster)
+    static std::atomic<int> n_cu_dev[64];
+    int dev = 0;
+    WM_CHECK_HIP(hipGetDevice(&dev));
+    const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+    int n_cu = n_cu_dev[slot].load(std::memory_order_relaxed);
+    using Kern = void (*)(GemmBigParams);
+    static const Kern kerns[3] = {gemm_f16p_kernel<STAGES, 0>, gemm_f16p_kernel<STAGES, 1>, gemm_f16p_kernel<STAGES, 2>};
+    constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE + MAX_N * 2;
+    if (n_cu == 0) {
+        int v = 0;
+        WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+        for (int a = 0; a < 3; ++a)
+            WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        n_cu_dev[slot].store(n_cu, std::memory_order_relaxed);
+    }
+    // one workgroup per CU (a workgroup holds 128 of the CU's 160 KB of LDS), a multiple of 8 so that every XCD gets the same count
+    const int n_tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    int grid = (n_cu / 8) * 8;
+    if (grid < 8) grid = 8;
+    const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(kerns[p.act], dim3(grid), dim3(512), LDS_BYTES, stream, p);
+    WM_LAUNCH_CHECK(stream, "gemm_f16p");
+    return 0;
+}
+
+}  // namespace wm

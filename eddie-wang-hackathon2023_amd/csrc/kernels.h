@@ -21,7 +21,9 @@ struct GemmBigParams {
     int a_rows; long a_bstride;
     int c_rows; long c_bstride;              // same for C (out_mode 0 only)
 };
-int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // 256x256 (256x128) tile, LDS-DMA ring
+int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // dispatch: gemm_f16p.hip when it supports the shape, else gemm_f16.hip's kernel
+int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream);     // persistent 256x256 tiles, continuous LDS-DMA stream, alternating wave groups
+bool gemm_f16p_supports(const GemmBigParams& p);
 int launch_dequant_w8(const int8_t* q, const h16* scale, h16* out, int N, int K, hipStream_t stream);
 
 // ---------------------------------------------------------------- gemm_skinny.hip
