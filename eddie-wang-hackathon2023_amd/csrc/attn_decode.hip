@@ -47,6 +47,26 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int T = p.t_dev ? *p.t_dev : p.T;      // device-resident step counter (graph replay) or host value
     const int C = p.H * 64;
+    // The kernel is a chain of dependent memory round trips (this call's q / k / v sums, the cached K rows, the cached V rows)
+    // and at small batches nothing else: the first 64 K rows (one per lane) and the first 32 V rows (lane = dim) do not depend on
+    // q, so they are requested before anything is waited for -- for T <= 32 cached tokens the whole kernel is one round trip.
+    const unsigned char* pastK0 = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(0 * p.H + h) * p.past_cap * 64) * (I8 ? 1 : 2);
+    const unsigned char* pastV0 = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(1 * p.H + h) * p.past_cap * 64) * (I8 ? 1 : 2);
+    // (no per-element test around a load: hipcc would branch around each and wait for it before the next; rows past the
+    // end re-read the last cached row instead, their values are never used)
+    uint4 kpre[I8 ? 4 : 8];
+    int8_t vpre8[32]; h16 vpre16[32];
+    if (T > 0) {                                 // wave-uniform
+        const int kr = min(lane, T - 1);
+#pragma unroll
+        for (int c = 0; c < (I8 ? 4 : 8); ++c) kpre[c] = ((const uint4*)(pastK0 + (size_t)kr * (I8 ? 64 : 128)))[c];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int vr = min(u, T - 1);
+            if (I8) vpre8[u] = ((const int8_t*)pastV0)[(size_t)vr * 64 + lane];
+            else vpre16[u] = ((const h16*)pastV0)[(size_t)vr * 64 + lane];
+        }
+    }
     const float t_dq = p.kv_scale;
     const float inv_t = 1.0f / p.kv_scale;
     const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.B * p.L * p.ldp;
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
                         const uint4* kr = (const uint4*)(pastK + (size_t)j * 64);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const uint4 w = kr[c];
+                            const uint4 w = j0 == 0 ? kpre[c] : kr[c];
                             const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
                         const half8v* kr = (const half8v*)(pastK + (size_t)j * 128);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
-                            const half8v w = kr[c];
+                            const half8v w = j0 == 0 ? __builtin_bit_cast(half8v, kpre[c]) : kr[c];
 #pragma unroll
                             for (int e = 0; e < 8; ++e)
                                 acc += (float)s_q[c * 8 + e] * r16((float)w[e] * ATTN_SCALE);
@@ -173,6 +193,10 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
         int j = 0;
         if (I8) {
             const int8_t* pv = (const int8_t*)pastV + lane;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)          // the prefetched rows (same ascending order as the loops below)
+                if (u < T) o += s_p[u] * r16((float)vpre8[u] * t_dq);
+            j = min(T, 32);
             for (; j + 32 <= T; j += 32) {        // 32 loads in flight per lane: the loop is HBM-latency bound
                 int8_t vq[32];
 #pragma unroll
@@ -190,6 +214,10 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
             for (; j < T; ++j) o += s_p[j] * r16((float)pv[(size_t)j * 64] * t_dq);
         } else {
             const h16* pv = (const h16*)pastV + lane;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)          // the prefetched rows (same ascending order as the loops below)
+                if (u < T) o += s_p[u] * (float)vpre16[u];
+            j = min(T, 32);
             for (; j + 32 <= T; j += 32) {
                 h16 vh[32];
 #pragma unroll
@@ -559,18 +587,29 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     }
 }
 
-// combine the key-range splits: softmax-weighted merge of (max, sum, unnormalised o)
+// combine the key-range splits: softmax-weighted merge of (max, sum, unnormalised o).  All of an item's partial results
+// are requested at once (lanes < nsplit: max and sum; every lane: its dim of each split's o), the factors travel by
+// shuffle -- one memory round trip instead of 3 x nsplit dependent ones (8 -> 2 us at batch 1, where this kernel runs
+// 32 times per token).  Sums are taken in split order, as before.
 __global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams p) {
     const int h = blockIdx.x, b = blockIdx.y, i = blockIdx.z, d = threadIdx.x;
     const float* w = p.ws + ((((size_t)b * p.H + h) * p.nsplit) * p.L + i) * 66;
     const size_t stride = (size_t)p.L * 66;
-    float m = -INFINITY;
-    for (int s = 0; s < p.nsplit; ++s) m = fmaxf(m, w[s * stride]);
+    float ms = w[min(d, p.nsplit - 1) * stride], ls = w[min(d, p.nsplit - 1) * stride + 1];
+    if (d >= p.nsplit) { ms = -INFINITY; ls = 0.f; }
+    float ov[16];                                 // (no per-element test around a load; splits past the end re-read the last one, weight 0)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) ov[s] = w[min(s, p.nsplit - 1) * stride + 2 + d];
+    const float m = wave_max(ms);
+    const float f = d < p.nsplit ? __expf(ms - m) : 0.f;
+    const float lf = ls * f;
     float den = 0.f, num = 0.f;
-    for (int s = 0; s < p.nsplit; ++s) {
-        const float f = __expf(w[s * stride] - m);
-        den += w[s * stride + 1] * f;
-        num += w[s * stride + 2 + d] * f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s < p.nsplit) {                       // wave-uniform
+            den += __shfl(lf, s);
+            num += ov[s] * __shfl(f, s);
+        }
     }
     p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + d] = (h16)(num / den);
 }

@@ -588,9 +588,36 @@ __global__ void stamp_kernel(long long* tl, int cap, long long tag, long long wh
     if (i < cap) { tl[1 + 3 * i] = tag; tl[2 + 3 * i] = what; tl[3 + 3 * i] = wall_clock64(); }
 }
 
+constexpr int SMALL_PATH_DEFAULT_ROWS = 4;
+// Small batches (M = B * L <= SMALL_PATH_DEFAULT_ROWS rows) take the fused path of gemv_small.hip: every Linear is ONE launch
+// that also applies the LayerNorm of its input rows and its own epilogue (bias / GELU / residual) -- 8 launches per layer
+// instead of 12, no fp32 slabs, no row kernels.  WM_SMALL_PATH=<rows> moves the switch (0: the big-batch kernels for every size).
+// (For more rows the same fusion was built into gemm_skinny.hip and measured: without a K split its 10-40 workgroups each
+// stage the whole activation block, 70 us per launch at M = 192 against 16 + 10 for the split GEMM + row kernel, and the
+// decode step at B = 576 went from 26.1 to 30.3 ms -- profiles/r2d_b576_fused_skinny_ks1_kernel_stats.csv.  Not kept.)
+int small_path_max_rows() {               // WM_SMALL_PATH=<rows>: the fused path serves M <= rows (0: never)
+    static const int rows = [] { const char* v = getenv("WM_SMALL_PATH"); int r = v ? atoi(v) : SMALL_PATH_DEFAULT_ROWS;
+                                 return r < 0 ? 0 : (r > GEMV_SMALL_MAX_M ? GEMV_SMALL_MAX_M : r); }();
+    return rows;
+}
+
 struct GroupStep {
     const wm_engine* e; const wm_decoder_io* io; DecWs w;
     int B, L, T, C, H, M;
+    bool small = false;                          // the fused small-batch path
+
+    // one Linear of the small-batch path.  mode as epilogue.h; ln_g != null: LayerNorm of the input rows (the residual stream)
+    // inside the kernel
+    int gemv(const Lin& l, const h16* A, int lda, int mode, const h16* ln_g, const h16* ln_b, h16* out16, int ld16, hipStream_t s) {
+        GemvSmallParams p{};
+        p.A = A; p.lda = lda; p.M = M; p.K = l.K; p.Wt = l.w; p.n_blocks = l.n_blocks; p.w8 = l.wcode; p.scale = l.s;
+        p.ln_g = ln_g; p.ln_b = ln_b;                // the kernel normalises the (few) input rows itself
+        p.mode = mode; p.bias = l.b; p.gelu_kind = e->gelu();
+        p.out32 = w.part; p.ld32 = l.N;
+        p.out16 = out16; p.ld16 = ld16; p.n_valid = l.N;
+        p.x = w.x; p.ldx = C;
+        return launch_gemv_small(p, s);
+    }
 
     Profiler* prof = nullptr;
 
@@ -610,6 +637,7 @@ struct GroupStep {
         WM_REQUIRE(C == H * 64, "head size must be 64");
         w = carve_decoder(e, B, L, io->workspace);
         WM_REQUIRE(io->workspace_bytes >= w.total, "decoder workspace too small: %zu < %zu", io->workspace_bytes, w.total);
+        small = M <= small_path_max_rows();
         return 0;
     }
 
@@ -627,6 +655,7 @@ struct GroupStep {
         EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
                        (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev};
         if (launch_embed(ep, s)) return 2;
+        if (small) return 0;                         // the first LayerNorm happens inside the qkv projection
         return launch_layernorm(w.x, C, M, C, e->dec[0].ln1g, e->dec[0].ln1b, w.xn, C, s);
     }
 
@@ -634,7 +663,10 @@ struct GroupStep {
     int pre_cross(int i, hipStream_t s) {
         const DecLayer& Lr = e->dec[i];
         int ks = 0;
-        if (skinny_all(Lr.qkv, w.xn, C, M, w.part, &ks, s)) return 2;
+        if (small) {
+            if (gemv(Lr.qkv, w.x, C, 0, Lr.ln1g, Lr.ln1b, nullptr, 0, s)) return 2;      // LN + qkv sums -> w.part [M][3C]
+            ks = 1;
+        } else if (skinny_all(Lr.qkv, w.xn, C, M, w.part, &ks, s)) return 2;
         AttnSelfParams p{};
         p.part = w.part; p.ksplit = ks; p.ldp = Lr.qkv.N; p.part_sstride = (long)M * Lr.qkv.N; p.bias = Lr.qkv.b;
         p.B = B; p.L = L; p.T = T; p.H = H;
@@ -648,6 +680,12 @@ struct GroupStep {
         p.amax = io->qkv_amax ? io->qkv_amax + i : nullptr;
         p.t_dev = io->n_past_dev;
         if (launch_attn_self(p, s)) return 2;
+        if (small) {
+            if (gemv(Lr.out, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;    // x += out(ctx)
+            if (gemv(Lr.cq, w.x, C, 0, Lr.lncg, Lr.lncb, nullptr, 0, s)) return 2;       // LN + q sums -> w.part [M][C]
+            cq_ks = 1;
+            return 0;
+        }
         if (skinny_all(Lr.out, w.ctx, C, M, w.part, &ks, s)) return 2;
         if (finish(Lr.out, ks, 0, Lr.lncg, Lr.lncb, w.xn, C, C, s)) return 2;
         if (skinny_all(Lr.cq, w.xn, C, M, w.part, &cq_ks, s)) return 2;
@@ -684,6 +722,11 @@ struct GroupStep {
         const DecLayer& Lr = e->dec[i];
         const wm_dims& d = e->dims;
         int ks = 0;
+        if (small) {
+            if (gemv(Lr.cout, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;
+            if (gemv(Lr.mlp1, w.x, C, 1, Lr.ln2g, Lr.ln2b, w.hid, 4 * C, s)) return 2;     // LN + GELU
+            return gemv(Lr.mlp2, w.hid, 4 * C, 2, nullptr, nullptr, nullptr, 0, s);
+        }
         if (skinny_all(Lr.cout, w.ctx, C, M, w.part, &ks, s)) return 2;
         if (finish(Lr.cout, ks, 0, Lr.ln2g, Lr.ln2b, w.xn, C, C, s)) return 2;
         if (skinny_all(Lr.mlp1, w.xn, C, M, w.part, &ks, s)) return 2;
@@ -696,6 +739,14 @@ struct GroupStep {
     // logits = ln(x) . E^T (fp16 out, whisper/model.py:288-290)
     int end(hipStream_t s) {
         const wm_dims& d = e->dims;
+        if (small) {
+            // the final LayerNorm as a launch of its own: 3 242 workgroups (16 vocabulary entries each) would all redo it
+            if (launch_layernorm(w.x, C, M, C, e->lnfg, e->lnfb, w.xn, C, s)) return 2;
+            GemvSmallParams p{};
+            p.A = w.xn; p.lda = C; p.M = M; p.K = C; p.Wt = e->emb_t; p.n_blocks = e->emb_blocks; p.w8 = 0;
+            p.mode = 3; p.out16 = (h16*)io->logits; p.ld16 = d.n_vocab; p.n_valid = d.n_vocab;
+            return launch_gemv_small(p, s);
+        }
         for (int r0 = 0; r0 < M; r0 += SKINNY_MAX_M) {
             GemmSkinnyParams p{};
             p.A = w.xn + (size_t)r0 * C; p.lda = C; p.M = (M - r0) < SKINNY_MAX_M ? (M - r0) : SKINNY_MAX_M; p.K = C;
@@ -897,6 +948,18 @@ int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_b
     return launch_gemm_skinny(p, (hipStream_t)stream);
 }
 int wm_gemm_skinny_default_ksplit(int M, int K, int n_blocks, int w8) { return skinny_default_ksplit(M, K, n_blocks, w8); }
+
+int wm_gemv_fused(const wm_gemv_io* io, wm_stream_t stream) {
+    WM_REQUIRE(io && io->a && io->wt, "wm_gemv_fused: null argument");
+    GemvSmallParams p{};
+    p.A = (const h16*)io->a; p.lda = io->lda; p.M = io->m; p.K = io->k; p.Wt = io->wt; p.n_blocks = io->n_blocks; p.w8 = io->w8;
+    p.scale = (const h16*)io->scale;
+    p.ln_g = (const h16*)io->ln_gamma; p.ln_b = (const h16*)io->ln_beta;
+    p.mode = io->mode; p.bias = (const h16*)io->bias; p.gelu_kind = io->gelu_kind;
+    p.out32 = io->out32; p.ld32 = io->ld32; p.out16 = (h16*)io->out16; p.ld16 = io->ld16; p.n_valid = io->n_valid;
+    p.x = (h16*)io->x; p.ldx = io->ldx;
+    return launch_gemv_small(p, (hipStream_t)stream);
+}
 
 int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta, void* out, int ldo,
                  wm_stream_t stream) {

@@ -1,0 +1,42 @@
+// The fused Linear epilogue of the small-batch decode path (gemv_small.hip): what the big-batch path's row kernel does
+// after the K slices are added, with the same rounding points.
+#pragma once
+#include "common.h"
+
+namespace wm {
+
+struct FusedEpilogue {
+    int mode;                    // 0: fp32 sums -> out32   1: fp16(gelu(fp16(y + bias))) -> out16
+                                 // 2: x = fp16(x + fp16(y + bias)) in place   3: fp16(y) -> out16, col < n_valid
+    const h16* bias; int gelu_kind;
+    float* out32; int ld32;
+    h16* out16; int ld16; int n_valid;
+    h16* x; int ldx;
+};
+
+// One 16 x 16 accumulator tile (MFMA C/D layout: lane -> channel nb * 16 + (lane & 15), rows mt * 16 + 4 (lane >> 4) + r)
+// whose values y[r] are the Linear's fp32 sums (scaled, K slices already combined).
+__device__ __forceinline__ void fused_epilogue_tile(const FusedEpilogue& e, int M, int nb, int mt, int lane, const float (&y)[4]) {
+    const int g = lane >> 4, col = nb * 16 + (lane & 15);
+    const float bias = (e.mode == 1 || e.mode == 2) && e.bias ? (float)e.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + g * 4 + r;
+        if (row >= M) continue;
+        if (e.mode == 0) {                             // raw sums for the attention kernels (they add the bias and round)
+            e.out32[(size_t)row * e.ld32 + col] = y[r];
+        } else if (e.mode == 3) {                      // logits: fp16(x . E^T), whisper/model.py:288-290
+            if (col < e.n_valid) e.out16[(size_t)row * e.ld16 + col] = (h16)y[r];
+        } else {
+            const float y16 = r16(y[r] + bias);                                       // the Linear's fp16 output
+            if (e.mode == 1) {
+                e.out16[(size_t)row * e.ld16 + col] = (h16)(e.gelu_kind == 2 ? gelu_tanh(y16) : gelu_erf(y16));
+            } else {                                   // mode 2: residual stream, in place
+                h16* xp = e.x + (size_t)row * e.ldx + col;
+                *xp = (h16)r16((float)*xp + y16);
+            }
+        }
+    }
+}
+
+}  // namespace wm

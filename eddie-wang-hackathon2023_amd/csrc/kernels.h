@@ -42,6 +42,25 @@ constexpr int SKINNY_MAX_M = 256;   // rows per launch of the weight-streaming G
 int launch_gemm_skinny(const GemmSkinnyParams& p, hipStream_t stream);
 int skinny_default_ksplit(int M, int K, int n_blocks, int w8);
 
+// ---------------------------------------------------------------- gemv_small.hip
+// One launch per Linear for small decode batches (M <= 32 rows): LayerNorm of the input rows inside the kernel, W read once,
+// K slices combined inside the workgroup, bias / GELU / residual in the epilogue.
+struct GemvSmallParams {
+    const h16* A; int lda; int M; int K;     // input rows: the residual stream x (with ln_g: LayerNorm'ed by the kernel) or ctx / hid
+    const void* Wt; int n_blocks; int w8;    // tile-linear weights, n_blocks = padded N / 16; w8: 0 fp16, 1 int8, 4 packed int4
+    const h16* scale;                        // [n_blocks*16] (weight-only)
+    int ksplit;                              // K slices = waves per workgroup, 1..16
+    const h16* ln_g; const h16* ln_b;        // non-null: LayerNorm of the input rows over K channels, eps 1e-5
+    int mode;                                // 0: fp32 sums -> out32 (attention kernels add bias, round)   1: fp16(gelu(fp16(y + bias))) -> out16
+                                             // 2: x = fp16(x + fp16(y + bias)) in place   3: fp16(y) -> out16, col < n_valid
+    const h16* bias; int gelu_kind;
+    float* out32; int ld32;
+    h16* out16; int ld16; int n_valid;
+    h16* x; int ldx;
+};
+constexpr int GEMV_SMALL_MAX_M = 32;
+int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
+
 // ---------------------------------------------------------------- rowops.hip
 struct RowFinishParams {
     // y = sum_s part[s][m][:] + bias ; y16 = fp16(y)

@@ -21,7 +21,7 @@ EXPORTS = (
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
     "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
-    "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
+    "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_gemv_fused", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
 )
 
 
@@ -55,6 +55,19 @@ class WmDecoderIO(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("qkv_amax", C.c_void_p),
         ("n_past_dev", C.c_void_p),
+    ]
+
+
+class WmGemvIO(C.Structure):
+    """wm_gemv_io (include/whisper_mi355.h)."""
+    _fields_ = [
+        ("a", C.c_void_p), ("lda", C.c_int32), ("m", C.c_int32), ("k", C.c_int32),
+        ("wt", C.c_void_p), ("n_blocks", C.c_int32), ("w8", C.c_int32), ("scale", C.c_void_p),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+        ("mode", C.c_int32), ("bias", C.c_void_p), ("gelu_kind", C.c_int32),
+        ("out32", C.c_void_p), ("ld32", C.c_int32),
+        ("out16", C.c_void_p), ("ld16", C.c_int32), ("n_valid", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
     ]
 
 
@@ -113,6 +126,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_gemm.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp, sz, vp]
     lib.wm_conv1d_gelu.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp, vp]
     lib.wm_argmax.argtypes = [vp, C.c_int64, i32, i32, vp, vp]
+    lib.wm_gemv_fused.argtypes = [C.POINTER(WmGemvIO), vp]
     lib.wm_gemm_skinny.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.wm_gemm_skinny_default_ksplit.argtypes = [i32, i32, i32, i32]
     lib.wm_layernorm.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp]

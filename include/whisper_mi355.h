@@ -173,6 +173,26 @@ int wm_argmax(const void* logits, int64_t row_stride, int batch, int n_vocab, in
 int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_blocks, int w8,
                    const void* scale, int ksplit, float* part, wm_stream_t stream);
 int wm_gemm_skinny_default_ksplit(int M, int K, int n_blocks, int w8);
+/* One Linear of a SMALL decode batch (m <= 32 rows) in one launch -- what the decoder engine runs per projection at the
+ * reference's own batch size of 1 (W/run.py:43-46): [LayerNorm of the input rows over k channels, eps 1e-5, when
+ * ln_gamma is given] -> a . W^T (W as for wm_gemm_skinny, read once; K split over the waves of a workgroup, combined in
+ * LDS) -> epilogue by `mode`:
+ *   0  out32[row*ld32 + col] = the fp32 sums, scaled, without bias (the decode attention kernels add bias and round)
+ *   1  out16 = fp16(gelu(fp16(y + bias)))                 (gelu_kind 1 erf, 2 tanh)
+ *   2  x = fp16(x + fp16(y + bias)) in place              (residual stream)
+ *   3  out16 = fp16(y), columns < n_valid                 (logits)
+ * Replaces weight_only_gemv_launcher + bias / gelu / residual / LayerNorm layers (weightOnlyMatrixVectorMultiplication.cu:
+ * 136-277,371-378; quantization/layer.py:311-312; functional.py:2044-2056; normalization.py:6-30).                      */
+typedef struct wm_gemv_io {
+    const void* a; int32_t lda, m, k;
+    const void* wt; int32_t n_blocks, w8; const void* scale;
+    const void* ln_gamma; const void* ln_beta;
+    int32_t mode; const void* bias; int32_t gelu_kind;
+    float* out32; int32_t ld32;
+    void* out16; int32_t ld16, n_valid;
+    void* x; int32_t ldx;
+} wm_gemv_io;
+int wm_gemv_fused(const wm_gemv_io* io, wm_stream_t stream);
 /* fp16 LayerNorm rows, fp32 statistics, eps 1e-5 (layernormKernels.cu:62-188). */
 int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta,
                  void* out, int ldo, wm_stream_t stream);

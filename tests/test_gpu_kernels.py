@@ -224,6 +224,94 @@ def test_gemm_skinny_rows_do_not_depend_on_the_launch(lib, w8):
         assert torch.equal(run(M), full[:, :M]), M
 
 
+@pytest.mark.parametrize("M,w8,K,N", [(1, 1, 1280, 1280), (3, 1, 1280, 3840), (8, 0, 1280, 1280), (16, 4, 1280, 1280), (20, 1, 5120, 1280),
+                                        (32, 0, 1280, 1280), (1, 1, 5120, 1280), (32, 4, 5120, 1280)])
+def test_gemv_fused_small_batch_path(lib, M, w8, K, N):
+    """wm_gemv_fused (csrc/gemv_small.hip), the one-launch Linear of the small-batch decode path, mode by mode, against
+    fp32 restatements with the reference's rounding points (fp16 Linear output, then the element-wise op in fp32, rounded):
+      * mode 0: the fp32 sums against numpy and against the slab form (wm_gemm_skinny, slabs added): same products, another
+        order of the K slices -> a few fp32 ulps;
+      * the kernel's own LayerNorm of the input rows against torch's fp32 LayerNorm of the same fp16 rows;
+      * mode 1 (bias + erf GELU), mode 2 (bias + residual in place: exact), mode 3 (logits, ragged vocabulary edge);
+      * a row's result does not depend on how many rows share the launch (bit for bit)."""
+    r = rng(700 + M + w8 + K)
+    A = (r.standard_normal((M, K)) * 0.7 + 0.2).astype(np.float16)
+    Wf = (r.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    bias = (r.standard_normal(N) * 0.1).astype(np.float16)
+    if w8 == 4:
+        q, sc = symmetric_quantize_int4(Wf); tiles = W.tile_linear_int4(q)
+        Wd = q.astype(np.float32) * sc.astype(np.float32)[:, None]
+    elif w8:
+        q, sc = symmetric_quantize_int8(Wf); tiles = W.tile_linear(q)
+        Wd = q.astype(np.float32) * sc.astype(np.float32)[:, None]
+    else:
+        sc, tiles, Wd = None, W.tile_linear(Wf), Wf.astype(np.float32)
+    t_dev, s_dev, a_dev, b_dev = dev(tiles.view(np.uint8)), (dev(sc) if sc is not None else None), dev(A), dev(bias)
+
+    def call(mode, a, m=M, **kw):
+        io = native.WmGemvIO()
+        io.a, io.lda, io.m, io.k = a.data_ptr(), K, m, K
+        io.wt, io.n_blocks, io.w8 = t_dev.data_ptr(), N // 16, w8
+        io.scale = s_dev.data_ptr() if s_dev is not None else None
+        io.mode, io.bias, io.gelu_kind = mode, b_dev.data_ptr(), 1
+        for k_, v in kw.items():
+            setattr(io, k_, v)
+        native.check(lib.wm_gemv_fused(C.byref(io), stream()), "wm_gemv_fused")
+        torch.cuda.synchronize()
+
+    # ---- mode 0
+    out32 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    call(0, a_dev, out32=out32.data_ptr(), ld32=N)
+    want = A.astype(np.float32) @ Wd.T
+    scale_ = max(1.0, np.abs(want).max())
+    assert np.abs(out32.cpu().numpy() - want).max() < 2e-5 * scale_ * np.sqrt(K / 1280)
+    ks = lib.wm_gemm_skinny_default_ksplit(M, K, N // 16, w8)
+    part = torch.zeros((ks, M, N), dtype=torch.float32, device="cuda")
+    native.check(lib.wm_gemm_skinny(a_dev.data_ptr(), K, M, K, t_dev.data_ptr(), N // 16, w8,
+                                    s_dev.data_ptr() if s_dev is not None else None, ks, part.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    assert float((out32 - part.sum(0)).abs().max()) < 2e-5 * scale_ * np.sqrt(K / 1280)
+    if M > 1:                                                  # batch independence: row 0 alone == row 0 of the batch
+        solo = torch.zeros((1, N), dtype=torch.float32, device="cuda")
+        call(0, a_dev, m=1, out32=solo.data_ptr(), ld32=N)
+        assert torch.equal(solo[0], out32[0])
+    y16 = (out32.cpu().numpy() + bias.astype(np.float32)).astype(np.float16).astype(np.float32)     # the Linear's fp16 output
+
+    # ---- mode 1: GELU
+    h = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+    call(1, a_dev, out16=h.data_ptr(), ld16=N, n_valid=N)
+    ref = torch.nn.functional.gelu(torch.from_numpy(y16)).half().float().numpy()
+    assert np.abs(h.float().cpu().numpy() - ref).max() <= 2.0 ** -10 * max(1.0, np.abs(ref).max())
+
+    # ---- mode 2: residual stream in place
+    x0 = (r.standard_normal((M, N)) * 1.5).astype(np.float16)
+    x = dev(x0)
+    call(2, a_dev, x=x.data_ptr(), ldx=N)
+    x_ref = (x0.astype(np.float32) + y16).astype(np.float16)
+    assert np.array_equal(x.cpu().numpy(), x_ref)                                   # rounding points are the reference's: exact
+
+    # ---- mode 3: logits with a ragged vocabulary edge
+    lg = torch.full((M, N), 7.0, dtype=torch.float16, device="cuda")
+    call(3, a_dev, out16=lg.data_ptr(), ld16=N, n_valid=N - 5)
+    assert torch.equal(lg[:, :N - 5], out32.half()[:, :N - 5]) and bool((lg[:, N - 5:] == 7.0).all())
+
+    # ---- LayerNorm of the input rows inside the kernel (the LayerNorm'ed inputs are residual-stream rows: K = 1280)
+    if K == 1280:
+        gam = (1 + r.uniform(-0.1, 0.1, K)).astype(np.float16)
+        bet = r.uniform(-0.1, 0.1, K).astype(np.float16)
+        g_dev, be_dev = dev(gam), dev(bet)
+        out_ln = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+        call(0, a_dev, out32=out_ln.data_ptr(), ld32=N, ln_gamma=g_dev.data_ptr(), ln_beta=be_dev.data_ptr())
+        xn = torch.nn.functional.layer_norm(torch.from_numpy(A.astype(np.float32)), (K,), torch.from_numpy(gam.astype(np.float32)),
+                                            torch.from_numpy(bet.astype(np.float32)), 1e-5).half()
+        out_pre = torch.zeros((M, N), dtype=torch.float32, device="cuda")             # the same GEMV on torch's LayerNorm output
+        call(0, xn.cuda(), out32=out_pre.data_ptr(), ld32=N)
+        want_ln = xn.float().numpy() @ Wd.T
+        # two-pass fp32 statistics like torch's: the normalised rows differ in a handful of last fp16 bits at most
+        assert float((out_pre - out_ln).abs().max()) < 1e-3 * max(1.0, np.abs(want_ln).max())
+        assert np.abs(out_ln.cpu().numpy() - want_ln).max() < 2e-3 * max(1.0, np.abs(want_ln).max())
+
+
 def test_attn_decode_cross_rows_do_not_depend_on_the_launch(lib):
     """One workgroup per (utterance, head) for 12 utterances, the persistent balanced launch for 64: same bits per row."""
     r = rng(123)

@@ -39,7 +39,8 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     fields = {"wm_dims": [n for n, _ in native.WmDims._fields_],
               "wm_decoder_io": [n for n, _ in native.WmDecoderIO._fields_],
-              "wm_greedy_io": [n for n, _ in native.WmGreedyIO._fields_]}
+              "wm_greedy_io": [n for n, _ in native.WmGreedyIO._fields_],
+              "wm_gemv_io": [n for n, _ in native.WmGemvIO._fields_]}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "whisper_mi355.h"', 'int main(void){']
     for s, fs in fields.items():
         src.append(f'printf("{s} %zu\\n", sizeof({s}));')
@@ -49,7 +50,8 @@ def test_struct_layouts_match_header(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            str(tmp_path / "l.c"), "-o", str(tmp_path / "l")])
     got = dict(line.split() for line in subprocess.check_output([str(tmp_path / "l")]).decode().splitlines())
-    for s, cls in (("wm_dims", native.WmDims), ("wm_decoder_io", native.WmDecoderIO), ("wm_greedy_io", native.WmGreedyIO)):
+    for s, cls in (("wm_dims", native.WmDims), ("wm_decoder_io", native.WmDecoderIO), ("wm_greedy_io", native.WmGreedyIO),
+                   ("wm_gemv_io", native.WmGemvIO)):
         assert int(got[s]) == C.sizeof(cls), s
         for f in fields[s]:
             assert int(got[f"{s}.{f}"]) == getattr(cls, f).offset, f"{s}.{f}"
