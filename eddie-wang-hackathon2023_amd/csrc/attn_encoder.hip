@@ -18,9 +18,12 @@
 //    ds_read_b64_tr_b16 (hardware transposed read): lane i of a 16-lane group receives 4 keys of
 //    dim i.  The MFMA's k index is mapped to keys as k = 8g + j <-> key 16 (j >> 2) + 4g + (j & 3)
 //    inside each 32-key chunk, which is exactly how the S^T accumulators are laid out.
-//  * K/V tiles of 64 keys are register-staged one tile ahead into a double-buffered LDS image
-//    with 144-byte rows; one barrier per tile.  Each wave owns QB blocks of 16 queries and
-//    re-uses every K / V fragment for all of them.
+//  * K/V tiles of 64 keys go global -> LDS directly (global_load_lds, 16 B per lane, one tile ahead, double-buffered; one
+//    barrier per tile).  Rows are 128 B; the 16-byte chunk c of key row r sits at position c ^ ((r >> 1) & 7), applied
+//    to the per-lane SOURCE address (the DMA writes LDS linearly) and to every read.  Round 1 staged the tiles through
+//    registers into padded rows: with 246 VGPRs the 16 staging registers were spilled -- scratch stores right behind the
+//    global loads, i.e. every tile waited for its successor's HBM round trip (4 scratch stores + 2 loads per tile, found in
+//    the ISA in round 2).  Each wave owns QB blocks of 16 queries and re-uses every K / V fragment for all of them.
 #include <type_traits>
 
 #include "common.h"
@@ -29,12 +32,12 @@
 namespace wm {
 
 constexpr int KT_KEYS = 64;
-constexpr int AROW = 144;                      // LDS bytes per key row (64 halves + pad)
-constexpr int KV_TILE = KT_KEYS * AROW;        // 9216
+constexpr int AROW = 128;                      // LDS bytes per key row (64 halves, chunk-swizzled)
+constexpr int KV_TILE = KT_KEYS * AROW;        // 8192
 
 template <int QB>
 __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {     // 2 waves per SIMD: <= 256 registers
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * KV_TILE];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * KV_TILE];
     auto sK = [&](int b) { return smem + b * 2 * KV_TILE; };
     auto sV = [&](int b) { return smem + b * 2 * KV_TILE + KV_TILE; };
 
@@ -56,30 +59,20 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
             qf[qb][s] = *(const half8v*)(base + (size_t)qrow * p.ld + h * 64 + s * 32 + g * 8);
     }
 
-    // ---- K/V staging: 512 16-byte chunks per tile each, 2 per thread ----------------------------
-    uint4 rk[2], rv[2];
-    int st_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i;
-        st_off[i] = (c >> 3) * AROW + (c & 7) * 16;
-    }
-    auto load_kv = [&](int tile) {
+    // ---- K/V staging: a tile is 8 wave-wide DMA pieces (8 key rows x 128 B each) per matrix; wave w issues pieces w and
+    // w + 4 of K and of V.  Lane -> key row (lane >> 3) of the piece, LDS chunk (lane & 7) <- source chunk (lane & 7) ^ swz(row)
+    auto load_kv = [&](int tile, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i;
-            int key = tile * KT_KEYS + (c >> 3);
+            const int piece = wid + 4 * i;
+            const int r = piece * 8 + (lane >> 3);                        // key row inside the tile
+            int key = tile * KT_KEYS + r;
             if (key > p.T - 1) key = p.T - 1;
-            const h16* row = base + (size_t)key * p.ld + h * 64 + (c & 7) * 8;
-            rk[i] = *(const uint4*)(row + C);
-            rv[i] = *(const uint4*)(row + 2 * C);
-        }
-    };
-    auto store_kv = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(uint4*)(sK(buf) + st_off[i]) = rk[i];
-            *(uint4*)(sV(buf) + st_off[i]) = rv[i];
+            const h16* row = base + (size_t)key * p.ld + h * 64 + (((lane & 7) ^ ((r >> 1) & 7)) * 8);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + C),
+                                             (__attribute__((address_space(3))) void*)(sK(buf) + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + 2 * C),
+                                             (__attribute__((address_space(3))) void*)(sV(buf) + piece * 1024), 16, 0, 0);
         }
     };
 
@@ -93,26 +86,30 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
     for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
 
     const int ntiles = (p.T + KT_KEYS - 1) / KT_KEYS;
-    load_kv(0);
-    store_kv(0);
+    load_kv(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // LDS addresses: K A-operand (row = key li, dims 8g..): li*AROW + g*16 (+ kb*16*AROW + s*64)
-    const int k_off = li * AROW + g * 16;
-    // V transposed read: lane i of its 16-lane group supplies row (i >> 2), columns 4 * (i & 3) ..
-    const int v_off = (4 * g + (li >> 2)) * AROW + (li & 3) * 8;
+    // LDS addresses (chunk positions XOR-swizzled with (row >> 1) & 7; a row block of 16 or 32 rows does not change that value):
+    // K A-operand: row = key li (+ 16 kb), dims 8g.. (chunk g) and 32 + 8g.. (chunk g + 4)
+    const int k_swz = (li >> 1) & 7;
+    const int k_off0 = li * AROW + ((g ^ k_swz) << 4), k_off1 = li * AROW + (((g + 4) ^ k_swz) << 4);
+    // V transposed read: lane i of its 16-lane group supplies row 4g + (i >> 2) (+ 16 for the upper half, + 32 c), 4 columns
+    // from 4 (i & 3) + 16 db: chunk 2 db + ((i & 3) >> 1), its upper or lower 8 bytes
+    const int v_row = 4 * g + (li >> 2), v_swz = (v_row >> 1) & 7;
+    const int v_base = v_row * AROW + (li & 1) * 8, v_chunk = (li & 3) >> 1;
 
     auto tile_body = [&](int t, auto TAIL_) {
         constexpr bool TAIL = decltype(TAIL_)::value;     // only the last tile masks keys >= T
         const int cur = t & 1;
-        if (t + 1 < ntiles) load_kv(t + 1);
+        if (t + 1 < ntiles) load_kv(t + 1, cur ^ 1);       // lands while this tile is multiplied; nobody reads that buffer before the barrier below
 
         // ---- S^T = K . Q^T : [64 keys] x [16 QB queries] ------------------------------------------
         float4v sacc[4][QB];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const half8v k0 = *(const half8v*)(sK(cur) + k_off + kb * 16 * AROW);
-            const half8v k1 = *(const half8v*)(sK(cur) + k_off + kb * 16 * AROW + 64);
+            const half8v k0 = *(const half8v*)(sK(cur) + k_off0 + kb * 16 * AROW);
+            const half8v k1 = *(const half8v*)(sK(cur) + k_off1 + kb * 16 * AROW);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 float4v a = float4v{0.f, 0.f, 0.f, 0.f};
@@ -174,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const unsigned char* va = sV(cur) + v_off + (c * 32) * AROW + db * 32;
+                const unsigned char* va = sV(cur) + v_base + (c * 32) * AROW + (((2 * db + v_chunk) ^ v_swz) << 4);
                 const short4r lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) short4r*)(va));
                 const short4r hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c][qb], o[db][qb], 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) store_kv(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next tile have landed
         __syncthreads();
     };
     for (int t = 0; t + 1 < ntiles; ++t) tile_body(t, std::false_type{});

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -595,10 +596,16 @@ constexpr int SMALL_PATH_DEFAULT_ROWS = 4;
 // (For more rows the same fusion was built into gemm_skinny.hip and measured: without a K split its 10-40 workgroups each
 // stage the whole activation block, 70 us per launch at M = 192 against 16 + 10 for the split GEMM + row kernel, and the
 // decode step at B = 576 went from 26.1 to 30.3 ms -- profiles/r2d_b576_fused_skinny_ks1_kernel_stats.csv.  Not kept.)
-int small_path_max_rows() {               // WM_SMALL_PATH=<rows>: the fused path serves M <= rows (0: never)
-    static const int rows = [] { const char* v = getenv("WM_SMALL_PATH"); int r = v ? atoi(v) : SMALL_PATH_DEFAULT_ROWS;
-                                 return r < 0 ? 0 : (r > GEMV_SMALL_MAX_M ? GEMV_SMALL_MAX_M : r); }();
-    return rows;
+std::atomic<int> g_small_rows{-1};        // -1: not yet read from the environment
+int small_path_max_rows() {               // WM_SMALL_PATH=<rows> / wm_set_small_batch_rows: the fused path serves M <= rows (0: never)
+    int r = g_small_rows.load(std::memory_order_relaxed);
+    if (r < 0) {
+        const char* v = getenv("WM_SMALL_PATH");
+        r = v ? atoi(v) : SMALL_PATH_DEFAULT_ROWS;
+        r = r < 0 ? 0 : (r > GEMV_SMALL_MAX_M ? GEMV_SMALL_MAX_M : r);
+        g_small_rows.store(r, std::memory_order_relaxed);
+    }
+    return r;
 }
 
 struct GroupStep {
@@ -948,6 +955,12 @@ int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_b
     return launch_gemm_skinny(p, (hipStream_t)stream);
 }
 int wm_gemm_skinny_default_ksplit(int M, int K, int n_blocks, int w8) { return skinny_default_ksplit(M, K, n_blocks, w8); }
+
+int wm_set_small_batch_rows(int rows) {
+    const int prev = small_path_max_rows();
+    g_small_rows.store(rows < 0 ? 0 : (rows > GEMV_SMALL_MAX_M ? GEMV_SMALL_MAX_M : rows), std::memory_order_relaxed);
+    return prev;
+}
 
 int wm_gemv_fused(const wm_gemv_io* io, wm_stream_t stream) {
     WM_REQUIRE(io && io->a && io->wt, "wm_gemv_fused: null argument");

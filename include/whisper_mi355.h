@@ -193,6 +193,11 @@ typedef struct wm_gemv_io {
     void* x; int32_t ldx;
 } wm_gemv_io;
 int wm_gemv_fused(const wm_gemv_io* io, wm_stream_t stream);
+/* Decoder calls with batch * n_new <= rows activation rows take the fused small-batch path (wm_gemv_fused per Linear);
+ * default 4 (or WM_SMALL_PATH), 0 = never, at most 32.  Returns the previous value.  A row's result does not depend on
+ * the batch it is in on either side of the switch; across it the two paths agree to fp32 summation order (a last-bit
+ * difference of fp16 values in rare cases).  Captured graphs keep the path they were captured with.                    */
+int wm_set_small_batch_rows(int rows);
 /* fp16 LayerNorm rows, fp32 statistics, eps 1e-5 (layernormKernels.cu:62-188). */
 int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta,
                  void* out, int ldo, wm_stream_t stream);

@@ -366,7 +366,55 @@ def test_main_loop_fast_equals_reference_loop_and_oracle(tmpdir_module):
     print(f"fused loop vs oracle rules: {n_diverged} of {len(same)} rows part ways at a near-tie, none elsewhere")
 
 
-def test_batch_independence(tmpdir_module):
+@pytest.fixture
+def one_decode_path():
+    """Pins the decoder to the big-batch kernels for every batch size (wm_set_small_batch_rows(0)), for tests that compare
+    a batch with its rows taken alone bit for bit: the fused small-batch path (<= 4 rows by default) adds up its K slices
+    in another order, so across the switch rows agree to fp32 summation order, not bit for bit."""
+    lib = native.load_library()
+    prev = lib.wm_set_small_batch_rows(0)
+    yield
+    lib.wm_set_small_batch_rows(prev)
+
+
+def test_small_batch_path_agrees_with_big_batch_path(tmpdir_module):
+    """The same decoder calls on the fused small-batch path (gemv_small.hip: in-kernel LayerNorm, K split over the waves of a
+    workgroup, fused epilogues) and on the big-batch path (split-K slabs + row kernels), weight-only int8 + int8 KV:
+    teacher-forced logits agree far inside the logit tolerance, the int8 caches almost everywhere, and within the small
+    path a row does not depend on the batch it is in."""
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3, weight_only=True, int8_kv=True, kv_scales=[0.05] * dims.n_text_layer)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    lib = native.load_library()
+    xa = enc.get_audio_features(synthetic_mel(3, 2 * dims.n_audio_ctx, dims.n_mels, 5).cuda())
+    cross = dec.xa2cross_key_value(xa)
+    feed = [torch.tensor([[50258, 50259, 50359]] * 3).cuda()] + [torch.tensor([[t]] * 3).cuda() for t in (50364, 1200, 900, 31)]
+
+    def run(rows, sel=slice(0, 3)):
+        prev = lib.wm_set_small_batch_rows(rows)
+        try:
+            out, kv = [], None
+            for x in feed:
+                logits, kv = dec.decode(x[sel], [c[sel] for c in cross], kv)
+                out.append(logits.float().cpu())
+            return out, [k.cpu() for k in kv]
+        finally:
+            lib.wm_set_small_batch_rows(prev)
+
+    big, kv_big = run(0)
+    small, kv_small = run(32)
+    worst = max(float((a - b).abs().max()) for a, b in zip(big, small))
+    flips = max(float((a.int() - b.int()).abs().max()) for a, b in zip(kv_big, kv_small))
+    frac = max(float(((a.int() - b.int()).abs() > 0).float().mean()) for a, b in zip(kv_big, kv_small))
+    print(f"small-batch vs big-batch path: max |dlogit| = {worst:.5f}, int8 cache codes differ by <= {flips:.0f} in {100 * frac:.3f} % of the entries")
+    assert worst < LOGIT_TOL / 2 and flips <= 1 and frac < 0.01
+    assert all(torch.equal(a[:, -1].argmax(-1), b[:, -1].argmax(-1)) for a, b in zip(big, small)
+               if float((a[:, -1].topk(2).values[:, 0] - a[:, -1].topk(2).values[:, 1]).min()) > 2 * LOGIT_TOL)
+    solo, _ = run(32, slice(1, 2))                                    # within the small path: row 1 alone == row 1 of the batch
+    assert all(torch.equal(a[1:2], b) for a, b in zip(small, solo))
+
+
+def test_batch_independence(tmpdir_module, one_decode_path):
     """Utterances are independent units (the data-parallel sharding relies on it): a batch of 3
     gives the rows it gives one by one."""
     dims = Dims(**synthetic.DIMS["micro"])
@@ -669,7 +717,7 @@ def test_full_size_large_v2_matches_oracle_on_gpu(tmpdir_module):
     assert n_ok == n_safe and n_safe > 0
 
 
-def test_full_size_large_v2_properties(tmpdir_module):
+def test_full_size_large_v2_properties(tmpdir_module, one_decode_path):
     """BASELINE.json configs[3] at FULL size (32 + 32 layers, int8 weight-only + int8 KV; the CPU oracle would need
     minutes per token there), through properties that do not need it: the fused graph-replayed loop == the literal
     reference loop token for token, utterances are independent (a batch row == the same clip alone, bit for bit),
