@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--config", type=str, default="int8", choices=list(CONFIGS))
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--engine-cache", type=str, default="/tmp/wm_bench_engines")
+    ap.add_argument("--encoder-cus", type=int, default=96,
+                    help="CUs the next step's encoder runs on beside the current step's decode loop (0: no pipelining, one stage after the other)")
+    ap.add_argument("--groups", type=int, default=0, help="utterance groups of the decode loop (0: the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank (self-test)")
@@ -272,6 +275,8 @@ def main():
         dist.barrier()
     enc, dec = WhisperEncoding(eng_dir), WhisperDecoding(eng_dir)
     dec.sample_len = args.decode_steps
+    if args.groups > 0:
+        dec.micro_batches = args.groups
     dims = synthetic.DIMS[args.model]
     B, T = args.batch, args.decode_steps
 
@@ -288,19 +293,26 @@ def main():
     loop_events = []            # (start, end) of every decode loop: torch events on the current stream, which main_loop
     last = {}                   # joins with its group streams before it returns
 
-    def step():
-        xa = enc.get_audio_features_async(mel)
+    # One step = encoder + cross-K/V + language pass + prefill + decode loop of one batch.  Consecutive steps are software-
+    # pipelined the way a transcription job over many batches is (run.py): while the HBM-bound decode loop of batch n runs,
+    # the MFMA-bound encoder of batch n + 1 runs beside it on a budget of CUs (WhisperEncoding.prefetch).  Every step's
+    # encoder runs inside the region that is timed: the first one in the open, the last decode loop with nothing beside it.
+    def step(more_to_come: bool):
+        xa = enc.collect() if last.get("prefetched") else enc.get_audio_features_async(mel)
         dec.detect_language(xa)
+        last["prefetched"] = bool(args.encoder_cus > 0 and more_to_come)
+        if last["prefetched"]:
+            enc.prefetch(mel, args.encoder_cus)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         tokens, sum_lp, _ = dec.main_loop(xa, ignore_eot=True)
         e1.record()
-        loop_events.append((e0, e1))
+        loop_events.append((e0, e1, last["prefetched"]))
         last["xa"] = xa
         return dp.gather_results(tokens, sum_lp, n_total, width, dec.tokenizer.eot)
 
-    for _ in range(args.warmup):
-        out = step()
+    for k in range(args.warmup):
+        out = step(k + 1 < args.warmup)
     if not args.no_roofline:
         native.check(lib.wm_profile_configure(1, 8, 4096))       # every 8th layer's cross-attention launch
         dec.lang_id_sequential = True                            # timed launches run with the HBM to themselves (as under rocprofv3)
@@ -309,14 +321,19 @@ def main():
     torch.cuda.synchronize()
     loop_events.clear()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for k in range(args.steps):
+        out = step(k + 1 < args.steps)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
 
-    decode_loop_ms = float(np.mean([a.elapsed_time(b) for a, b in loop_events])) if loop_events else None
+    # decode loops with nothing beside them (the last step's; every step's when the pipelining is off) and with the next
+    # batch's encoder beside them
+    alone = [a.elapsed_time(b) for a, b, shared in loop_events if not shared]
+    shared = [a.elapsed_time(b) for a, b, shared in loop_events if shared]
+    decode_loop_ms = float(np.mean(alone)) if alone else None
+    decode_loop_shared_ms = float(np.mean(shared)) if shared else None
     weight_bytes = sum(sess.engine.weight_bytes for sess in (enc.session, dec.decoder_session, dec.cross_attn_session))
     torch_bytes = torch.cuda.memory_allocated(dev)
     free_b, total_b = torch.cuda.mem_get_info(dev)
@@ -355,7 +372,11 @@ def main():
                 cross_bytes = B * dims["n_text_layer"] * H * 2 * Tk * 64 * kv_bytes          # B x 245.76 MB at large-v2
                 roofline.update({"decode_loop_ms": round(decode_loop_ms, 2), "decode_step_ms": round(step_ms, 3),
                                  "decode_step_frac": round(cross_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "decode_step_note": "cross-K/V bytes of one token step for the whole batch / (decode loop time / tokens) / 8 TB/s"})
+                                 "decode_step_note": "cross-K/V bytes of one token step for the whole batch / (decode loop time / tokens) / 8 TB/s"
+                                                     + ("; decode loops with nothing beside them (the last step's)" if shared else "")})
+                if decode_loop_shared_ms is not None:
+                    roofline.update({"decode_loop_beside_encoder_ms": round(decode_loop_shared_ms, 2),
+                                     "decode_step_beside_encoder_ms": round(decode_loop_shared_ms / T, 3)})
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -371,7 +392,10 @@ def main():
             "utterances_per_s": round(n_total / (ms_per_step * 1e-3), 2),
             "config": {"workload": f"whisper {args.model} {args.config}: {WORKLOADS[args.config]}; {B} x 30 s utterances per GPU per step, {T} forced greedy tokens each "
                                    f"(+3-token prefill, +1-token language-ID pass); random-init weights",
-                       "batch_per_gpu": B, "decode_steps": T, "parallelism": f"dp{world} (utterance sharding, no "
+                       "batch_per_gpu": B, "decode_steps": T,
+                       "pipelining": (f"encoder of step n+1 on {args.encoder_cus} CUs beside the decode loop of step n; all {args.steps} encoders inside the timed region"
+                                      if args.encoder_cus > 0 and args.steps > 1 else "none"),
+                       "parallelism": f"dp{world} (utterance sharding, no "
                                                                             f"data-path collective)"},
             "engine_build_s": round(build_s, 1),
             # what sits in HBM while the job runs: engine weights (hipMalloc'ed by the library: weight-only encoder / cross-K/V

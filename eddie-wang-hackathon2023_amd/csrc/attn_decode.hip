@@ -40,6 +40,9 @@ constexpr int MAX_L = 4;                              // query tokens per call h
 // ------------------------------------------------------------------------------------------------
 template <bool I8>
 __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
+    // issue priority over the other groups' K/V stream waves (see gemm_skinny_kernel)
+    __builtin_amdgcn_s_setprio(3);
+
     constexpr int MAXT = 512;
     __shared__ float s_p[MAXT];
     __shared__ h16 s_qall[MAX_L][64], s_knew[MAX_L][64], s_vnew[MAX_L][64];

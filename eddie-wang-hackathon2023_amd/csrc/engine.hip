@@ -338,13 +338,14 @@ EncWs carve_encoder(const wm_engine* e, int B, void* ws) {
 }
 
 int big(const Lin& l, const wm_engine* e, const h16* A, int lda, int M, h16* Cout, int ldc, int act,
-        const h16* residual, int ldr, hipStream_t s, GemmBigParams* custom = nullptr) {
+        const h16* residual, int ldr, hipStream_t s, GemmBigParams* custom = nullptr, int max_wgs = 0) {
     GemmBigParams p{};
     if (custom) p = *custom;
     WM_REQUIRE(l.s == nullptr, "big GEMM: int8 weights must have been expanded at engine creation");
     p.A = A; p.lda = lda; p.M = M; p.K = l.K; p.W = l.w; p.N = l.N;
     p.bias = l.b; p.C = Cout; p.ldc = ldc; p.act = act;
     if (!custom) { p.residual = residual; p.ldr = ldr; }
+    p.max_wgs = max_wgs;
     return launch_gemm_f16(p, s);        // int8 [N][K] weights were expanded at engine creation (expand_lin)
 }
 
@@ -418,8 +419,14 @@ size_t wm_encoder_workspace_bytes(const wm_engine* e, int batch) {
 
 int wm_encoder_forward(const wm_engine* e, const void* mel, int B, void* out, void* workspace,
                        size_t workspace_bytes, wm_stream_t stream_) {
+    return wm_encoder_forward_shared(e, mel, B, out, workspace, workspace_bytes, 0, stream_);
+}
+
+int wm_encoder_forward_shared(const wm_engine* e, const void* mel, int B, void* out, void* workspace,
+                              size_t workspace_bytes, int cu_budget, wm_stream_t stream_) {
     WM_REQUIRE(e && e->kind == WM_ENGINE_ENCODER, "wm_encoder_forward: not an encoder engine");
     WM_REQUIRE(mel && out && workspace && B >= 1, "wm_encoder_forward: null argument or empty batch");
+    WM_REQUIRE(cu_budget >= 0, "wm_encoder_forward_shared: cu_budget=%d", cu_budget);
     hipStream_t s = (hipStream_t)stream_;
     const wm_dims& d = e->dims;
     const int T = d.n_audio_ctx, Tin = 2 * T, C = d.n_audio_state, H = d.n_audio_head, M = B * T;
@@ -436,7 +443,7 @@ int wm_encoder_forward(const wm_engine* e, const void* mel, int B, void* out, vo
         p.a_rows = Tin; p.a_bstride = (long)(Tin + 2) * d.n_mels;
         p.c_rows = Tin; p.c_bstride = (long)(Tin + 2) * C;
         WM_REQUIRE(e->conv1.K >= 3 * d.n_mels, "conv1 weight K=%d < 3*n_mels", e->conv1.K);
-        if (big(e->conv1, e, w.melT, d.n_mels, B * Tin, w.c1 + C, C, e->gelu(), nullptr, 0, s, &p)) return 2;
+        if (big(e->conv1, e, w.melT, d.n_mels, B * Tin, w.c1 + C, C, e->gelu(), nullptr, 0, s, &p, cu_budget)) return 2;
         if (launch_zero_pad_rows(w.c1, B, Tin + 2, C, s)) return 2;
     }
     // conv2 (k3 s2 p1) + GELU + positional embedding: row t = padded rows 2t, 2t+1, 2t+2
@@ -444,7 +451,7 @@ int wm_encoder_forward(const wm_engine* e, const void* mel, int B, void* out, vo
         GemmBigParams p{};
         p.a_rows = T; p.a_bstride = (long)(Tin + 2) * C;
         p.residual = e->enc_pos; p.ldr = C; p.res_mod = T;
-        if (big(e->conv2, e, w.c1, 2 * C, M, w.x, C, e->gelu(), nullptr, 0, s, &p)) return 2;
+        if (big(e->conv2, e, w.c1, 2 * C, M, w.x, C, e->gelu(), nullptr, 0, s, &p, cu_budget)) return 2;
     }
     const float qk_scale = 0.35355339059327373f;    // 64^-0.25
     for (int i = 0; i < d.n_audio_layer; ++i) {
@@ -453,14 +460,14 @@ int wm_encoder_forward(const wm_engine* e, const void* mel, int B, void* out, vo
         {
             GemmBigParams p{};
             p.colscale_n = 2 * C; p.colscale = qk_scale;
-            if (big(L.qkv, e, w.xn, C, M, w.qkv, 3 * C, 0, nullptr, 0, s, &p)) return 2;
+            if (big(L.qkv, e, w.xn, C, M, w.qkv, 3 * C, 0, nullptr, 0, s, &p, cu_budget)) return 2;
         }
         AttnEncParams ap{w.qkv, 3 * C, B, T, H, w.ctx, C};
         if (launch_attn_encoder(ap, s)) return 2;
-        if (big(L.out, e, w.ctx, C, M, w.x, C, 0, w.x, C, s)) return 2;
+        if (big(L.out, e, w.ctx, C, M, w.x, C, 0, w.x, C, s, nullptr, cu_budget)) return 2;
         if (launch_layernorm(w.x, C, M, C, L.ln2g, L.ln2b, w.xn, C, s)) return 2;
-        if (big(L.mlp1, e, w.xn, C, M, w.hid, 4 * C, e->gelu(), nullptr, 0, s)) return 2;
-        if (big(L.mlp2, e, w.hid, 4 * C, M, w.x, C, 0, w.x, C, s)) return 2;
+        if (big(L.mlp1, e, w.xn, C, M, w.hid, 4 * C, e->gelu(), nullptr, 0, s, nullptr, cu_budget)) return 2;
+        if (big(L.mlp2, e, w.hid, 4 * C, M, w.x, C, 0, w.x, C, s, nullptr, cu_budget)) return 2;
     }
     if (launch_layernorm(w.x, C, M, C, e->lnpg, e->lnpb, (h16*)out, C, s)) return 2;
     return 0;

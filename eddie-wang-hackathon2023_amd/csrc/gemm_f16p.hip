@@ -344,6 +344,7 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     const int n_tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     int grid = (n_cu / 8) * 8;
     if (grid < 8) grid = 8;
+    if (p.max_wgs > 0 && p.max_wgs < grid) grid = p.max_wgs >= 8 ? (p.max_wgs / 8) * 8 : 8;
     const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
     if (grid > need) grid = need;
     hipLaunchKernelGGL(kerns[p.act], dim3(grid), dim3(512), LDS_BYTES, stream, p);

@@ -20,6 +20,9 @@ struct GemmBigParams {
     // row m lives at A + (m / a_rows) * a_bstride + (m % a_rows) * lda   (a_rows == 0: plain)
     int a_rows; long a_bstride;
     int c_rows; long c_bstride;              // same for C (out_mode 0 only)
+    // > 0: at most this many (persistent, one per CU) workgroups -- the launch then leaves the other CUs to whatever runs
+    // beside it (wm_encoder_forward_shared); the tiles and their arithmetic are the same, only who computes them changes
+    int max_wgs;
 };
 int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // dispatch: gemm_f16p.hip when it supports the shape, else gemm_f16.hip's kernel
 int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream);     // persistent 256x256 tiles, continuous LDS-DMA stream, alternating wave groups

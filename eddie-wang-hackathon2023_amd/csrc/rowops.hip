@@ -40,6 +40,9 @@ __device__ __forceinline__ void st_h4(h16* p, float4 v) {
 // a runtime-indexed register array would be demoted to scratch).  4 elements per thread per trip,
 // 16-byte loads of the fp32 slabs, 8-byte loads/stores of fp16 data.
 __global__ __launch_bounds__(ROW_THREADS) void row_finish_kernel(RowFinishParams p) {
+    // issue priority over the other groups' K/V stream waves (see gemm_skinny_kernel)
+    __builtin_amdgcn_s_setprio(3);
+
     __shared__ float red[ROW_THREADS / 64];
     __shared__ __attribute__((aligned(16))) float row[ROW_MAX_N];
     const int m = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;

@@ -23,6 +23,10 @@ from session import Session, TensorInfo, str_dtype_to_trt, trt_dtype_to_torch, l
 # only for a tensor that carries the generation it cached.
 _GENERATION = itertools.count(1)
 
+# CUs the encoder keeps when it runs beside a decode loop (WhisperEncoding.prefetch): measured at B = 576 on MI355X,
+# see DESIGN.md "encoder under the decode loop"
+DEFAULT_SHARED_CU_BUDGET = 96
+
 
 def stamp_generation(audio_features):
     audio_features.wm_generation = next(_GENERATION)
@@ -80,11 +84,47 @@ class WhisperEncoding:
         stream.synchronize()
         return stamp_generation(outputs['output'])
 
-    def get_audio_features_async(self, mel, out=None):
+    def get_audio_features_async(self, mel, out=None, cu_budget: int = 0):
         """Fast path: no dictionaries, no synchronisation; enqueued on the current stream."""
         mel = mel.type(torch.float16).contiguous()
         d = self.session.dims
         if out is None:
             out = torch.empty((mel.shape[0], d['n_audio_ctx'], d['n_audio_state']), dtype=torch.float16, device=mel.device)
-        self.session.encoder_forward(mel, out, torch.cuda.current_stream().cuda_stream)
+        self.session.encoder_forward(mel, out, torch.cuda.current_stream().cuda_stream, cu_budget)
         return stamp_generation(out)
+
+    # -- the encoder of the NEXT batch under the decode loop of the current one --------------------------------------
+    # The decode loop is HBM-bound (it streams the cross-attention K/V once per token), the encoder MFMA-bound.  With
+    # cu_budget workgroups pinned to as many CUs the encoder leaves the rest of the chip to the decode kernels, which are
+    # then never dispatched behind a 128 KB-LDS GEMM tile.  prefetch() enqueues from a helper thread on a stream of its
+    # own (the ctypes calls release the GIL); collect() joins it and makes the current stream wait for the result.
+    def prefetch(self, mel, cu_budget: int = DEFAULT_SHARED_CU_BUDGET):
+        import threading
+        assert getattr(self, "_prefetch", None) is None, "one prefetch at a time"
+        if getattr(self, "_prefetch_stream", None) is None:
+            self._prefetch_stream = torch.cuda.Stream(device=mel.device)
+        side, box = self._prefetch_stream, {}
+        side.wait_stream(torch.cuda.current_stream())          # mel may still be in flight on the caller's stream
+        device = mel.device
+
+        def work():
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(side):
+                    box["xa"] = self.get_audio_features_async(mel, cu_budget=cu_budget)
+            except BaseException as exc:                       # re-raised by collect()
+                box["error"] = exc
+
+        th = threading.Thread(target=work, name="wm-encoder-prefetch", daemon=True)
+        th.start()
+        self._prefetch = (th, box)
+
+    def collect(self):
+        """The audio features of the batch handed to prefetch(); the current stream waits for them."""
+        th, box = self._prefetch
+        self._prefetch = None
+        th.join()
+        if "error" in box:
+            raise box["error"]
+        torch.cuda.current_stream().wait_stream(self._prefetch_stream)
+        return box["xa"]

@@ -174,13 +174,14 @@ class Session(object):
             return False
 
     # -- typed fast path ---------------------------------------------------------------------------
-    def encoder_forward(self, mel: torch.Tensor, out: torch.Tensor, stream: int):
+    def encoder_forward(self, mel: torch.Tensor, out: torch.Tensor, stream: int, cu_budget: int = 0):
+        """cu_budget > 0: the pass runs on at most that many CUs, beside other streams' work (wm_encoder_forward_shared)."""
         lib = self._engine.lib
         b = mel.shape[0]
         nbytes = lib.wm_encoder_workspace_bytes(self._engine.handle, b)
         ws = self._workspace(("enc",), nbytes)        # one buffer, grown on demand: 26 GB at B = 576
-        check(lib.wm_encoder_forward(self._engine.handle, mel.data_ptr(), b, out.data_ptr(), ws.data_ptr(),
-                                     ws.numel(), stream), "wm_encoder_forward")
+        check(lib.wm_encoder_forward_shared(self._engine.handle, mel.data_ptr(), b, out.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), int(cu_budget), stream), "wm_encoder_forward")
 
     def cross_kv(self, xa: torch.Tensor, outs: Sequence[torch.Tensor], stream: int):
         lib = self._engine.lib

@@ -88,6 +88,25 @@ def eval_engines(whisper_encoding, whisper_decoding, mel) -> list:
     return whisper_decoding.post_process(tokens, sum_logprobs, no_speech_probs, audio_features, languages)
 
 
+def eval_engines_stream(whisper_encoding, whisper_decoding, mels, cu_budget: Optional[int] = None):
+    """eval_engines over a sequence of mel batches, software-pipelined: while the decode loop of batch n streams its
+    cross-attention K/V, the encoder of batch n + 1 runs beside it on `cu_budget` CUs (WhisperEncoding.prefetch).
+    Yields one result list per batch, in order; the results are the ones eval_engines returns batch by batch."""
+    from encoding import DEFAULT_SHARED_CU_BUDGET
+    budget = DEFAULT_SHARED_CU_BUDGET if cu_budget is None else cu_budget
+    it = iter(mels)
+    mel, pending = next(it, None), False
+    while mel is not None:
+        audio_features = whisper_encoding.collect() if pending else whisper_encoding.get_audio_features_async(mel)
+        languages, _ = whisper_decoding.detect_language(audio_features)
+        mel = next(it, None)
+        pending = mel is not None and budget > 0
+        if pending:
+            whisper_encoding.prefetch(mel, budget)
+        tokens, sum_logprobs, no_speech_probs = whisper_decoding.main_loop(audio_features)
+        yield whisper_decoding.post_process(tokens, sum_logprobs, no_speech_probs, audio_features, languages)
+
+
 def eval_torch(whisper_encoding, whisper_decoding, mel, model) -> list:
     audio_features = whisper_encoding.torch_get_audio_features(model, mel)
     languages, _ = whisper_decoding.torch_detect_language(model, audio_features)
@@ -110,6 +129,39 @@ def load_torch_model(checkpoint_file: str, device):
 def score(hypotheses: List[str], references: List[str], normalizer=None) -> float:
     normalizer = normalizer or EnglishTextNormalizer()
     return word_error_rate([normalizer(t) for t in references], [normalizer(t) for t in hypotheses])
+
+
+def transcribe_dataset_stream(pairs, stream_evaluate, batch_size: int, device) -> Tuple[List[str], List[str], float]:
+    """transcribe_dataset for a pipelined evaluator: `stream_evaluate(iterator of mel batches)` yields one result list per
+    batch (eval_engines_stream).  The batches are formed lazily, so the audio of batch n + 1 is read and its log-mel computed
+    while batch n decodes; the seconds returned are the wall time of the whole loop (file reading included)."""
+    import collections
+    hyps, refs, waiting = [], [], collections.deque()
+
+    def batches():
+        audio, texts = [], []
+        for audio_file, ref in pairs:
+            a = load_audio(str(audio_file))
+            if a.shape[-1] > N_SAMPLES:
+                continue
+            audio.append(a)
+            texts.append(ref)
+            if len(audio) == batch_size:
+                waiting.append(list(texts))
+                yield mel_batch(audio, device)
+                audio, texts = [], []
+        if audio:
+            waiting.append(list(texts))
+            yield mel_batch(audio, device)
+
+    t0 = time.time()
+    for results in stream_evaluate(batches()):
+        for ref, res in zip(waiting.popleft(), results):
+            hyps.append(clean_hypothesis(res.text))
+            refs.append(ref)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+    return hyps, refs, time.time() - t0
 
 
 def transcribe_dataset(pairs, evaluate, batch_size: int, device) -> Tuple[List[str], List[str], float]:
@@ -168,7 +220,11 @@ def main(args) -> Optional[dict]:
     if args.test_trt_llm:
         runs.append(("whisper-mi355", lambda mel: eval_engines(whisper_encoding, whisper_decoding, mel)))
     for name, evaluate in runs:
-        hyps, refs, seconds = transcribe_dataset(pairs[lo:hi], evaluate, args.batch_size, device)
+        if name == "whisper-mi355" and args.overlap_encoder:
+            hyps, refs, seconds = transcribe_dataset_stream(
+                pairs[lo:hi], lambda mels: eval_engines_stream(whisper_encoding, whisper_decoding, mels), args.batch_size, device)
+        else:
+            hyps, refs, seconds = transcribe_dataset(pairs[lo:hi], evaluate, args.batch_size, device)
         if world > 1:
             gathered = [None] * world
             dist.all_gather_object(gathered, (hyps, refs, seconds))
@@ -195,6 +251,8 @@ def parse_arguments(argv=None):
     parser.add_argument('--checkpoint_file', type=str, default='./large-v2.pt')
     parser.add_argument('--batch_size', type=int, default=32, help='utterances decoded together (the reference: 1)')
     parser.add_argument('--vocab', type=str, default=None, help='path to multilingual.tiktoken / gpt2.tiktoken')
+    parser.add_argument('--overlap_encoder', action='store_true',
+                        help='run the encoder of the next batch beside the decode loop of the current one (eval_engines_stream)')
     return parser.parse_args(argv)
 
 

@@ -63,6 +63,13 @@ size_t wm_engine_weight_bytes(const wm_engine* e);
 size_t wm_encoder_workspace_bytes(const wm_engine* e, int batch);
 int wm_encoder_forward(const wm_engine* e, const void* mel, int batch, void* out,
                        void* workspace, size_t workspace_bytes, wm_stream_t stream);
+/* The same forward pass, sharing the GPU with other work (the reference's run.py takes its batches one after the other,
+ * W/run.py:109-169; here the encoder of batch n+1 can run UNDER the HBM-bound decode loop of batch n).
+ * cu_budget > 0: the MFMA-bound kernels of this call occupy at most that many compute units -- their workgroups are
+ * persistent and stay on their CU, so kernels of other streams are never queued behind them; the results are bit-identical
+ * to wm_encoder_forward's (same tiles, same arithmetic, fewer workgroups walking over them).  0 = the whole chip. */
+int wm_encoder_forward_shared(const wm_engine* e, const void* mel, int batch, void* out,
+                              void* workspace, size_t workspace_bytes, int cu_budget, wm_stream_t stream);
 
 /* ---- cross-attention K/V engine: W/decoding.py:515-541 -> CrossAttn_KV.forward (model.py:469-540)
  * xa          : fp16 [batch, n_audio_ctx, n_text_state]

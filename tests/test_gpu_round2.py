@@ -219,3 +219,49 @@ def test_bench_force_dist_single_rank(tmp_path):
     out = Path(ROOT) / "gpurun_out"
     if out.is_dir():
         (out / "bench_force_dist.json").write_text(json.dumps(line) + "\n")
+
+
+# ---------------------------------------------------------------------------------------------- encoder beside a decode loop
+def test_encoder_on_a_cu_budget_is_bit_identical(tmpdir_module):
+    """wm_encoder_forward_shared: with a budget of CUs the persistent GEMM launches fewer workgroups over the SAME tiles,
+    so the audio features are bit-identical to the whole-chip pass -- at large-v2 width (1280: the persistent kernel's
+    shapes), for a budget of one workgroup per XCD, a ragged one (rounded down to a multiple of 8) and one above the CU count."""
+    synthetic.DIMS["large-v2-2layer"] = dict(synthetic.DIMS["large-v2"], n_audio_layer=2, n_text_layer=2)
+    eng = build_engine(tmpdir_module, "large-v2-2layer", 12)
+    enc = WhisperEncoding(eng)
+    mel = synthetic_mel(3, 3000, 80, 77).cuda()
+    whole = enc.get_audio_features(mel)
+    assert bool(torch.isfinite(whole.float()).all()) and float(whole.float().abs().max()) > 0
+    for budget in (8, 43, 96, 4096):
+        part = enc.get_audio_features_async(mel, cu_budget=budget)
+        torch.cuda.synchronize()
+        assert torch.equal(part, whole), budget
+    with pytest.raises(Exception):
+        enc.get_audio_features_async(mel, cu_budget=-1)
+
+
+def test_prefetched_encoder_and_pipelined_evaluation(tmpdir_module):
+    """WhisperEncoding.prefetch / collect (the encoder of the next batch enqueued from a helper thread on a stream of its
+    own, beside the decode loop) and summarize.eval_engines_stream over three batches: same features, same tokens and
+    texts as batch-by-batch evaluation."""
+    import summarize as S
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    dec.sample_len = 6
+    mels = [synthetic_mel(4, 2 * dims.n_audio_ctx, dims.n_mels, 300 + i).cuda() for i in range(3)]
+    plain = [S.eval_engines(enc, dec, m) for m in mels]
+    want_xa = enc.get_audio_features(mels[1])
+    enc.prefetch(mels[1], 16)
+    with pytest.raises(AssertionError):
+        enc.prefetch(mels[2], 16)                                 # one at a time
+    got_xa = enc.collect()
+    torch.cuda.synchronize()
+    assert torch.equal(got_xa, want_xa) and got_xa.wm_generation != want_xa.wm_generation
+    for budget in (16, 0):
+        piped = list(S.eval_engines_stream(enc, dec, iter(mels), cu_budget=budget))
+        assert len(piped) == 3
+        for a, b in zip(plain, piped):
+            assert [r.tokens for r in a] == [r.tokens for r in b]
+            assert [r.text for r in a] == [r.text for r in b]
+    assert enc._prefetch is None
