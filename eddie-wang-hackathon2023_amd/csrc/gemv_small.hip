@@ -37,7 +37,7 @@ constexpr int gemv_tpw(int wb) { return wb == 16 ? 10 : 5; }
 constexpr int GEMV_MAX_WAVES = 16;
 
 template <int WB, int MT, bool LN>       // WB: weight bits (16, 8, 4); MT: 16-row MFMA tiles (1, 2); LN: LayerNorm of the input rows
-__global__ __launch_bounds__(1024) void gemv_small_kernel(GemvSmallParams p) {
+__global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallParams p) {
     constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);   // inputs per 1 KiB weight tile
     constexpr int NM = KT / 32;                               // MFMAs (32-deep) per tile
     constexpr int TB = gemv_tpw(WB);
@@ -55,20 +55,29 @@ __global__ __launch_bounds__(1024) void gemv_small_kernel(GemvSmallParams p) {
 
     // ---- Everything this wave needs from global memory is requested up front, in the order it will be waited for (the
     // memory counter is in order: data requested behind the weights could only be waited for together with them):
-    //   1. with LayerNorm: the input rows, on their way to LDS (L2 hits, back first; the weights stay in flight behind them
-    //      while the rows are normalised);   2. the wave's weight tiles (HBM, read once);
-    //   3. without LayerNorm: the wave's activation fragments (L2).  One round trip per launch.
-    const int xs_row = (p.K + 8) * 2;                         // bytes; K + 8 halves: the 16 rows of a fragment read land on different banks
-    const int pieces_per_row = p.K >> 3, n_pieces = p.M * pieces_per_row;
-    constexpr int XV = 5;                                     // 16-byte pieces of the input rows per thread and sweep (M = 32, K = 1280, 1024 threads: one sweep)
-    uint4 xv[XV];
+    //   1. with LayerNorm: the rows whose statistics this wave computes (L2 hits, back first; the weights stay in flight
+    //      behind them), and the gamma / beta fragments;   2. the wave's weight tiles (HBM, read once);
+    //   3. the wave's activation fragments (L2) -- with LayerNorm requested after the statistics (registers).
     // (No load below sits behind a per-element run-time test: hipcc branches around such a load and waits for each one
     // before the next -- a dependent round trip per element.  Out-of-range elements re-read the last valid one instead.)
-    if (ln) {
+    const int pieces_per_row = p.K >> 3;
+    constexpr int RB = 8, XP = 3;               // rows per wave and sweep (register budget); 16-byte pieces per lane and row (K <= 1536)
+    uint4 xv[LN ? RB : 1][LN ? XP : 1];
+    auto stat_rows_load = [&](int r_first) {                  // rows r_first, r_first + nwave, ... (clamped)
 #pragma unroll
-        for (int u = 0; u < XV; ++u) {
-            const int c = min(u * nthr + tid, n_pieces - 1);
-            xv[u] = *(const uint4*)(p.A + (size_t)(c / pieces_per_row) * p.lda + (c % pieces_per_row) * 8);
+        for (int j = 0; j < RB; ++j) {
+            const h16* row = p.A + (size_t)min(r_first + j * nwave, p.M - 1) * p.lda;
+#pragma unroll
+            for (int u = 0; u < XP; ++u) xv[j][u] = *(const uint4*)(row + min(lane + 64 * u, pieces_per_row - 1) * 8);
+        }
+    };
+    half8v gp[LN ? XP : 1], bp[LN ? XP : 1];                  // gamma / beta at this lane's pieces
+    if constexpr (ln) {
+        stat_rows_load(wid);
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            gp[u] = *(const half8v*)(p.ln_g + min(lane + 64 * u, pieces_per_row - 1) * 8);
+            bp[u] = *(const half8v*)(p.ln_b + min(lane + 64 * u, pieces_per_row - 1) * 8);
         }
     }
     const int t_last = max(t_end - 1, 0);
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(1024) void gemv_small_kernel(GemvSmallParams p) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) wreg[i] = __builtin_nontemporal_load(wt + (size_t)min(t_begin + i, t_last) * 64);
     half8v a[TB][MT][NM];       // this lane's KT / 4 inputs of each tile, per row tile: NM fragments of 8 (rows >= M: clamped, never stored)
-    if constexpr (!ln) {
+    auto frag_load = [&]() {
 #pragma unroll
         for (int i = 0; i < TB; ++i)
 #pragma unroll
@@ -85,43 +94,52 @@ __global__ __launch_bounds__(1024) void gemv_small_kernel(GemvSmallParams p) {
 #pragma unroll
                 for (int m = 0; m < NM; ++m) a[i][mt][m] = *(const half8v*)(arow + m * 8);
             }
-    }
+    };
+    if constexpr (!ln) frag_load();
 
     // ---- LayerNorm of the input rows (W/torch_model.py:25-27: fp32 statistics over the fp16 row, two passes, eps 1e-5,
-    // affine, result rounded to fp16), done by the workgroup itself: the M <= 32 rows are a few KB.  Each wave normalises
-    // its share of the rows in LDS, in place; the MFMA fragments are then read from LDS.
+    // affine, result rounded to fp16) without a LayerNorm kernel.  Row r belongs to wave r % nwave: the wave has the row in
+    // registers (a lane holds pieces lane, lane + 64, lane + 128), runs both passes and the affine step there and writes
+    // the normalised row to LDS once; after one barrier the MFMA fragments are read from LDS.  Everything from global memory
+    // (rows, gamma / beta, weights) was requested before the first wait: one round trip.
+    // (Two earlier forms, both slower: all rows copied to LDS raw and normalised there in three LDS passes -- the copy
+    // took several dependent sweeps above 8 rows, 14.8 us per launch at 16 rows against 7.3 us without LayerNorm; and
+    // statistics only, every lane normalising its own fragments after a second round trip to L2 -- +5 us at ONE row.)
     if constexpr (ln) {
+        const int xs_row = (p.K + 8) * 2;                     // bytes; K + 8 halves: the 16 rows of a fragment read land on different banks
+        for (int r0 = wid; r0 < p.M; r0 += RB * nwave) {
+            if (r0 != wid) stat_rows_load(r0);
 #pragma unroll
-        for (int u = 0; u < XV; ++u) {
-            const int c = u * nthr + tid;
-            if (c < n_pieces) *(uint4*)(s_x + (c / pieces_per_row) * xs_row + (c % pieces_per_row) * 16) = xv[u];      // (a store: no wait)
-        }
-        for (int c = XV * nthr + tid; c < n_pieces; c += nthr)              // (more rows than one sweep covers)
-            *(uint4*)(s_x + (c / pieces_per_row) * xs_row + (c % pieces_per_row) * 16) =
-                *(const uint4*)(p.A + (size_t)(c / pieces_per_row) * p.lda + (c % pieces_per_row) * 8);
-        __syncthreads();
-        for (int r = wid; r < p.M; r += nwave) {
-            unsigned char* row = s_x + r * xs_row;
-            float sum = 0.f;
-            for (int c = lane; c < pieces_per_row; c += 64) {
-                const half8v x = *(const half8v*)(row + c * 16);
+            for (int j = 0; j < RB; ++j) {
+                if (r0 + j * nwave >= p.M) continue;          // wave-uniform (the loads of such a row were clamped, its values are not used)
+                float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sum += (float)x[e];
-            }
-            const float mean = wave_sum(sum) / (float)p.K;
-            float sq = 0.f;
-            for (int c = lane; c < pieces_per_row; c += 64) {
-                const half8v x = *(const half8v*)(row + c * 16);
+                for (int u = 0; u < XP; ++u) {
+                    const half8v x = __builtin_bit_cast(half8v, xv[j][u]);
+                    if (lane + 64 * u < pieces_per_row) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = (float)x[e] - mean; sq += d * d; }
-            }
-            const float rstd = rsqrtf(wave_sum(sq) / (float)p.K + 1e-5f);
-            for (int c = lane; c < pieces_per_row; c += 64) {
-                half8v x = *(const half8v*)(row + c * 16);
-                const half8v gm = *(const half8v*)(p.ln_g + c * 8), bt = *(const half8v*)(p.ln_b + c * 8);
+                        for (int e = 0; e < 8; ++e) sum += (float)x[e];
+                    }
+                }
+                const float mean = wave_sum(sum) / (float)p.K;
+                float sq = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = (h16)(((float)x[e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
-                *(half8v*)(row + c * 16) = x;
+                for (int u = 0; u < XP; ++u) {
+                    const half8v x = __builtin_bit_cast(half8v, xv[j][u]);
+                    if (lane + 64 * u < pieces_per_row) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = (float)x[e] - mean; sq += d * d; }
+                    }
+                }
+                const float rstd = rsqrtf(wave_sum(sq) / (float)p.K + 1e-5f);
+                const int r = r0 + j * nwave;
+#pragma unroll
+                for (int u = 0; u < XP; ++u) {
+                    half8v x = __builtin_bit_cast(half8v, xv[j][u]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = (h16)(((float)x[e] - mean) * rstd * (float)gp[u][e] + (float)bp[u][e]);
+                    if (lane + 64 * u < pieces_per_row) *(half8v*)(s_x + r * xs_row + (lane + 64 * u) * 16) = x;
+                }
             }
         }
         __syncthreads();
@@ -249,9 +267,11 @@ int launch_gemv_small(const GemvSmallParams& p_, hipStream_t stream) {
     WM_REQUIRE(p.mode != 0 || p.out32, "gemv_small: mode 0 needs out32");
     WM_REQUIRE((p.mode != 1 && p.mode != 3) || p.out16, "gemv_small: modes 1 and 3 need out16");
     WM_REQUIRE(p.mode != 2 || p.x, "gemv_small: mode 2 needs x");
+    // LayerNorm variant: a lane holds up to 3 16-byte pieces of a row, a workgroup has at most 8 waves (register budget),
+    // the normalised rows sit in LDS
     constexpr size_t LN_LDS_MAX = 100 * 1024;      // 32 rows of 1536 channels
-    WM_REQUIRE(!p.ln_g || (p.ln_b && p.K % 8 == 0 && (size_t)p.M * (p.K + 8) * 2 <= LN_LDS_MAX),
-               "gemv_small: LayerNorm needs beta and M * (K + 8) <= 50 K inputs (M=%d, K=%d)", p.M, p.K);
+    WM_REQUIRE(!p.ln_g || (p.ln_b && p.K % 8 == 0 && p.K <= 1536 && p.ksplit <= 8 && (size_t)p.M * (p.K + 8) * 2 <= LN_LDS_MAX),
+               "gemv_small: LayerNorm needs beta, K <= 1536 and <= 8 K slices (K=%d, slices=%d)", p.K, p.ksplit);
     static bool attr_set = false;                  // (per process; the attribute is a property of the code object)
     if (!attr_set) {
         const void* kerns[6] = {(const void*)gemv_small_kernel<16, 1, true>, (const void*)gemv_small_kernel<16, 2, true>, (const void*)gemv_small_kernel<8, 1, true>,

@@ -369,7 +369,7 @@ def test_main_loop_fast_equals_reference_loop_and_oracle(tmpdir_module):
 @pytest.fixture
 def one_decode_path():
     """Pins the decoder to the big-batch kernels for every batch size (wm_set_small_batch_rows(0)), for tests that compare
-    a batch with its rows taken alone bit for bit: the fused small-batch path (<= 4 rows by default) adds up its K slices
+    a batch with its rows taken alone bit for bit: the fused small-batch path (<= 8 rows by default) adds up its K slices
     in another order, so across the switch rows agree to fp32 summation order, not bit for bit."""
     lib = native.load_library()
     prev = lib.wm_set_small_batch_rows(0)
@@ -433,9 +433,10 @@ def test_batch_independence(tmpdir_module, one_decode_path):
         assert torch.equal(lb[0], lg[b])
 
 
-def test_micro_batched_streams_give_identical_tokens(tmpdir_module):
+def test_micro_batched_streams_give_identical_tokens(tmpdir_module, one_decode_path):
     """main_loop splits a large batch into stream-parallel groups; utterances are independent, so
-    the tokens must be exactly those of the single-stream run."""
+    the tokens must be exactly those of the single-stream run.  (One set of kernels for every group size: 16 rows in one
+    group take the big-batch kernels by default, two groups of 8 the fused small-batch ones.)"""
     dims = Dims(**synthetic.DIMS["micro-fullvocab"])
     eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
     enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
