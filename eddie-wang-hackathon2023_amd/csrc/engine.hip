@@ -531,7 +531,8 @@ int cross_nsplit(int B, int H) {
     // fill >= ~2 workgroups per CU with (b, h, split) triples
     int n = (512 + B * H - 1) / (B * H);
     if (n < 1) n = 1;
-    if (n > 16) n = 16;
+    if (n > 8) n = 8;       // B = 1: 8 splits + combine 10.2 us, 16 splits 11.3, 4 splits 10.5 (scripts/bench_cross_small.py); one
+                            // 16-wave workgroup per head over the whole key range, without a combine launch: 12.2
     return n;
 }
 
