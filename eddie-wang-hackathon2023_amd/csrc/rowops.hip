@@ -138,8 +138,97 @@ int launch_row_finish(const RowFinishParams& p, hipStream_t stream) {
     return 0;
 }
 
+// ---- standalone LayerNorm, streaming form: one WAVE per row, the row in registers ----------------------------------
+// The encoder runs 65 LayerNorms over 1500 x batch rows: with one 256-thread workgroup per row (row_finish_kernel, the
+// row staged in LDS, two block-wide reductions) a launch over 864 000 rows took 2.4 ms against 0.8 ms of HBM time.  Here a
+// wave holds its rows in registers and streams: 8-byte pieces, two rows in flight per wave, no LDS, no barrier.
+// The arithmetic is row_finish_kernel's bit for bit, so the two are interchangeable: lane l plays that kernel's threads
+// l, l + 64, l + 128, l + 192 (thread t owns the 4-element groups t, t + 256, ...), the four per-wave sums are reduced
+// separately and added in wave order, exactly as block_sum does.
+constexpr int LNS_G = 6;                       // groups per lane: N <= 1536
+constexpr int LNS_ROWS = 2;                    // rows in flight per wave
+
+__global__ __launch_bounds__(256) void layernorm_stream_kernel(const h16* x, int ldx, int M, int N, const h16* g, const h16* b,
+                                                               h16* out, int ldo) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n4 = N >> 2;
+    const int row0 = (blockIdx.x * 4 + wid) * LNS_ROWS;
+    if (row0 >= M) return;                     // wave-uniform
+    // group j of this lane: column group c = lane + 64 * (j & 3) + 256 * (j >> 2)  (thread t = lane + 64 * (j & 3), trip j >> 2)
+    half4v xv[LNS_ROWS][LNS_G], gv[LNS_G], bv[LNS_G];
+#pragma unroll
+    for (int r = 0; r < LNS_ROWS; ++r) {
+        const h16* row = x + (size_t)min(row0 + r, M - 1) * ldx;
+#pragma unroll
+        for (int j = 0; j < LNS_G; ++j) {
+            const int c = min(lane + 64 * (j & 3) + 256 * (j >> 2), n4 - 1);
+            xv[r][j] = *(const half4v*)(row + c * 4);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LNS_G; ++j) {
+        const int c = min(lane + 64 * (j & 3) + 256 * (j >> 2), n4 - 1);
+        gv[j] = *(const half4v*)(g + c * 4);
+        bv[j] = *(const half4v*)(b + c * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < LNS_ROWS; ++r) {
+        if (row0 + r >= M) break;              // wave-uniform, after every load was issued
+        float xf[LNS_G][4];
+#pragma unroll
+        for (int j = 0; j < LNS_G; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xf[j][e] = (float)xv[r][j][e];
+        // pass 1: thread t's partial sum over its trips, per "wave" w = j & 3; then the four wave sums in order
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < (LNS_G + 3) / 4; ++k) {
+                const int j = w + 4 * k;
+                if (j < LNS_G && lane + 64 * w + 256 * k < n4) s += (xf[j][0] + xf[j][1]) + (xf[j][2] + xf[j][3]);
+            }
+            tot += wave_sum(s);
+        }
+        const float mean = tot / (float)N;
+        float qt = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < (LNS_G + 3) / 4; ++k) {
+                const int j = w + 4 * k;
+                if (j < LNS_G && lane + 64 * w + 256 * k < n4) {
+                    const float a = xf[j][0] - mean, bb = xf[j][1] - mean, cc = xf[j][2] - mean, d = xf[j][3] - mean;
+                    q += (a * a + bb * bb) + (cc * cc + d * d);
+                }
+            }
+            qt += wave_sum(q);
+        }
+        const float rstd = rsqrtf(qt / (float)N + 1e-5f);
+        h16* orow = out + (size_t)(row0 + r) * ldo;
+#pragma unroll
+        for (int j = 0; j < LNS_G; ++j) {
+            const int c = lane + 64 * (j & 3) + 256 * (j >> 2);
+            if (c < n4)
+                st_h4(orow + c * 4, make_float4((xf[j][0] - mean) * rstd * (float)gv[j][0] + (float)bv[j][0],
+                                                (xf[j][1] - mean) * rstd * (float)gv[j][1] + (float)bv[j][1],
+                                                (xf[j][2] - mean) * rstd * (float)gv[j][2] + (float)bv[j][2],
+                                                (xf[j][3] - mean) * rstd * (float)gv[j][3] + (float)bv[j][3]));
+        }
+    }
+}
+
 int launch_layernorm(const h16* x, int ldx, int M, int N, const h16* g, const h16* b, h16* out, int ldo,
                      hipStream_t stream) {
+    const char* form = getenv("WM_LN_FORM");       // "workgroup": row_finish_kernel's form for every width (A/B runs, the bit-identity test)
+    if (N % 4 == 0 && N <= LNS_G * 256 && ldx % 4 == 0 && ldo % 4 == 0 && M > 0 && !(form && form[0] == 'w')) {      // by row width only: a row's result never depends on M
+        const int rows_per_wg = 4 * LNS_ROWS;
+        hipLaunchKernelGGL(layernorm_stream_kernel, dim3((M + rows_per_wg - 1) / rows_per_wg), dim3(256), 0, stream, x, ldx, M, N, g, b, out, ldo);
+        WM_LAUNCH_CHECK(stream, "layernorm");
+        return 0;
+    }
     RowFinishParams p{};
     p.mode = 2; p.M = M; p.N = N; p.x = const_cast<h16*>(x); p.ldx = ldx; p.ln_g = g; p.ln_b = b;
     p.out = out; p.ldo = ldo;

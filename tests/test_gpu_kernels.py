@@ -362,6 +362,25 @@ def test_layernorm(lib, M, N):
     assert np.abs(out.float().cpu().numpy() - ref).max() <= 2.0 ** -10 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N", [(1, 1280), (7, 1280), (4501, 1280), (33, 384), (9, 128), (5, 1536), (10, 1024)])
+def test_layernorm_streaming_form_is_bit_identical(lib, M, N, monkeypatch):
+    """The streaming LayerNorm (one wave per row, rows in registers: the encoder's 65 launches over 1500 x batch rows) adds
+    up a row in the order of the one-workgroup-per-row form inside row_finish_kernel, so the two are interchangeable bit
+    for bit -- ragged row counts (the last wave's second row, the last workgroup's idle waves) and every row width included."""
+    r = rng(M + N)
+    x = dev((r.standard_normal((M, N)) * 3 + 1).astype(np.float16))
+    g, b = dev(r.uniform(0.5, 1.5, N).astype(np.float16)), dev(r.uniform(-0.5, 0.5, N).astype(np.float16))
+    outs = []
+    for form in ("", "workgroup"):
+        monkeypatch.setenv("WM_LN_FORM", form)
+        out = torch.full((M + 1, N), 7.0, dtype=torch.float16, device="cuda")
+        native.check(lib.wm_layernorm(x.data_ptr(), N, M, N, g.data_ptr(), b.data_ptr(), out.data_ptr(), N, stream()))
+        torch.cuda.synchronize()
+        assert bool((out[M] == 7.0).all())                    # nothing written past the last row
+        outs.append(out[:M].clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------------------------------ encoder attention
 @pytest.mark.parametrize("B,T,H", [(1, 64, 1), (2, 150, 2), (1, 1500, 3), (3, 300, 2)])
 def test_attn_encoder(lib, B, T, H):
