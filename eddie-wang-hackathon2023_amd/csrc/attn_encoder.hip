@@ -35,7 +35,10 @@ constexpr int KT_KEYS = 64;
 constexpr int AROW = 128;                      // LDS bytes per key row (64 halves, chunk-swizzled)
 constexpr int KV_TILE = KT_KEYS * AROW;        // 8192
 
-template <int QB>
+// PERSIST: fewer workgroups than (query tile, head, clip) items, each walking over its share -- the form used when the
+// encoder runs on a budget of CUs beside another stream's work (wm_encoder_forward_shared): two workgroups fill a CU's
+// register file, so 2 x budget of them occupy `budget` CUs and nothing else is dispatched there.  Same arithmetic.
+template <int QB, bool PERSIST = false>
 __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {     // 2 waves per SIMD: <= 256 registers
     __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * KV_TILE];
     auto sK = [&](int b) { return smem + b * 2 * KV_TILE; };
@@ -43,9 +46,15 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
     const int C = p.H * 64;
-    const int q_base = blockIdx.x * (64 * QB) + wid * (16 * QB);
+    int item = blockIdx.x;                     // PERSIST only (the launch never has more workgroups than items)
+    do {
+    int bx, h, b;
+    if constexpr (PERSIST) {
+        const int nx = (p.T + 64 * QB - 1) / (64 * QB);
+        bx = item % nx; h = (item / nx) % p.H; b = item / (nx * p.H);
+    } else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
+    const int q_base = bx * (64 * QB) + wid * (16 * QB);
     const h16* base = p.qkv + (size_t)b * p.T * p.ld;
 
     // ---- Q^T fragments: B operand, lane -> query li, dims 32s + 8g .. +8 --------------------------
@@ -213,6 +222,8 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
             *(half4v*)(dst + db * 16 + g * 4) = w;
         }
     }
+    if constexpr (PERSIST) item += gridDim.x;
+    } while (PERSIST && item < ((p.T + 64 * QB - 1) / (64 * QB)) * p.H * p.B);
 }
 
 int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream) {
@@ -222,7 +233,9 @@ int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream) {
     // the faster variant at every batch size for T = 1500 (B = 1: 60 vs 67 us, B = 128: 21 vs 36 us per clip-layer).
     // The choice depends on T only, never on the batch: the two instantiations agree to one fp16 ulp, not bit for bit,
     // and the result of a clip must not depend on how many clips share the launch (tests: batch independence).
-    if (p.T > 128) {
+    if (p.T > 128 && p.max_wgs > 0 && p.max_wgs < ((p.T + 255) / 256) * p.H * p.B) {
+        hipLaunchKernelGGL((attn_encoder_kernel<4, true>), dim3(p.max_wgs), dim3(256), 0, stream, p);
+    } else if (p.T > 128) {
         dim3 grid((p.T + 255) / 256, p.H, p.B);
         hipLaunchKernelGGL(attn_encoder_kernel<4>, grid, dim3(256), 0, stream, p);
     } else {

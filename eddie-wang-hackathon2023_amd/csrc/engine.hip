@@ -462,7 +462,7 @@ int wm_encoder_forward_shared(const wm_engine* e, const void* mel, int B, void* 
             p.colscale_n = 2 * C; p.colscale = qk_scale;
             if (big(L.qkv, e, w.xn, C, M, w.qkv, 3 * C, 0, nullptr, 0, s, &p, cu_budget)) return 2;
         }
-        AttnEncParams ap{w.qkv, 3 * C, B, T, H, w.ctx, C};
+        AttnEncParams ap{w.qkv, 3 * C, B, T, H, w.ctx, C, 2 * cu_budget};      // two workgroups fill a CU's registers
         if (launch_attn_encoder(ap, s)) return 2;
         if (big(L.out, e, w.ctx, C, M, w.x, C, 0, w.x, C, s, nullptr, cu_budget)) return 2;
         if (launch_layernorm(w.x, C, M, C, L.ln2g, L.ln2b, w.xn, C, s)) return 2;

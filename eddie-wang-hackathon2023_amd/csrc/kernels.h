@@ -105,6 +105,7 @@ struct AttnEncParams {
     const h16* qkv; int ld;                  // [B*T][3C] rows, q | k | v column blocks (q,k pre-scaled by d^-0.25)
     int B, T, H;                             // head size 64
     h16* out; int ldo;                       // [B*T][C]
+    int max_wgs;                             // > 0: persistent launch of at most that many workgroups (shared encoder)
 };
 int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream);
 
