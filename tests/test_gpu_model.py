@@ -779,6 +779,14 @@ def test_summarize_pipeline_on_flac(tmpdir_module, golden_dir, tmp_path):
     enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
     hyps, refs, _ = S.transcribe_dataset(pairs, lambda mel: S.eval_engines(enc, dec, mel), 3, torch.device("cuda"))
     assert len(set(hyps)) == 1 and refs == ["HE COULD WAIT NO LONGER"] * 3
+    # the pipelined job (--overlap_encoder: the next batch's audio is read and encoded while the current one decodes) gives
+    # the same hypotheses and the same report
+    piped = S.main(S.parse_arguments(["--test_trt_llm", "--engine_dir", str(eng), "--dataset_dir", str(tmp_path / "ds"),
+                                      "--batch_size", "2", "--log_level", "error", "--overlap_encoder"]))["whisper-mi355"]
+    assert piped["utterances"] == 3 and piped["wer"] == report["wer"]
+    hyps_p, refs_p, _ = S.transcribe_dataset_stream(pairs, lambda mels: S.eval_engines_stream(enc, dec, mels, cu_budget=8), 2,
+                                                    torch.device("cuda"))
+    assert hyps_p == hyps and refs_p == refs
     # the mel the pipeline fed: device front end == torch.stft mirror on the decoded FLAC
     audio = wu.pad_or_trim(wu.load_audio(str(pairs[0][0])))
     dev = wu.log_mel_spectrogram_device(torch.from_numpy(audio).cuda(), dtype=torch.float32).cpu()
