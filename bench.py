@@ -9,6 +9,11 @@ prefill (3 tokens) -> T forced greedy decode steps with Whisper's logit rules (E
 that random weights decode exactly T tokens), then the gather of the token ids.  Everything the
 reference's run.py times per utterance (W/run.py:56-61) is inside the timed region.
 
+Consecutive steps are software-pipelined the way a transcription job over many batches is (summarize.py
+--overlap_encoder): while the decode loop of step n runs, the encoder of step n + 1 runs beside it on --encoder-cus CUs
+(default 96; 0 = one stage after the other).  All K encoders, projections, language passes, prefills and decode loops of
+the K timed steps run inside the timed region: the first encoder in the open, the last decode loop with nothing beside it.
+
 Workload = BASELINE.json configs[3]: Whisper large-v2, weight-only int8 + int8 KV cache + fp16
 cross K/V ("the configuration the metric is quoted on"); random-init weights (no checkpoint exists
 on any box), KV scales calibrated with the reference's rule (torch_whisper_convert.py -kv).
@@ -16,7 +21,8 @@ on any box), KV scales calibrated with the reference's rule (torch_whisper_conve
 Prints ONE JSON line (rank 0): value = decoded tokens per second over the whole job
 (n_gpus * B * T tokens per step / step time), plus `rtf`, `roofline` for the dominant kernel (decode
 cross-attention, HBM-bound: measured in situ with HIP events on its launch stream) and
-`cpu_baseline` (the oracle, a port of the reference's PyTorch path, timed on this box's host cores).
+`cpu_baseline` (the oracle, a port of the reference's PyTorch path, timed on this box's host cores: one full-depth clip).
+`python bench.py --gpus N` without a launcher starts the N ranks itself (fresh child processes).
 """
 from __future__ import annotations
 
