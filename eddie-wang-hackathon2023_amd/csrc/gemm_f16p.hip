@@ -205,6 +205,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         const int tile = lo + j0 + t * per_xcd;
         const int tm = tile / nt_n, tn = tile - tm * nt_n;
         const int row0 = tm * BM, col0 = tn * BN;
+        const int hs_b0 = p.out_mode == 1 ? row0 / p.hs_T : 0, hs_t0 = p.out_mode == 1 ? row0 - hs_b0 * p.hs_T : 0;     // wave-uniform
         // every lane-dependent quantity of the epilogue is derived from `le`, which the compiler cannot see through: nothing
         // of the epilogue's address arithmetic is hoisted out of the tile loop into registers the K loop needs
         int le = lane;
@@ -277,12 +278,18 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                             for (int j = 0; j < 4; ++j)
                                 *(half4v*)(crow + j * 16) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
                         } else {       // head-split [B, 2, H, T, 64] (whisper/model.py:519); a lane's 4 channels stay inside one head
+                            // (no per-element integer division at Whisper's sizes: the tile's first row is divided once, on the
+                            // scalar unit, a tile spans fewer rows than an utterance has positions, and K | V is one comparison;
+                            // the divisions cost this epilogue several of a K = 1280 tile's 40 stages)
                             const int HC = p.hs_H * 64;
-                            const int bb = row / p.hs_T, tt = row % p.hs_T;
+                            int bb = hs_b0, tt = hs_t0 + (row - row0);
+                            if (p.hs_T >= BM) { if (tt >= p.hs_T) { tt -= p.hs_T; ++bb; } }       // at most one utterance boundary inside a tile
+                            else { bb = row / p.hs_T; tt = row - bb * p.hs_T; }                   // (tiny models: several utterances per tile)
+                            const bool two = p.N == 2 * HC;                                        // K | V side by side: one comparison
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const int col = colp + j * 16;
-                                const int kv = p.hs_kv < 0 ? col / HC : p.hs_kv, cc = p.hs_kv < 0 ? col % HC : col;
+                                const int kv = p.hs_kv < 0 ? (two ? (col >= HC ? 1 : 0) : col / HC) : p.hs_kv, cc = p.hs_kv < 0 ? col - kv * HC : col;
                                 const size_t off = ((((size_t)bb * 2 + kv) * p.hs_H + (cc >> 6)) * p.hs_T + tt) * 64 + (cc & 63);
                                 if (p.q8_inv_scale > 0.f) {      // int8 cross K/V (opt-in): the fp16 result, quantised like the self-attention cache
                                     char4 q;
