@@ -160,11 +160,12 @@ def pmc_traffic(group: int, kv_bytes: int) -> dict:
     return {"traffic": int(round(group * rec["fetch_bytes_per_utterance_layer"])), "traffic_source": os.path.relpath(files[-1], ROOT)}
 
 
-def in_situ_probe(dec, lib, xa, B: int, n_micro: int, algo_bytes: int, steps: int = 20) -> dict:
+def in_situ_probe(dec, lib, xa, B: int, n_micro: int, algo_bytes: int, steps: int = 20, beside=None) -> dict:
     """Durations of the cross-attention launches as the decode loop runs them: replayed from the captured graphs, the
     utterance groups' launches and short-kernel chains sharing the chip.  A 1-thread stamp kernel before and after every
     launch writes the device wall clock (wm_debug_timeline); the graphs are re-captured with the stamps for this probe
-    and dropped afterwards."""
+    and dropped afterwards.  `beside` = (encoder, mel, cus): the same probe with the next step's encoder running beside the
+    loop on that many CUs, as in the pipelined steps."""
     import native
     st = dec._state[B]
     st["graphs"].clear()
@@ -176,6 +177,13 @@ def in_situ_probe(dec, lib, xa, B: int, n_micro: int, algo_bytes: int, steps: in
         dec.sample_len = steps
         dec.main_loop(xa, ignore_eot=True)
         torch.cuda.synchronize()
+        if beside is not None:           # graph capture synchronises the device: capture first (above), then measure beside the encoder
+            buf.zero_()
+            beside[0].prefetch(beside[1], beside[2])
+            time.sleep(0.05)             # let the encoder's first launches reach the GPU
+            dec.main_loop(xa, ignore_eot=True)
+            beside[0].collect()
+            torch.cuda.synchronize()
     finally:
         native.check(lib.wm_debug_timeline(None, 0))
         dec.sample_len = keep
@@ -373,6 +381,9 @@ def main():
             # ---- the same kernel IN SITU: graph-replayed launches, the groups sharing the HBM (device-side stamps around
             # every launch, wm_debug_timeline; measured on extra, untimed decode steps after the timed region) ----
             roofline.update(in_situ_probe(dec, lib, last["xa"], B, n_micro, algo_bytes))
+            if args.encoder_cus > 0 and args.steps > 1:
+                b = in_situ_probe(dec, lib, last["xa"], B, n_micro, algo_bytes, beside=(enc, mel, args.encoder_cus))
+                roofline["in_situ_beside_encoder"] = {k.replace("in_situ_", ""): v for k, v in b.items() if k != "in_situ_note"}
             if decode_loop_ms is not None:
                 step_ms = decode_loop_ms / T
                 cross_bytes = B * dims["n_text_layer"] * H * 2 * Tk * 64 * kv_bytes          # B x 245.76 MB at large-v2
