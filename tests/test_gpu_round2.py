@@ -265,3 +265,10 @@ def test_prefetched_encoder_and_pipelined_evaluation(tmpdir_module):
             assert [r.tokens for r in a] == [r.tokens for r in b]
             assert [r.text for r in a] == [r.text for r in b]
     assert enc._prefetch is None
+    # an error in the helper thread surfaces in collect(), and the encoder is usable afterwards
+    enc.prefetch(mels[0], -1)
+    with pytest.raises(Exception):
+        enc.collect()
+    assert enc._prefetch is None
+    enc.prefetch(mels[1], 16)
+    assert torch.equal(enc.collect(), want_xa)
