@@ -126,5 +126,7 @@ class WhisperEncoding:
         th.join()
         if "error" in box:
             raise box["error"]
-        torch.cuda.current_stream().wait_stream(self._prefetch_stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self._prefetch_stream)
+        box["xa"].record_stream(cur)             # allocated on the side stream, used on this one
         return box["xa"]
