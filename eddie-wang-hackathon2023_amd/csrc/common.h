@@ -59,15 +59,35 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float r16(float x) { return (float)(h16)x; }   // round through fp16
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. far below an fp16 ulp of any GELU output
-// that matters) on the hardware exp / rcp: ~12 instructions instead of libm's ~40 in the epilogues.
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. far below an fp16 ulp of any GELU output that matters) on the
+// hardware reciprocal and exp2 (v_rcp_f32 / v_exp_f32, 1 ulp each -- inside the formula's own error): 14 instructions + 2
+// transcendentals per value.  (The first version called __frcp_rn and __expf: a correctly rounded reciprocal is a full IEEE
+// division sequence and __expf its own range reduction -- 35 instructions per value, found in the ISA of the mlp1 GEMM, whose
+// whole deficit against the plain GEMMs was this epilogue.)
 __device__ __forceinline__ float fast_erf(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    return copysignf(1.0f - poly * __expf(-ax * ax), x);
+    const float e = __builtin_amdgcn_exp2f(ax * (ax * -1.4426950408889634f));        // exp(-ax^2)
+    return copysignf(1.0f - poly * e, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// The same arithmetic on two values at a time: the multiplies and fused multiply-adds become packed fp32 instructions
+// (v_pk_mul_f32 / v_pk_fma_f32: two values per issue), rcp and exp2 stay one per value.  Every operation is the scalar
+// function's, in its order, so the results are bit-identical (scripts/lab/gemm_lab3.hip compares a GEMM that uses this
+// form with one that uses the scalar form, element by element).
+__device__ __forceinline__ float2v gelu_erf2(float2v x) {
+    const float2v xs = x * 0.70710678118654752f;
+    const float2v ax = {fabsf(xs[0]), fabsf(xs[1])};
+    const float2v d = 1.0f + 0.3275911f * ax;
+    const float2v t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const float2v poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float2v a2 = ax * (ax * -1.4426950408889634f);
+    const float2v e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+    const float2v m = 1.0f - poly * e;
+    const float2v erf = {copysignf(m[0], xs[0]), copysignf(m[1], xs[1])};
+    return 0.5f * x * (1.0f + erf);
+}
 __device__ __forceinline__ float gelu_tanh(float x) {
     return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }

@@ -249,7 +249,10 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[j][r] = r16(gelu_erf(v[j][r]));
+                            for (int r = 0; r < 4; r += 2) {             // two values per packed fp32 instruction, same arithmetic
+                                const float2v y = gelu_erf2(float2v{v[j][r], v[j][r + 1]});
+                                v[j][r] = r16(y[0]); v[j][r + 1] = r16(y[1]);
+                            }
                     } else if (ACT == 2) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
