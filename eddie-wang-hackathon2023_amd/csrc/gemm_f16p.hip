@@ -54,7 +54,9 @@ constexpr int A_PART = BM * BK * 2, STAGE = (BM + BN) * BK * 2;      // 16 KB + 
 constexpr int MAX_N = 8192;                                          // the bias vector sits in LDS behind the ring: 16 KB
 }  // namespace f16p
 
-template <int STAGES, int ACT>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU
+// SIMPLE: plain row-major output and residual (the encoder layers' four GEMMs): the epilogue then carries none of the
+// strided-view / head-split / int8 address arithmetic (integer divisions, their branches) the general form is compiled with.
+template <int STAGES, int ACT, bool SIMPLE = false>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU
 __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     using namespace f16p;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         const int tile = lo + j0 + t * per_xcd;
         const int tm = tile / nt_n, tn = tile - tm * nt_n;
         const int row0 = tm * BM, col0 = tn * BN;
-        const int hs_b0 = p.out_mode == 1 ? row0 / p.hs_T : 0, hs_t0 = p.out_mode == 1 ? row0 - hs_b0 * p.hs_T : 0;     // wave-uniform
+        const int hs_b0 = !SIMPLE && p.out_mode == 1 ? row0 / p.hs_T : 0, hs_t0 = !SIMPLE && p.out_mode == 1 ? row0 - hs_b0 * p.hs_T : 0;     // wave-uniform
         // every lane-dependent quantity of the epilogue is derived from `le`, which the compiler cannot see through: nothing
         // of the epilogue's address arithmetic is hoisted out of the tile loop into registers the K loop needs
         int le = lane;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                 for (int i = 0; i < 4; ++i) {
                     const int row = row0 + wr * 64 + i * 16 + rl;
                     const int rowc = row < p.M ? row : p.M - 1;
-                    const h16* rrow = p.residual + (size_t)(p.res_mod > 0 ? rowc % p.res_mod : rowc) * p.ldr + colw;
+                    const h16* rrow = p.residual + (size_t)(!SIMPLE && p.res_mod > 0 ? rowc % p.res_mod : rowc) * p.ldr + colw;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r4[i][j] = *(const half4v*)(rrow + j * 16);
                 }
@@ -273,7 +275,14 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[j][r] += (float)r4[i][jh * 4 + j][r];
                     }
-                    if (row < p.M) {
+                    if constexpr (SIMPLE) {
+                        if (row < p.M) {
+                            h16* crow = p.C + (size_t)row * p.ldc + colp;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                *(half4v*)(crow + j * 16) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
+                        }
+                    } else if (row < p.M) {
                         if (p.out_mode == 0) {
                             h16* crow = p.C + (p.c_rows > 0 ? (size_t)(row / p.c_rows) * p.c_bstride + (size_t)(row % p.c_rows) * p.ldc
                                                             : (size_t)row * p.ldc) + colp;
@@ -340,13 +349,14 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     const int slot = (dev >= 0 && dev < 64) ? dev : 0;
     int n_cu = n_cu_dev[slot].load(std::memory_order_relaxed);
     using Kern = void (*)(GemmBigParams);
-    static const Kern kerns[3] = {gemm_f16p_kernel<STAGES, 0>, gemm_f16p_kernel<STAGES, 1>, gemm_f16p_kernel<STAGES, 2>};
+    static const Kern kerns[6] = {gemm_f16p_kernel<STAGES, 0>, gemm_f16p_kernel<STAGES, 1>, gemm_f16p_kernel<STAGES, 2>,
+                                  gemm_f16p_kernel<STAGES, 0, true>, gemm_f16p_kernel<STAGES, 1, true>, gemm_f16p_kernel<STAGES, 2, true>};
     constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE + MAX_N * 2;
     if (n_cu == 0) {
         int v = 0;
         WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
         n_cu = v > 0 ? v : 256;
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 6; ++a)
             WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         n_cu_dev[slot].store(n_cu, std::memory_order_relaxed);
     }
@@ -357,7 +367,8 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     if (p.max_wgs > 0 && p.max_wgs < grid) grid = p.max_wgs >= 8 ? (p.max_wgs / 8) * 8 : 8;
     const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(kerns[p.act], dim3(grid), dim3(512), LDS_BYTES, stream, p);
+    const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f;
+    hipLaunchKernelGGL(kerns[p.act + (simple ? 3 : 0)], dim3(grid), dim3(512), LDS_BYTES, stream, p);
     WM_LAUNCH_CHECK(stream, "gemm_f16p");
     return 0;
 }
