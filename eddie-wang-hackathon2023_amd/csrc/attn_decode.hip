@@ -263,6 +263,11 @@ int launch_attn_self(const AttnSelfParams& p, hipStream_t stream) {
 // load instruction (lane -> row lane>>3, 16-byte column lane&7), 4 instructions (4 KiB) in flight per wave.
 constexpr int CROSS_MAX_KEYS = 1536;
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {        // the value of the lane the DPP control selects (all lanes active)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 // I8 (opt-in, beyond the reference: SURVEY 8f-4): K/V are int8 codes [B,2,H,Tk,64] with one scale t per layer; a row is
 // 64 B, a lane takes 16 dims (one 16-byte load), a wave-instruction covers 16 rows.  The values are exactly code * t (no
 // fp16 rounding of the dequantised tensor), so the scale factors out of both products: score = r16((q16 . code) * t *
@@ -481,9 +486,13 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
             }
 #pragma unroll
             for (int i = 0; i < L; ++i) {
+                // sum over the LPR lanes that share a row: DPP moves inside the ALU (quad swaps, then the mirrored half-row brings
+                // the other quad's sum) instead of __shfl_xor, which compiles to ds_bpermute + a wait on the LDS counter per step --
+                // three dependent LDS round trips per row were most of this loop's issue time.  Same pairs, same sums.
                 float acc = accs[i];
-#pragma unroll
-                for (int x = 1; x < LPR; x <<= 1) acc += __shfl_xor(acc, x);
+                acc += dpp_f32<0xB1>(acc);                       // lane ^ 1
+                acc += dpp_f32<0x4E>(acc);                       // lane ^ 2
+                if constexpr (LPR == 8) acc += dpp_f32<0x141>(acc);      // the other quad of the 8 (row_half_mirror)
                 const float sc = I8 ? r16(acc * k_scale) : r16(acc);
                 if (r < nkeys) {
                     if (sub == 0) s_sc[i][r] = sc;
