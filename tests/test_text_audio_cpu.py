@@ -214,6 +214,37 @@ def test_summarize_dataset_discovery_and_scoring(golden_dir, tmp_path):
     assert args.test_trt_llm and not args.test_torch and args.data_type == "fp16" and args.checkpoint_file == "./large-v2.pt"
 
 
+def test_pipelined_evaluation_protocol_with_fakes():
+    """summarize.eval_engines_stream / transcribe_dataset_stream: the host-side pipelining protocol on fakes (no GPU, no
+    library).  The encoder of batch n + 1 is handed to prefetch() after the language pass of batch n and before its decode
+    loop, collect() is called once per prefetch, the first batch is encoded directly, a budget of 0 switches the overlap off,
+    and results come back in batch order."""
+    import summarize as S
+    log = []
+
+    class Enc:
+        def __init__(self): self.pending = None
+        def get_audio_features_async(self, mel): log.append(("encode", mel)); return ("xa", mel)
+        def prefetch(self, mel, budget): assert self.pending is None; log.append(("prefetch", mel, budget)); self.pending = mel
+        def collect(self): mel, self.pending = self.pending, None; log.append(("collect", mel)); return ("xa", mel)
+
+    class Dec:
+        def detect_language(self, xa): log.append(("lang", xa[1])); return ["en"], None
+        def main_loop(self, xa): log.append(("loop", xa[1])); return [xa[1]], [0.0], [0.0]
+        def post_process(self, tokens, lp, nsp, xa, languages): return [("result", xa[1])]
+
+    out = list(S.eval_engines_stream(Enc(), Dec(), iter(["a", "b", "c"]), cu_budget=24))
+    assert out == [[("result", "a")], [("result", "b")], [("result", "c")]]
+    assert log == [("encode", "a"), ("lang", "a"), ("prefetch", "b", 24), ("loop", "a"),
+                   ("collect", "b"), ("lang", "b"), ("prefetch", "c", 24), ("loop", "b"),
+                   ("collect", "c"), ("lang", "c"), ("loop", "c")]
+    log.clear()
+    out = list(S.eval_engines_stream(Enc(), Dec(), iter(["a", "b"]), cu_budget=0))
+    assert out == [[("result", "a")], [("result", "b")]]
+    assert log == [("encode", "a"), ("lang", "a"), ("loop", "a"), ("encode", "b"), ("lang", "b"), ("loop", "b")]
+    assert list(S.eval_engines_stream(Enc(), Dec(), iter([]))) == []
+
+
 # ---- BPE against an implementation that is not ours ---------------------------------------------------------------------
 def test_bpe_encode_matches_independent_implementation_and_known_gpt2_ids(golden_dir):
     """tokenizer.py's byte-pair encoder on the vendored Whisper vocabularies (assets/ASSETS.md) against
