@@ -47,14 +47,49 @@ int post_launch_check(hipStream_t s, const char* what);
     } while (0)
 
 // ---- device helpers ------------------------------------------------------------------
+// Wave-wide reductions as an xor butterfly from 32 down to 1, entirely inside the ALU: v_permlane32_swap / v_permlane16_swap
+// (gfx950) for the two cross-row steps, DPP row rotations and quad permutations for the rest.  __shfl_xor compiles to
+// ds_bpermute_b32 plus a wait on the LDS counter per step -- six dependent LDS round trips per reduction, most of the time of
+// the small kernels' LayerNorm / softmax tails.  The values added are the ones the xor butterfly adds, in its order (after
+// the steps 32, 16, 8 a lane's value depends on lane mod 8 only, so the lane a rotation by 4 reaches holds exactly what lane ^ 4
+// holds; likewise for 2 and 1 with the quad permutations): results are bit-identical to the __shfl_xor form.
+template <int CTRL>
+__device__ __forceinline__ float wave_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// The two swap steps are written in assembly: the instruction exchanges halves BETWEEN two registers and has two results, and
+// the compiler's handling of the second result of its intrinsic was wrong in context (v = r0 + r0).  x keeps its lower rows /
+// lower half twice, y ends up with the upper ones twice: x + y is own + partner on every lane, in either order.
+__device__ __forceinline__ void wave_swap32(int& x, int& y) {
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
+}
+__device__ __forceinline__ void wave_swap16(int& x, int& y) {
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    int x = __builtin_bit_cast(int, v), y;
+    wave_swap32(x, y);
+    v = __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+    x = __builtin_bit_cast(int, v);
+    wave_swap16(x, y);
+    v = __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+    v += wave_dpp<0x128>(v);            // row_ror:8   = lane ^ 8
+    v += wave_dpp<0x124>(v);            // row_ror:4   ~ lane ^ 4
+    v += wave_dpp<0x4E>(v);             // quad_perm [2,3,0,1] = lane ^ 2
+    v += wave_dpp<0xB1>(v);             // quad_perm [1,0,3,2] = lane ^ 1
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    int x = __builtin_bit_cast(int, v), y;
+    wave_swap32(x, y);
+    v = fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+    x = __builtin_bit_cast(int, v);
+    wave_swap16(x, y);
+    v = fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+    v = fmaxf(v, wave_dpp<0x128>(v));
+    v = fmaxf(v, wave_dpp<0x124>(v));
+    v = fmaxf(v, wave_dpp<0x4E>(v));
+    v = fmaxf(v, wave_dpp<0xB1>(v));
     return v;
 }
 __device__ __forceinline__ float r16(float x) { return (float)(h16)x; }   // round through fp16
