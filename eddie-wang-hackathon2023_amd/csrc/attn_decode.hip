@@ -263,10 +263,6 @@ int launch_attn_self(const AttnSelfParams& p, hipStream_t stream) {
 // load instruction (lane -> row lane>>3, 16-byte column lane&7), 4 instructions (4 KiB) in flight per wave.
 constexpr int CROSS_MAX_KEYS = 1536;
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {        // the value of the lane the DPP control selects (all lanes active)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
 
 // I8 (opt-in, beyond the reference: SURVEY 8f-4): K/V are int8 codes [B,2,H,Tk,64] with one scale t per layer; a row is
 // 64 B, a lane takes 16 dims (one 16-byte load), a wave-instruction covers 16 rows.  The values are exactly code * t (no
@@ -490,9 +486,9 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
                 // the other quad's sum) instead of __shfl_xor, which compiles to ds_bpermute + a wait on the LDS counter per step --
                 // three dependent LDS round trips per row were most of this loop's issue time.  Same pairs, same sums.
                 float acc = accs[i];
-                acc += dpp_f32<0xB1>(acc);                       // lane ^ 1
-                acc += dpp_f32<0x4E>(acc);                       // lane ^ 2
-                if constexpr (LPR == 8) acc += dpp_f32<0x141>(acc);      // the other quad of the 8 (row_half_mirror)
+                acc += wave_dpp<0xB1>(acc);                       // lane ^ 1
+                acc += wave_dpp<0x4E>(acc);                       // lane ^ 2
+                if constexpr (LPR == 8) acc += wave_dpp<0x141>(acc);      // the other quad of the 8 (row_half_mirror)
                 const float sc = I8 ? r16(acc * k_scale) : r16(acc);
                 if (r < nkeys) {
                     if (sub == 0) s_sc[i][r] = sc;
@@ -573,8 +569,10 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 #pragma unroll
         for (int e = 0; e < DPL; ++e) {
             float v = o[i][e];
-#pragma unroll
-            for (int x = LPR; x < 64; x <<= 1) v += __shfl_xor(v, x);
+            if constexpr (LPR == 4) v += __shfl_xor(v, 4);          // (int8 K/V only: no ALU-side exchange reaches lane ^ 4 exactly)
+            v += wave_dpp<0x128>(v);                                // lane ^ 8: row_ror:8 inside a row of 16 lanes
+            v = wave_add_xor16(v);                                  // lane ^ 16, lane ^ 32: permlane swaps (common.h) -- no LDS round trips,
+            v = wave_add_xor32(v);                                  // the same pairs and order as the __shfl_xor loop this replaces
             o[i][e] = v;
         }
     if (rowi == 0) {
@@ -619,8 +617,8 @@ __global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams 
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         if (s < p.nsplit) {                       // wave-uniform
-            den += __shfl(lf, s);
-            num += ov[s] * __shfl(f, s);
+            den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), s));     // (v_readlane: s is a constant after unrolling)
+            num += ov[s] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), s));
         }
     }
     p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + d] = (h16)(num / den);
