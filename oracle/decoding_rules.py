@@ -6,14 +6,18 @@ last-position logits of every step (W/ = /root/reference/tensorrt_llm_july-relea
     SuppressBlank          W/decoding.py:202-209
     SuppressTokens         W/decoding.py:212-217   (list built by _get_suppress_tokens :394-421)
     ApplyTimestampRules    W/decoding.py:134-199
-    GreedyDecoder.update   W/decoding.py:274-300
+    GreedyDecoder.update   W/decoding.py:274-300   (temperature 0 restated; temperature > 0 pinned through goldens)
+    MaximumLikelihoodRanker W/decoding.py:92-115
     detect_language        W/decoding.py:703-741   (mask to language tokens, argmax, softmax)
     no_speech_prob         W/decoding.py:803-807
     main_loop              W/decoding.py:785-821
 
 Pinned by tests/golden/decoding_rules.npz, which oracle/gen_golden.py produced by running the
 reference's own classes (imported from /root/reference with stub modules for tiktoken/tensorrt)
-on seeded logits and token histories.
+on seeded logits and token histories, and by tests/golden/sampling.npz (same generator): the
+reference's GreedyDecoder at temperature 0.7, its MaximumLikelihoodRanker with and without a
+length penalty, and its main_loop + post_process driven with best_of = 3 on the seeded logits of
+`sampling_logits` below.
 """
 from __future__ import annotations
 
@@ -198,3 +202,33 @@ def golden_rule_cases(ids: SpecialIds = MULTILINGUAL):
             cases.append((np.array(sot_seq + hist, dtype=np.int64),
                           logits.astype(np.float16).astype(np.float32)))
     return cases
+
+
+def rank_max_likelihood(lengths: Sequence[Sequence[int]], sum_logprobs: Sequence[Sequence[float]],
+                        length_penalty: Optional[float]) -> List[int]:
+    """MaximumLikelihoodRanker.rank (W/decoding.py:92-115): per group, the index of the highest
+    sum_logprob / penalty, penalty = length, or ((5 + length) / 6) ** length_penalty (Google NMT)."""
+    picks = []
+    for ls, lps in zip(lengths, sum_logprobs):
+        sc = [lp / (n if length_penalty is None else ((5 + n) / 6) ** length_penalty) for n, lp in zip(ls, lps)]
+        picks.append(int(np.argmax(sc)))
+    return picks
+
+
+def sampling_logits(step: int, n_rows: int, n_tokens: int, ids: SpecialIds = MULTILINGUAL, seed: int = 4242) -> np.ndarray:
+    """Seeded decoder outputs [n_rows, n_tokens, V] (fp32 values that are fp16-representable) for the sampling
+    goldens: the stand-in for `decode()` that both the reference's main_loop (in oracle/gen_golden.py) and the
+    product's main_loop_reference (in tests/) are driven with.  A few text tokens and timestamps stand out so
+    that temperature 0.7 picks among a handful of candidates; from step 3 on EOT gains weight row by row, so
+    candidates of one utterance end at different lengths (what the ranker's length term needs)."""
+    rng = np.random.Generator(np.random.Philox(key=seed + 1000 * step))
+    V, tb = ids.n_vocab, ids.timestamp_begin
+    lg = (rng.standard_normal((n_rows, n_tokens, V)) * 1.5).astype(np.float32)
+    for r in range(n_rows):
+        hot = rng.integers(300, 40000, size=6)
+        lg[r, :, hot] += rng.uniform(7.0, 10.0, size=6).astype(np.float32)[:, None]
+        ts = tb + rng.integers(0, 1400, size=3)
+        lg[r, :, ts] += rng.uniform(5.0, 9.0, size=3).astype(np.float32)[:, None]
+        if step >= 3:
+            lg[r, :, ids.eot] += np.float32(6.0 + 1.5 * ((r + step) % 4))
+    return lg.astype(np.float16).astype(np.float32)

@@ -6,7 +6,8 @@ Python can not and does not travel to the GPU box.  Test infrastructure, not pro
 
 What is imported from the reference (W/ = /root/reference/tensorrt_llm_july-release-v1/examples/whisper):
   * W/torch_model.py  (Whisper, ModelDimensions, install_kv_cache_hooks)  -- real import.
-  * W/decoding.py     (ApplyTimestampRules, SuppressBlank, SuppressTokens, GreedyDecoder) --
+  * W/decoding.py     (ApplyTimestampRules, SuppressBlank, SuppressTokens, GreedyDecoder, MaximumLikelihoodRanker,
+    WhisperDecoding.main_loop / post_process as unbound functions) --
     imported with permissive stub modules for tiktoken / tensorrt / tensorrt_llm / build /
     tokenizer, none of which the logit rules touch.
   * W/assets/*.tiktoken  -- read (not copied) to pin our BPE + suppress list.
@@ -238,6 +239,90 @@ def gen_rules_fixture(dec):
     print("tokenizer.npz written")
 
 
+def gen_sampling_fixture(dec):
+    """The sampling path of the decode loop, produced by the reference's own classes:
+      (1) GreedyDecoder(temperature=0.7).update (W/decoding.py:274-300) on seeded CPU logits under torch.manual_seed,
+          three consecutive steps with EOT stickiness;
+      (2) MaximumLikelihoodRanker(length_penalty in {None, 0.6}).rank (:92-115) on fixed candidate groups;
+      (3) WhisperDecoding.main_loop (:785-821) + post_process (:827-878) as unbound functions on a stand-in `self`
+          carrying best_of = 3, temperature 0.7, the reference's filters / decoder / ranker, and a `decode` that returns
+          DR.sampling_logits(step) -- two utterances x three candidates, until every row has sampled EOT.
+    Only expected OUTPUTS are stored; the inputs are regenerated from seeds (DR.sampling_logits)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "wm_tokenizer", os.path.join(ROOT, "eddie-wang-hackathon2023_amd", "tokenizer.py"))
+    OurTok = sys.modules.get("wm_tokenizer")
+    if OurTok is None:
+        OurTok = importlib.util.module_from_spec(spec)
+        sys.modules["wm_tokenizer"] = OurTok
+        spec.loader.exec_module(OurTok)
+    tk = OurTok.Tokenizer.from_vocab(os.path.join(W, "assets", "multilingual.tiktoken"), True, "en", "transcribe")
+    ids = DR.MULTILINGUAL
+    V = ids.n_vocab
+    fix = {}
+
+    # (1) one decoder, three updates in a row (the generator state carries over, as in a loop)
+    greedy = dec.GreedyDecoder(0.7, ids.eot)
+    torch.manual_seed(1234)
+    tokens = torch.tensor([[ids.sot, ids.lang0, ids.transcribe]] * 5)
+    tokens[3, -1] = ids.eot                       # a row that is already finished: stays at EOT, adds no log-prob
+    sum_lp = torch.zeros(5)
+    for step in range(3):
+        lg = torch.from_numpy(DR.sampling_logits(step + 10, 5, 1)[:, 0].copy())
+        tokens, done = greedy.update(tokens, lg, sum_lp)
+        fix[f"upd{step}_next"] = tokens[:, -1].numpy().copy()
+        fix[f"upd{step}_sumlp"] = sum_lp.numpy().copy()
+        fix[f"upd{step}_done"] = bool(done)
+    ftok, flp = greedy.finalize(tokens.reshape(1, 5, -1), sum_lp.reshape(1, 5))
+    fix["upd_final_tokens"], fix["upd_final_sumlp"] = ftok.numpy(), np.array(flp, dtype=np.float64)
+
+    # (2) ranker: lengths and sums chosen so that the three rules disagree
+    groups_len = [[3, 9, 5], [12, 2, 7], [4, 4, 4], [1, 30, 10]]
+    groups_lp = [[-2.0, -4.5, -3.1], [-9.0, -2.2, -6.5], [-1.0, -0.9, -1.1], [-0.8, -12.0, -5.0]]
+    toks = [[torch.zeros(n, dtype=torch.long) for n in g] for g in groups_len]
+    fix["rank_lengths"], fix["rank_sumlp"] = np.array(groups_len), np.array(groups_lp)
+    for tag, pen in (("none", None), ("0p6", 0.6), ("1p0", 1.0)):
+        fix[f"rank_{tag}"] = np.array([int(i) for i in dec.MaximumLikelihoodRanker(pen).rank(toks, groups_lp)])
+
+    # (3) the loop itself
+    sup = sorted(set(list(tk.non_speech_tokens) + [tk.transcribe, tk.translate, tk.sot, tk.sot_prev, tk.sot_lm, tk.no_speech]))
+    ftk = _Tok(ids, tk.blank_tokens())
+    ftk.no_speech = ids.no_speech
+    ftk.decode = lambda t: " ".join(str(int(x)) for x in t)
+    n_audio, n_group, sample_len = 2, 3, 12
+    for tag, pen in (("none", None), ("0p6", 0.6)):
+        calls = []
+
+        def decode(x, cross, past, calls=calls):
+            calls.append(tuple(x.shape))
+            return torch.from_numpy(DR.sampling_logits(len(calls) - 1, x.shape[0], x.shape[1])), None
+        me = types.SimpleNamespace(
+            tokens=torch.tensor([[ids.sot, ids.lang0, ids.transcribe]] * n_audio), n_group=n_group, sample_len=sample_len,
+            initial_token_length=3, sot_index=0, sample_begin=3, tokenizer=ftk,
+            decoder_config={"num_text_ctx": 448, "num_audio": n_audio},
+            logit_filters=[dec.SuppressBlank(ftk, 3), dec.SuppressTokens(sup), dec.ApplyTimestampRules(ftk, 3, 50)],
+            decoder=dec.GreedyDecoder(0.7, ids.eot), sequence_ranker=dec.MaximumLikelihoodRanker(pen),
+            options=types.SimpleNamespace(temperature=0.7), xa2cross_key_value=lambda xa: None, decode=decode,
+            compression_ratio=lambda text: 1.0)
+        xa = torch.zeros(n_audio * n_group, 1, 1)             # the reference expects one feature row per candidate (:829)
+        torch.manual_seed(99)
+        tokens, sum_lp, nsp = dec.WhisperDecoding.main_loop(me, xa)
+        res = dec.WhisperDecoding.post_process(me, tokens, sum_lp, nsp, xa, ["en"] * n_audio)
+        fix[f"loop_{tag}_tokens"] = tokens.numpy()
+        fix[f"loop_{tag}_sumlp"] = sum_lp.numpy()
+        fix[f"loop_{tag}_nsp"] = np.array(nsp, dtype=np.float64)
+        fix[f"loop_{tag}_calls"] = np.array(calls)
+        fix[f"loop_{tag}_selected_tokens"] = np.array([" ".join(map(str, r.tokens)) for r in res])
+        fix[f"loop_{tag}_avg_logprob"] = np.array([r.avg_logprob for r in res], dtype=np.float64)
+        fix[f"loop_{tag}_nsp_selected"] = np.array([r.no_speech_prob for r in res], dtype=np.float64)
+    fix["suppress"] = np.array(sup)
+    np.savez_compressed(os.path.join(OUT, "sampling.npz"), **fix)
+    print("sampling.npz: update next", [fix[f"upd{s}_next"].tolist() for s in range(3)], "ranks", fix["rank_none"].tolist(),
+          fix["rank_0p6"].tolist(), fix["rank_1p0"].tolist())
+    print("  loop tokens", fix["loop_none_tokens"].shape, "selected", fix["loop_none_selected_tokens"].tolist(),
+          fix["loop_0p6_selected_tokens"].tolist())
+
+
 def gen_mel_fixture():
     """log_mel_spectrogram(seeded noise) from the reference's own whisper_utils (next-scope row f1)."""
     sys.path.insert(0, W)
@@ -259,9 +344,13 @@ if __name__ == "__main__":
     if "--only-tiny" in sys.argv:
         gen_tiny_en_shape_fixture(tm)
         sys.exit(0)
+    if "--only-sampling" in sys.argv:
+        gen_sampling_fixture(import_reference_decoding())
+        sys.exit(0)
     gen_model_fixture(tm)
     gen_tiny_en_shape_fixture(tm)
     gen_op_fixtures(tm)
     gen_mel_fixture()
     dec = import_reference_decoding()
     gen_rules_fixture(dec)
+    gen_sampling_fixture(dec)
