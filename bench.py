@@ -53,6 +53,7 @@ WORKLOADS = {"fp16": "fp16 GEMMs + fp16 self-KV + fp16 cross-KV", "int8wo": "wei
              "int4": "weight-only int4 GEMMs + int8 self-KV + fp16 cross-KV",
              "int8x": "weight-only int8 GEMMs + int8 self-KV + INT8 cross-KV (opt-in, beyond the reference's numerics)"}
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 
 
 def parse():
@@ -69,6 +70,12 @@ def parse():
     ap.add_argument("--encoder-cus", type=int, default=96,
                     help="CUs the next step's encoder runs on beside the current step's decode loop (0: no pipelining, one stage after the other)")
     ap.add_argument("--groups", type=int, default=0, help="utterance groups of the decode loop (0: the library's choice)")
+    ap.add_argument("--length-dist", type=str, default="librispeech-like", choices=["forced", "librispeech-like"],
+                    help="SECOND figure beside the headline (which always decodes --decode-steps forced tokens per utterance): "
+                         "extra untimed-for-the-headline steps in which utterances end after LibriSpeech-like token counts "
+                         "(per-row completion: finished rows drop out of the attention kernels); forced = skip it")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="do not run the rocprofv3 --pmc FETCH_SIZE pass of the dominant kernel (roofline.traffic then comes from the committed pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank (self-test)")
@@ -158,6 +165,65 @@ def pmc_traffic(group: int, kv_bytes: int) -> dict:
     with open(files[-1]) as f:
         rec = json.load(f)
     return {"traffic": int(round(group * rec["fetch_bytes_per_utterance_layer"])), "traffic_source": os.path.relpath(files[-1], ROOT)}
+
+
+def measure_traffic(group: int, kv_bytes: int, timeout_s: float = 240.0) -> dict:
+    """`roofline.traffic` measured in this run: a rocprofv3 --pmc FETCH_SIZE pass (its own process, counters only, as
+    MI355X_MICROARCH.md prescribes) over scripts/cross_attn_probe.py at this run's launch shape -- the same kernel, grid and
+    K/V layout the decode loop launches, four K/V buffers rotated so that the Infinity Cache cannot serve re-reads.
+    HBM bytes per launch = FETCH_SIZE (KB) x 1024 x 2 (gfx950: the counter reports half the bytes of 16 B/lane streaming
+    reads).  Returns {} when rocprofv3 is missing or the pass fails (the caller then falls back to the committed pass)."""
+    import csv
+    import glob
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or kv_bytes != 2:
+        return {}
+    out = tempfile.mkdtemp(prefix="wm_pmc_")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "--",
+               sys.executable, os.path.join(ROOT, "scripts", "cross_attn_probe.py"), str(group), "8"]
+        proc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+        vals = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if "attn_cross_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == "FETCH_SIZE":
+                        vals.append(float(row["Counter_Value"]))
+        if proc.returncode != 0 or not vals:
+            return {}
+        fetch = float(np.mean(vals)) * 1024.0 * 2.0
+        return {"traffic": int(round(fetch)),
+                "traffic_source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE over scripts/cross_attn_probe.py {group} 8 "
+                                  f"({len(vals)} launches; FETCH_SIZE KB x 1024 x 2, the gfx950 correction for 16 B/lane streaming reads)"}
+    except Exception:       # noqa: BLE001 -- a profiler problem must not cost the bench line
+        return {}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def librispeech_like_lengths(n: int, t_max: int, seed: int = 2620) -> np.ndarray:
+    """Sampled-token counts per utterance for the second figure: LibriSpeech test-clean has 2 620 utterances of 1.3-35 s
+    (mean 7.4 s, long right tail); a Whisper transcript of it carries about 3.6 tokens per second of speech plus the two
+    timestamps.  Durations ~ log-normal(median 6.3 s, sigma 0.62) clipped to [1.3, 30] s (clips over 30 s are skipped by the
+    reference, W/summarize.py:118-120), tokens = round(3.6 x duration) + 2, capped at the decode budget.  Sorted ascending:
+    a transcription job batches clips by duration (summarize.py), so the utterance groups of a batch -- contiguous
+    slices -- hold clips of similar length and the group of the shortest clips finishes as a whole."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    dur = np.clip(np.exp(rng.normal(np.log(6.3), 0.62, size=n)), 1.3, 30.0)
+    tok = np.minimum(np.rint(3.6 * dur).astype(np.int64) + 2, t_max)
+    return np.sort(np.maximum(tok, 1))
+
+
+def encoder_flops_per_clip(d: dict) -> float:
+    """Algorithmic FLOPs of one encoder pass (2.272 TFLOP per clip at large-v2): the four Linears and the attention
+    of every block, the two convolutions."""
+    T, C, L, M = d["n_audio_ctx"], d["n_audio_state"], d["n_audio_layer"], d["n_mels"]
+    per_layer = 2.0 * T * (3 * C * C + C * C + 2 * C * 4 * C) + 4.0 * T * T * C
+    conv = 2.0 * (2 * T) * M * 3 * C + 2.0 * T * C * 3 * C
+    return L * per_layer + conv
 
 
 def in_situ_probe(dec, lib, xa, B: int, n_micro: int, algo_bytes: int, steps: int = 20, beside=None) -> dict:
@@ -342,6 +408,62 @@ def main():
         dist.barrier()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
 
+    # ---- untimed probes after the headline region -------------------------------------------------------------------
+    # (a) the encoder alone on the whole chip (MFMA roofline of the other big stage)
+    enc_alone_ms = None
+    if not args.no_roofline:
+        for _ in range(2):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            enc.get_audio_features_async(mel)
+            b.record()
+            torch.cuda.synchronize()
+            enc_alone_ms = a.elapsed_time(b)
+    # (b) the SECOND figure: utterances that end after LibriSpeech-like token counts (per-row completion).  One warm-up
+    # step (it captures the graphs of the live-row loop), then two measured steps, each the whole path like the headline's.
+    ragged = None
+    if args.length_dist != "forced":
+        limits = librispeech_like_lengths(B, T)
+        lim_dev = torch.as_tensor(limits, dtype=torch.int32, device=dev)
+
+        def ragged_step():
+            xa_r = enc.get_audio_features_async(mel)
+            dec.detect_language(xa_r)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tokens, sum_lp, _ = dec.main_loop(xa_r, row_limit=lim_dev)
+            e1.record()
+            return tokens, e0, e1
+        tokens_r, _, _ = ragged_step()
+        torch.cuda.synchronize()
+        eot = dec.tokenizer.eot
+        got = (tokens_r[:, dec.sample_begin:] != eot).sum(dim=1).cpu().numpy()
+        if use_dist:
+            dist.barrier()
+        t_r = time.perf_counter()
+        loops = []
+        for _ in range(2):
+            _, e0, e1 = ragged_step()
+            loops.append((e0, e1))
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        r_elapsed = dp.max_over_ranks(time.perf_counter() - t_r, dev) / 2
+        r_loop_ms = float(np.mean([a.elapsed_time(b) for a, b in loops]))
+        kvb = 1 if args.config == "int8x" else 2
+        row_bytes = dims["n_text_layer"] * dims["n_text_head"] * 2 * dims["n_audio_ctx"] * 64 * kvb       # cross K/V of one utterance, one token
+        live_bytes = float(limits.sum() + B) * row_bytes       # every row is streamed once per token it samples (+ the step that ends it)
+        ragged = {"length_dist": "librispeech-like (log-normal durations, 3.6 tokens/s + 2 timestamps, sorted by duration; bench.py: librispeech_like_lengths)",
+                  "useful_tokens_per_s": round(float(limits.sum()) * world / r_elapsed, 1),
+                  "tokens_per_utterance": {"mean": round(float(limits.mean()), 1), "min": int(limits.min()), "max": int(limits.max())},
+                  "tokens_match_the_limits": bool((got == limits).all()),
+                  "ms_per_step": round(r_elapsed * 1e3, 1), "decode_loop_ms": round(r_loop_ms, 1),
+                  "decode_loop_vs_live_row_bytes": round(r_loop_ms * 1e-3 / (live_bytes / 5.66e12), 3),
+                  "note": "whole path per step as in the headline (encoder + cross-K/V + language pass + prefill + decode loop), one stage after "
+                          "the other; rows that reach their length emit EOT, drop out of the attention kernels (live-row lists) and finished "
+                          "groups are no longer stepped.  decode_loop_vs_live_row_bytes = decode loop time / (cross-K/V bytes of the rows still "
+                          "decoding, summed over the steps, / 5.66 TB/s -- the rate of the forced loop's whole step)"}
+
     # decode loops with nothing beside them (the last step's; every step's when the pipelining is off) and with the next
     # batch's encoder beside them
     alone = [a.elapsed_time(b) for a, b, shared in loop_events if not shared]
@@ -369,7 +491,9 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBS, 4),
                         # HBM bytes per launch: read from the PMC pass committed under profiles/ (FETCH_SIZE x 1024 x 2, the
                         # gfx950 correction for 16 B/lane streaming reads, MI355X_MICROARCH.md), per utterance-layer
-                        **pmc_traffic(group, kv_bytes),
+                        **((not args.no_measure_traffic and world == 1 and measure_traffic(group, kv_bytes)) or
+                           {k: (v if k != "traffic_source" or v is None else v + " (committed PMC pass, not measured in this run)")
+                            for k, v in pmc_traffic(group, kv_bytes).items()}),
                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5),
                         "samples": int(cnt.value), "utterances_per_launch": group,
                         "note": "HIP events around the eager (language-ID pass) launches of the kernel inside the timed "
@@ -394,6 +518,16 @@ def main():
                 if decode_loop_shared_ms is not None:
                     roofline.update({"decode_loop_beside_encoder_ms": round(decode_loop_shared_ms, 2),
                                      "decode_step_beside_encoder_ms": round(decode_loop_shared_ms / T, 3)})
+                # the whole job against its HBM-only floor: every token step streams the batch's cross K/V once
+                ms_step = elapsed / args.steps * 1e3
+                roofline["job_frac"] = round(cross_bytes * T / (HBM_PEAK_GBS * 1e9) / (ms_step * 1e-3), 4)
+                roofline["job_note"] = "cross-K/V bytes of all token steps of one batch / 8 TB/s, over the measured time per step (encoder, projection, language pass and prefill included in the time, not in the bytes)"
+            if enc_alone_ms is not None:
+                fl = encoder_flops_per_clip(dims) * B
+                roofline["encoder"] = {"bound": "mfma", "ms": round(enc_alone_ms, 1), "achieved": round(fl / (enc_alone_ms * 1e-3) / 1e12, 1),
+                                       "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (enc_alone_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                       "note": f"one encoder pass of {B} clips alone on the chip after the timed region (HIP events): "
+                                               f"{encoder_flops_per_clip(dims) / 1e12:.3f} TFLOP per clip (SURVEY 8d) against the dense fp16 MFMA peak"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -422,6 +556,9 @@ def main():
             "hbm_bytes_resident": {"engine_weights": int(weight_bytes), "buffers": int(torch_bytes),
                                    "device_in_use": int(total_b - free_b), "batch_per_gpu": B},
             "roofline": roofline,
+            "second_figure": ragged,
+            # arithmetic-order / scheduling knobs read from the environment, echoed when set (defaults otherwise)
+            "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WM_")} or None,
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, T)

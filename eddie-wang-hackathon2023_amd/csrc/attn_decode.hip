@@ -47,7 +47,12 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     __shared__ float s_p[MAXT];
     __shared__ h16 s_qall[MAX_L][64], s_knew[MAX_L][64], s_vnew[MAX_L][64];
 
-    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int h = blockIdx.x, lane = threadIdx.x;
+    int b = blockIdx.y;
+    if (p.live) {                                // rows still decoding (wave-uniform): the others' caches are not touched
+        if (b >= p.live[0]) return;
+        b = p.live[1 + b];
+    }
     const int T = p.t_dev ? *p.t_dev : p.T;      // device-resident step counter (graph replay) or host value
     const int C = p.H * 64;
     // The kernel is a chain of dependent memory round trips (this call's q / k / v sums, the cached K rows, the cached V rows)
@@ -262,6 +267,7 @@ int launch_attn_self(const AttnSelfParams& p, hipStream_t stream) {
 // 256 threads = 4 waves; wave w, pass c covers keys [c*32*4 + w*32 ... ) in groups of 8 rows per
 // load instruction (lane -> row lane>>3, 16-byte column lane&7), 4 instructions (4 KiB) in flight per wave.
 constexpr int CROSS_MAX_KEYS = 1536;
+constexpr int CROSS_MAX_SPLIT = 16;                   // key-range splits the merge kernel combines (the engine uses <= 8)
 
 
 // I8 (opt-in, beyond the reference: SURVEY 8f-4): K/V are int8 codes [B,2,H,Tk,64] with one scale t per layer; a row is
@@ -291,12 +297,16 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     const int first = wid * (RPI * UNR);                  // this wave's first row of an item
     // a workgroup walks over (head, utterance, key split) items: with fewer workgroups than items the
     // launch is persistent and leaves wave slots on every CU to the other streams' short kernels
-    const int n_items = p.H * p.B * p.nsplit;
+    // rows still decoding (p.live: count, then indices): finished utterances drop out of the stream, the items are dealt
+    // over the live rows only -- the launch's cost follows the live rows (the reference stops at EOT, W/decoding.py:817-819)
+    const int n_rows = p.live ? p.live[0] : p.B;
+    const int n_items = p.H * n_rows * p.nsplit;
 
     struct Item { int h, b, sp, k_begin, nkeys; const unsigned char* K; const unsigned char* V; };
     auto geometry = [&](int item) {
         Item it;
-        it.h = item % p.H; it.b = (item / p.H) % p.B; it.sp = item / (p.H * p.B);
+        it.h = item % p.H; it.b = (item / p.H) % n_rows; it.sp = item / (p.H * n_rows);
+        if (p.live) it.b = p.live[1 + it.b];
         it.k_begin = it.sp * per_split;
         it.nkeys = max(0, min(p.Tk, it.k_begin + per_split) - it.k_begin);
         it.K = (const unsigned char*)p.kv + ((size_t)it.b * p.kv_bstride + ((size_t)(0 * p.H + it.h) * p.Tk) * 64) * ESZ;
@@ -602,20 +612,25 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 // shuffle -- one memory round trip instead of 3 x nsplit dependent ones (8 -> 2 us at batch 1, where this kernel runs
 // 32 times per token).  Sums are taken in split order, as before.
 __global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams p) {
-    const int h = blockIdx.x, b = blockIdx.y, i = blockIdx.z, d = threadIdx.x;
+    const int h = blockIdx.x, i = blockIdx.z, d = threadIdx.x;
+    int b = blockIdx.y;
+    if (p.live) {
+        if (b >= p.live[0]) return;
+        b = p.live[1 + b];
+    }
     const float* w = p.ws + ((((size_t)b * p.H + h) * p.nsplit) * p.L + i) * 66;
     const size_t stride = (size_t)p.L * 66;
     float ms = w[min(d, p.nsplit - 1) * stride], ls = w[min(d, p.nsplit - 1) * stride + 1];
     if (d >= p.nsplit) { ms = -INFINITY; ls = 0.f; }
-    float ov[16];                                 // (no per-element test around a load; splits past the end re-read the last one, weight 0)
+    float ov[CROSS_MAX_SPLIT];                    // (no per-element test around a load; splits past the end re-read the last one, weight 0)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) ov[s] = w[min(s, p.nsplit - 1) * stride + 2 + d];
+    for (int s = 0; s < CROSS_MAX_SPLIT; ++s) ov[s] = w[min(s, p.nsplit - 1) * stride + 2 + d];
     const float m = wave_max(ms);
     const float f = d < p.nsplit ? __expf(ms - m) : 0.f;
     const float lf = ls * f;
     float den = 0.f, num = 0.f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < CROSS_MAX_SPLIT; ++s) {
         if (s < p.nsplit) {                       // wave-uniform
             den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), s));     // (v_readlane: s is a constant after unrolling)
             num += ov[s] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), s));
@@ -628,6 +643,8 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
     WM_REQUIRE(p.L >= 1 && p.L <= MAX_L, "attn_cross: L=%d out of range [1,%d]", p.L, MAX_L);
     WM_REQUIRE(p.Tk >= 1 && p.Tk <= CROSS_MAX_KEYS, "attn_cross: Tk=%d out of range", p.Tk);
     WM_REQUIRE(p.nsplit >= 1 && (p.nsplit == 1 || p.ws != nullptr), "attn_cross: split needs a workspace");
+    WM_REQUIRE(p.nsplit <= CROSS_MAX_SPLIT, "attn_cross: nsplit=%d exceeds %d (the merge kernel holds one partial result per register)",
+               p.nsplit, CROSS_MAX_SPLIT);
     // Persistent launch for big batches: two workgroups per CU walk over the (head, utterance, split) items instead of
     // one workgroup per item.  The kernel alone is as fast either way (6.3-6.7 TB/s), but with 8 of a CU's 32 wave slots
     // it leaves room for the OTHER utterance group's short kernels to be dispatched while it streams: 13.2 instead of

@@ -60,14 +60,19 @@ __device__ __forceinline__ float wave_dpp(float v) {
 // The two swap steps are written in assembly: the instruction exchanges halves BETWEEN two registers and has two results, and
 // the compiler's handling of the second result of its intrinsic was wrong in context (v = r0 + r0).  x keeps its lower rows /
 // lower half twice, y ends up with the upper ones twice: x + y is own + partner on every lane, in either order.
-// The leading s_nop: the hazard recognizer does not look inside inline assembly, and the scratch register the move writes may
-// still be an operand of a matrix instruction in flight (found in the encoder attention kernel: wrong sums with fewer than
-// five wait states there).  Do not use these next to MFMAs without re-checking; the attention kernels keep __shfl_xor.
+// The leading s_nops: the hazard recognizer does not look inside inline assembly, and the scratch register the move writes may
+// still be the destination or the C operand of a matrix instruction in flight (found in the encoder attention kernel: wrong
+// sums with fewer than five wait states there).  LLVM's gfx940/950 tables ask for up to 18 wait states between a 16-pass XDL
+// write / SrcC read and a VALU write of the same register, so the helpers wait 19 (s_nop 7 + 7 + 2): safe wherever they are
+// inlined, MFMA kernels included -- 11 more idle cycles per reduction, nothing next to the memory round trips these kernels
+// are made of.  Users today: gemv_small (an MFMA kernel; the reductions run in the LayerNorm prologue, before its first
+// MFMA), rowops, greedy, attn_decode (cross kernel, merge kernel, self kernel: no MFMA).  attn_encoder keeps __shfl_xor.
+#define WM_SWAP_GUARD "s_nop 7\n\ts_nop 7\n\ts_nop 2\n\t"
 __device__ __forceinline__ void wave_swap32(int& x, int& y) {
-    asm volatile("s_nop 7\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
+    asm volatile(WM_SWAP_GUARD "v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
 }
 __device__ __forceinline__ void wave_swap16(int& x, int& y) {
-    asm volatile("s_nop 7\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
+    asm volatile(WM_SWAP_GUARD "v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
 }
 // single butterfly steps across rows (lane ^ 16, lane ^ 32): own + partner / max(own, partner) on every lane
 __device__ __forceinline__ float wave_add_xor16(float v) { int x = __builtin_bit_cast(int, v), y; wave_swap16(x, y); return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y); }

@@ -353,7 +353,7 @@ int big(const Lin& l, const wm_engine* e, const h16* A, int lda, int M, h16* Cou
 
 extern "C" {
 
-int wm_version(void) { return 1; }
+int wm_version(void) { return WM_ABI_VERSION; }
 const char* wm_last_error(void) { return g_err; }
 int wm_device_count(int* out) {
     WM_CHECK_HIP(hipGetDeviceCount(out));
@@ -694,6 +694,7 @@ struct GroupStep {
         p.int8_kv = e->i8kv(); p.kv_scale = Lr.kv_scale; p.out = w.ctx; p.ldo = C;
         p.amax = io->qkv_amax ? io->qkv_amax + i : nullptr;
         p.t_dev = io->n_past_dev;
+        p.live = io->live_rows;
         if (launch_attn_self(p, s)) return 2;
         if (small) {
             if (gemv(Lr.out, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;    // x += out(ctx)
@@ -727,6 +728,7 @@ struct GroupStep {
         p.kv = (const h16*)io->cross[i]; p.kv_bstride = (long)2 * H * d.n_audio_ctx * 64;
         p.kv_q8_scale = e->i8cross() ? Lr.cross_scale : 0.f;
         p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
+        p.live = io->live_rows;
         const int slot = (L == 1) ? prof_slot(*prof, i, s) : -1;
         if (launch_attn_cross(p, s, slot >= 0 ? prof->start[slot] : nullptr, slot >= 0 ? prof->stop[slot] : nullptr)) return 2;
         return 0;
@@ -912,10 +914,14 @@ int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream) {
     p.sample_begin = io->sample_begin; p.eot = io->eot; p.timestamp_begin = io->timestamp_begin;
     p.max_initial_ts = io->max_initial_timestamp_index; p.apply_rules = io->apply_rules; p.n_done = io->n_done;
     p.t_dev = io->n_past_dev;
+    p.done = io->done; p.row_limit = io->row_limit;
     return launch_greedy(p, (hipStream_t)stream);
 }
 
 int wm_step_advance(int32_t* counter, wm_stream_t stream) { return launch_step_advance(counter, (hipStream_t)stream); }
+int wm_step_finish(int32_t* counter, const int32_t* done, int batch, int32_t* live, wm_stream_t stream) {
+    return launch_step_finish(counter, done, batch, live, (hipStream_t)stream);
+}
 
 // ================================================================================================ kernel-level
 int wm_gemm(const void* A, int lda, int M, int K, const void* W, int N, int w8, const void* scale,

@@ -25,6 +25,8 @@
 // LDS.  (A first version built the statistics from per-block partial sums left by the producing kernel: 20 dependent
 // L2 round trips per row at the head of every projection -- B = 1 was SLOWER than the 12-launch chain, 2.50 vs 2.26 ms per
 // token.)
+#include <atomic>
+
 #include "common.h"
 #include "epilogue.h"
 #include "kernels.h"
@@ -272,12 +274,24 @@ int launch_gemv_small(const GemvSmallParams& p_, hipStream_t stream) {
     constexpr size_t LN_LDS_MAX = 100 * 1024;      // 32 rows of 1536 channels
     WM_REQUIRE(!p.ln_g || (p.ln_b && p.K % 8 == 0 && p.K <= 1536 && p.ksplit <= 8 && (size_t)p.M * (p.K + 8) * 2 <= LN_LDS_MAX),
                "gemv_small: LayerNorm needs beta, K <= 1536 and <= 8 K slices (K=%d, slices=%d)", p.K, p.ksplit);
-    static bool attr_set = false;                  // (per process; the attribute is a property of the code object)
-    if (!attr_set) {
+    // modes 0-2 read bias[col] and write out32 / out16 / x for every column of every 16-wide block (only the logits mode
+    // has a ragged last block): the logical width must be the blocks' width
+    const int n_full = p.n_blocks * 16;
+    WM_REQUIRE(p.mode == 3 || p.n_valid == 0 || p.n_valid == n_full,
+               "gemv_small: mode %d writes whole 16-column blocks: n_valid=%d must be 16 * n_blocks = %d", p.mode, p.n_valid, n_full);
+    WM_REQUIRE(p.mode != 0 || p.ld32 >= n_full, "gemv_small: ld32=%d < 16 * n_blocks = %d", p.ld32, n_full);
+    WM_REQUIRE(p.mode != 1 || p.ld16 >= n_full, "gemv_small: ld16=%d < 16 * n_blocks = %d", p.ld16, n_full);
+    WM_REQUIRE(p.mode != 2 || p.ldx >= n_full, "gemv_small: ldx=%d < 16 * n_blocks = %d", p.ldx, n_full);
+    // the dynamic-LDS limit is an attribute of the function ON A DEVICE: one process may drive several GPUs from several threads
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    WM_CHECK_HIP(hipGetDevice(&dev));
+    const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+    if (slot != dev || !attr_set[slot].load(std::memory_order_acquire)) {       // (devices past the table: set it every time)
         const void* kerns[6] = {(const void*)gemv_small_kernel<16, 1, true>, (const void*)gemv_small_kernel<16, 2, true>, (const void*)gemv_small_kernel<8, 1, true>,
                                 (const void*)gemv_small_kernel<8, 2, true>, (const void*)gemv_small_kernel<4, 1, true>, (const void*)gemv_small_kernel<4, 2, true>};
         for (const void* k : kerns) WM_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LN_LDS_MAX));
-        attr_set = true;
+        attr_set[slot].store(true, std::memory_order_release);
     }
     if (p.w8 == 4) launch_mt<4>(p, stream); else if (p.w8) launch_mt<8>(p, stream); else launch_mt<16>(p, stream);
     WM_LAUNCH_CHECK(stream, "gemv_small");

@@ -138,10 +138,16 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
         const float lp = best.v - logz;
         const int prev = toks[cur_len - 1];
         const bool alive = (prev != p.eot);
-        if (alive) p.sum_logprobs[b] += lp;
-        const int next = alive ? best.i : p.eot;
+        // per-row sample_len: the row has sampled its quota -> it ends here, like the reference's loop at sample_len
+        // (no log-probability for the closing EOT, W/decoding.py:794,817-821 + finalize :296-300)
+        const bool capped = alive && p.row_limit && (cur_len - p.sample_begin >= p.row_limit[b]);
+        if (alive && !capped) p.sum_logprobs[b] += lp;
+        const int next = (alive && !capped) ? best.i : p.eot;
         toks[cur_len] = next;
-        if (next == p.eot && p.n_done) atomicAdd(p.n_done, 1);
+        if (next == p.eot) {
+            if (p.n_done) atomicAdd(p.n_done, 1);
+            if (p.done) p.done[b] = 1;
+        }
     }
 }
 
@@ -173,6 +179,30 @@ int launch_argmax(const h16* logits, long ld_row, int B, int V, int32_t* ids, hi
 }
 
 __global__ void step_advance_kernel(int32_t* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1; }
+
+// End of a group's decode step: advance the step counter and rebuild the list of rows still decoding (ascending order:
+// ballot + prefix count per wave, wave offsets through LDS).  One workgroup, B <= 1024.
+__global__ __launch_bounds__(1024) void step_finish_kernel(int32_t* counter, const int32_t* done, int B, int32_t* live) {
+    __shared__ int s_cnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0 && counter) *counter += 1;
+    const bool alive = tid < B && done[tid] == 0;
+    const unsigned long long mask = __ballot(alive);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[wid] = __popcll(mask);
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wid) base += s_cnt[w]; total += s_cnt[w]; }
+    if (alive) live[1 + base + before] = tid;
+    if (tid == 0) live[0] = total;
+}
+
+int launch_step_finish(int32_t* counter, const int32_t* done, int B, int32_t* live, hipStream_t stream) {
+    WM_REQUIRE(done && live && B >= 1 && B <= 1024, "step_finish: null argument or batch %d outside [1, 1024]", B);
+    hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(1024), 0, stream, counter, done, B, live);
+    WM_LAUNCH_CHECK(stream, "step_finish");
+    return 0;
+}
 
 int launch_step_advance(int32_t* counter, hipStream_t stream) {
     WM_REQUIRE(counter, "step_advance: null counter");

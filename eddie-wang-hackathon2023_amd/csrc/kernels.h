@@ -121,6 +121,7 @@ struct AttnSelfParams {
     float* amax;                             // optional: running max |q|,|k|,|v| (int8-KV calibration)
     const int32_t* t_dev;                    // optional device copy of T (overrides T; hipGraph replay)
     h16* out; int ldo;                       // [M][C]
+    const int32_t* live;                     // optional [1 + B]: count, then the rows to process (others are skipped)
 };
 int launch_attn_self(const AttnSelfParams& p, hipStream_t stream);
 
@@ -134,6 +135,7 @@ struct AttnCrossParams {
     h16* out; int ldo;                       // [M][C]
     int nsplit;                              // key-range splits per (b,h)  (1 = single pass)
     float* ws;                               // [B*H*nsplit][L][66] partial (m, l, o[64]) when nsplit > 1
+    const int32_t* live;                     // optional [1 + B]: count, then the rows to process (others are skipped)
 };
 int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
@@ -149,9 +151,12 @@ struct GreedyParams {
     int apply_rules;                         // 0 = plain argmax (tests / models without special ids)
     int32_t* n_done;                         // [1] number of rows whose last token is eot after this step
     const int32_t* t_dev;                    // optional device step counter: cur_len = *t_dev + 1
+    int32_t* done;                           // optional [B]: 1 once the row's newest token is eot
+    const int32_t* row_limit;                // optional [B]: at most that many sampled tokens per row, then eot (no log-prob)
 };
 int launch_greedy(const GreedyParams& p, hipStream_t stream);
 int launch_step_advance(int32_t* counter, hipStream_t stream);
+int launch_step_finish(int32_t* counter, const int32_t* done, int B, int32_t* live, hipStream_t stream);
 int launch_argmax(const h16* logits, long ld_row, int B, int V, int32_t* ids, hipStream_t stream);
 
 // ---------------------------------------------------------------- frontend.hip

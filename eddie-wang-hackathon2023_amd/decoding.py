@@ -253,6 +253,11 @@ class WhisperDecoding:
         self.run_ahead = 3                # decode steps the host may be ahead of the GPU in the partitioned loop
         self._partition = None            # (light streams, heavy stream), created on first use
         self.use_graphs = True            # replay one captured decode step per token (hipGraph)
+        # Per-row completion (W/decoding.py:817-819 stops its single utterance at EOT): rows that have emitted EOT drop out
+        # of the attention kernels (their cross K/V -- 245.76 MB per token at large-v2 -- and KV cache are no longer read)
+        # and a group whose rows have all finished is no longer stepped.  Results are unchanged: a finished row is kept at
+        # EOT whatever its logits.  Off for `ignore_eot` loops (benchmarks decode a fixed number of tokens).
+        self.skip_finished_rows = True
         self._streams = []
         self._no_dedicated_queues = False
 
@@ -596,6 +601,10 @@ class WhisperDecoding:
             logits=torch.empty((n_batch, self.initial_token_length, V), dtype=torch.float16, device=device),
             sum_logprobs=torch.zeros(n_batch, dtype=torch.float32, device=device),
             n_done=torch.zeros(1, dtype=torch.int32, device=device),
+            done=torch.zeros(n_batch, dtype=torch.int32, device=device),          # per row: 1 once it has emitted EOT
+            live={},
+            # per-row sample_len (stable address: the captured graphs read it); 2^30 = no limit
+            row_limit=torch.full((n_batch,), 1 << 30, dtype=torch.int32, device=device),
             suppress=torch.tensor(suppress or [0], dtype=torch.int32, device=device), n_suppress=len(suppress),
             blank=torch.tensor(blank or [0], dtype=torch.int32, device=device), n_blank=len(blank),
         )
@@ -659,6 +668,17 @@ class WhisperDecoding:
             st['cross_key'], st['cross_xa'] = key, xa
         return st['cross']
 
+    def _live_list(self, st, n_micro, slot, lo, hi):
+        """The group's list of rows still decoding (int32 [1 + n]: count, indices relative to the group), reset to
+        "all of them"; wm_step_finish rebuilds it after every step from the `done` flags."""
+        key = (n_micro, slot)
+        if key not in st['live']:
+            st['live'][key] = torch.empty(1 + hi - lo, dtype=torch.int32, device=st['done'].device)
+        live = st['live'][key]
+        live[0] = hi - lo
+        live[1:] = torch.arange(hi - lo, dtype=torch.int32, device=live.device)
+        return live
+
     def _greedy(self, st, lo, hi, logits_ptr, row_stride, cur_len, stream, n_past_dev=None):
         """Fused logit rules + arg-max + append for utterances [lo, hi) of the batch state `st`."""
         tk = self.tokenizer
@@ -674,16 +694,22 @@ class WhisperDecoding:
         io.apply_rules = 1          # main_loop routes without_timestamps to the reference loop
         io.n_done = st['n_done'].data_ptr()
         io.n_past_dev = n_past_dev.data_ptr() if n_past_dev is not None else None
+        io.done = st['done'][lo:hi].data_ptr()
+        io.row_limit = st['row_limit'][lo:hi].data_ptr()
         native.check(native.load_library().wm_greedy_step(C.byref(io), stream), "wm_greedy_step")
 
-    def main_loop(self, audio_features, ignore_eot: bool = False):
+    def main_loop(self, audio_features, ignore_eot: bool = False, row_limit=None):
         """Greedy decoding, fast path.  Same return values as the reference's main_loop
         (tokens int64 [n, <=n_text_ctx+1], sum_logprobs fp32 [n], no_speech_probs list).
         `ignore_eot` (benchmarks with random weights) decodes `sample_len` tokens regardless.
+        `row_limit` (optional, int [n]): a per-utterance `sample_len` -- row b ends with EOT after row_limit[b] sampled
+        tokens (e.g. a bound from the clip's duration; bench.py's length distributions).
 
         Utterances are independent, so the batch is cut into `micro_batches` groups that advance in
         lock-step on separate HIP streams: while one group streams its cross-attention K/V (the
-        HBM-bound part of a step) the other group runs its latency-bound weight-streaming chain."""
+        HBM-bound part of a step) the other group runs its latency-bound weight-streaming chain.
+        Rows that have emitted EOT drop out of the attention kernels and a group whose rows are all
+        finished is no longer stepped (`skip_finished_rows`): the loop's cost follows the live rows."""
         if self.options.temperature != 0 or self.n_group != 1 or self.options.without_timestamps:
             return self.main_loop_reference(audio_features)
         dev = audio_features.device
@@ -697,31 +723,53 @@ class WhisperDecoding:
         st['tokens'][:, :L0] = tokens0.to(torch.int32)
         st['sum_logprobs'].zero_()
         st['n_done'].zero_()
+        st['done'].zero_()
+        if row_limit is not None:
+            row_limit = torch.as_tensor(row_limit).to(device=dev, dtype=torch.int32)
+            assert row_limit.shape == (n_batch,)
+            st['row_limit'].copy_(row_limit)
+        else:
+            st['row_limit'].fill_(1 << 30)
         n_micro, bounds = self._groups(n_batch)
-        if self.cu_partition and n_micro > 1 and self.decoder_session.qkv_amax is None:
+        if self.cu_partition and n_micro > 1 and self.decoder_session.qkv_amax is None and row_limit is None:
             return self._main_loop_partitioned(audio_features, st, cross, L0, n_micro, bounds, ignore_eot)
+        use_live = bool(self.skip_finished_rows) and not ignore_eot and max(hi - lo for lo, hi in bounds) <= 1024
         main = torch.cuda.current_stream()
         streams = self._group_streams(n_micro, dev)
-        for s_ in streams:
-            s_.wait_stream(main)
         sess, pos = self.decoder_session, self.positional_embedding
         groups = []
         for g, (lo, hi) in enumerate(bounds):
-            groups.append(dict(lo=lo, hi=hi, stream=streams[g].cuda_stream, slot=g,
+            groups.append(dict(lo=lo, hi=hi, stream=streams[g].cuda_stream, slot=g, active=True,
                                kv=[t[lo:hi] for t in st['kv']], cross=[t[lo:hi] for t in cross],
-                               logits=st['logits'][lo:hi], tokens=st['tokens'][lo:hi]))
+                               logits=st['logits'][lo:hi], tokens=st['tokens'][lo:hi], done=st['done'][lo:hi],
+                               live=self._live_list(st, n_micro, g, lo, hi) if use_live else None))
+        for s_ in streams:
+            s_.wait_stream(main)
         cur = L0
         steps_done = 0
         lib = native.load_library()
         use_graph = self.use_graphs and self.decoder_session.qkv_amax is None
+
+        def finish_step(gr, counter):
+            # end of a group's step: advance its device step counter (graph replay) and, with per-row completion,
+            # rebuild its list of live rows from the flags the greedy kernel has just updated
+            if gr['live'] is not None:
+                native.check(lib.wm_step_finish(counter.data_ptr() if counter is not None else None, gr['done'].data_ptr(),
+                                                gr['hi'] - gr['lo'], gr['live'].data_ptr(), gr['stream']), "wm_step_finish")
+            elif counter is not None:
+                native.check(lib.wm_step_advance(counter.data_ptr(), gr['stream']), "wm_step_advance")
+
         for i in range(self.sample_len):
             for gr in groups:
+                if not gr['active']:
+                    continue
                 lo, hi, sm, slot = gr['lo'], gr['hi'], gr['stream'], gr['slot']
-                gkey = (n_micro, slot)
+                gkey = (n_micro, slot, use_live)
                 if i == 0:
                     sess.decoder_step(gr['tokens'][:, :L0], pos[0:L0], gr['cross'], None, cap, gr['kv'], cap,
-                                      gr['logits'], 0, sm, slot=slot)
+                                      gr['logits'], 0, sm, slot=slot, live_rows=gr['live'])
                     self._greedy(st, lo, hi, gr['logits'].data_ptr() + (L0 - 1) * V * 2, L0 * V, cur, sm)
+                    finish_step(gr, None)
                 elif use_graph and gkey in st['graphs']:
                     if i == 1 or st['counters'][gkey + ('fresh',)]:
                         # the device step counter holds n_past = cur - 1; (re)seed it on the group's stream
@@ -732,8 +780,9 @@ class WhisperDecoding:
                         st['graphs'][gkey].replay()
                 else:
                     sess.decoder_step(gr['tokens'][:, cur - 1:cur], pos[cur - 1:cur], gr['cross'], gr['kv'], cap,
-                                      gr['kv'], cap, gr['logits'], cur - 1, sm, slot=slot)
+                                      gr['kv'], cap, gr['logits'], cur - 1, sm, slot=slot, live_rows=gr['live'])
                     self._greedy(st, lo, hi, gr['logits'].data_ptr(), V, cur, sm)
+                    finish_step(gr, None)
                     if use_graph:
                         # capture ONE decode step (decoder + fused greedy + counter advance) of this group;
                         # every later token replays it: T is read from a device counter inside the kernels
@@ -742,9 +791,9 @@ class WhisperDecoding:
                         graph = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph, stream=streams[slot]):
                             sess.decoder_step(gr['tokens'], pos, gr['cross'], gr['kv'], cap, gr['kv'], cap,
-                                              gr['logits'], 1, sm, slot=slot, n_past_dev=counter, n_new=1)
+                                              gr['logits'], 1, sm, slot=slot, n_past_dev=counter, n_new=1, live_rows=gr['live'])
                             self._greedy(st, lo, hi, gr['logits'].data_ptr(), V, 0, sm, n_past_dev=counter)
-                            native.check(lib.wm_step_advance(counter.data_ptr(), sm), "wm_step_advance")
+                            finish_step(gr, counter)
                         st['graphs'][gkey], st['counters'][gkey] = graph, counter
                         st['counters'][gkey + ('fresh',)] = True
             if i == 0 and self.tokenizer.no_speech is not None:
@@ -761,12 +810,17 @@ class WhisperDecoding:
             if cur > cap:
                 break
             if not ignore_eot and (steps_done % self.poll_every == 0):
-                # rows keep emitting EOT once finished, so "all rows EOT in the newest column" is
-                # monotone; poll it now and then instead of synchronising every step
+                # `done` is sticky (a finished row stays at EOT), so "every row is done" is monotone;
+                # poll it now and then instead of synchronising every step
                 for s_ in streams:
                     main.wait_stream(s_)
-                if bool((st['tokens'][:, cur - 1] == self.tokenizer.eot).all()):
+                done_host = st['done'].bool().cpu()
+                if bool(done_host.all()):
                     break
+                if use_live:
+                    for gr in groups:         # a group with no live row left costs a whole chain of launches per token: drop it
+                        if gr['active'] and bool(done_host[gr['lo']:gr['hi']].all()):
+                            gr['active'] = False
         for s_ in streams:
             main.wait_stream(s_)
         return self._finish_main_loop(st, cur, L0, n_batch, ignore_eot,
@@ -845,6 +899,10 @@ class WhisperDecoding:
     def _finish_main_loop(self, st, cur, L0, n_batch, ignore_eot, nsp_dev):
         tokens = st['tokens'][:, :cur].to(torch.int64)
         if not ignore_eot:
+            # a finished row stays at EOT (W/decoding.py:295); the columns a dropped group no longer wrote are EOT too
+            eot = self.tokenizer.eot
+            after = (tokens[:, L0:] == eot).cumsum(dim=1) > 0
+            tokens[:, L0:] = torch.where(after, torch.full_like(tokens[:, L0:], eot), tokens[:, L0:])
             # cut at the first column where every row is EOT: where the per-step check would have stopped
             all_eot = (tokens[:, L0:] == self.tokenizer.eot).all(dim=0)
             if bool(all_eot.any()):

@@ -23,7 +23,11 @@ EXPORTS = (
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
     "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
     "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_gemv_fused", "wm_set_small_batch_rows", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
+    "wm_step_finish",
 )
+
+
+ABI_VERSION = 2          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
 
 
 class WmError(RuntimeError):
@@ -56,6 +60,7 @@ class WmDecoderIO(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("qkv_amax", C.c_void_p),
         ("n_past_dev", C.c_void_p),
+        ("live_rows", C.c_void_p),
     ]
 
 
@@ -85,6 +90,8 @@ class WmGreedyIO(C.Structure):
         ("apply_rules", C.c_int32),
         ("n_done", C.c_void_p),
         ("n_past_dev", C.c_void_p),
+        ("done", C.c_void_p),
+        ("row_limit", C.c_void_p),
     ]
 
 
@@ -106,6 +113,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
             raise WmError(f"{path} does not export {name}")
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
     lib.wm_version.restype = i32
+    if lib.wm_version() != ABI_VERSION:       # a stale .so: signatures moved (wm_gemm's workspace), arguments would be misread
+        raise WmError(f"{path} has ABI version {lib.wm_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                      f"(python __graft_entry__.py)")
     lib.wm_last_error.restype = C.c_char_p
     lib.wm_device_count.argtypes = [C.POINTER(i32)]
     lib.wm_engine_create.argtypes = [vp, sz, i32, C.POINTER(vp)]
@@ -147,6 +157,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_flac_info.argtypes = [vp, sz, C.POINTER(WmFlacStreamInfo)]
     lib.wm_flac_decode.argtypes = [vp, sz, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.wm_step_advance.argtypes = [vp, vp]
+    lib.wm_step_finish.argtypes = [vp, vp, i32, vp, vp]
     lib.wm_debug_timeline.argtypes = [vp, i32]
     lib.wm_profile_configure.argtypes = [i32, i32, i32]
     lib.wm_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]

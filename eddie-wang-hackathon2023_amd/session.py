@@ -194,7 +194,8 @@ class Session(object):
                         past: Optional[Sequence[torch.Tensor]], past_capacity: int,
                         present: Sequence[torch.Tensor], present_capacity: int, logits: torch.Tensor,
                         n_past: int, qkv_amax: Optional[torch.Tensor] = None, slot: int = 0,
-                        n_past_dev: Optional[torch.Tensor] = None, n_new: Optional[int] = None) -> WmDecoderIO:
+                        n_past_dev: Optional[torch.Tensor] = None, n_new: Optional[int] = None,
+                        live_rows: Optional[torch.Tensor] = None) -> WmDecoderIO:
         """The wm_decoder_io of one call.  tokens int32 [B, L] (any row stride: a column window of a wider
         buffer works); past/present per layer [B,2,H,capacity,64]; present may be the same tensors as past
         (in-place append).  The struct keeps its pointer arrays alive (`io._keep`)."""
@@ -227,13 +228,16 @@ class Session(object):
             qkv_amax = self.qkv_amax          # calibration hook set by torch_whisper_convert.py
         io.qkv_amax = qkv_amax.data_ptr() if qkv_amax is not None else None
         io.n_past_dev = n_past_dev.data_ptr() if n_past_dev is not None else None
-        io._keep = (past_arr, present_arr, cross_arr, ws)
+        if live_rows is not None:      # int32 [1 + B]: count, then the rows still decoding (wm_step_finish keeps it current)
+            assert live_rows.dtype == torch.int32 and live_rows.numel() >= 1 + b and live_rows.is_contiguous()
+        io.live_rows = live_rows.data_ptr() if live_rows is not None else None
+        io._keep = (past_arr, present_arr, cross_arr, ws, live_rows)
         return io
 
     def decoder_step(self, tokens, pos, cross, past, past_capacity, present, present_capacity, logits, n_past,
-                     stream: int, qkv_amax=None, slot: int = 0, n_past_dev=None, n_new=None):
+                     stream: int, qkv_amax=None, slot: int = 0, n_past_dev=None, n_new=None, live_rows=None):
         io = self.make_decoder_io(tokens, pos, cross, past, past_capacity, present, present_capacity, logits, n_past,
-                                  qkv_amax, slot, n_past_dev, n_new)
+                                  qkv_amax, slot, n_past_dev, n_new, live_rows)
         check(self._engine.lib.wm_decoder_step(self._engine.handle, C.byref(io), stream), "wm_decoder_step")
 
     def decoder_step_multi(self, ios: Sequence[WmDecoderIO], light_streams: Sequence[int], heavy_stream: int):

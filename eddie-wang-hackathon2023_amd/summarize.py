@@ -67,6 +67,42 @@ def discover(dataset_dir) -> List[Tuple[Path, str]]:
     return pairs
 
 
+def clip_seconds(audio_file) -> float:
+    """Duration of a clip without decoding it: FLAC STREAMINFO (the fields wm_flac_info returns, read from the first 42
+    bytes), the wav header, the .npy header; file size as a last resort (monotone in the duration for one codec, which is all the ordering needs)."""
+    path = Path(audio_file)
+    try:
+        if path.suffix == ".flac":
+            with open(path, "rb") as fh:
+                head = fh.read(42)                          # "fLaC", block header, STREAMINFO (always the first block, RFC 9639)
+            if len(head) == 42 and head[:4] == b"fLaC" and (head[4] & 0x7f) == 0:
+                s = head[8:]
+                rate = (s[10] << 12) | (s[11] << 4) | (s[12] >> 4)
+                total = ((s[13] & 15) << 32) | (s[14] << 24) | (s[15] << 16) | (s[16] << 8) | s[17]
+                if rate > 0 and total > 0:
+                    return total / float(rate)
+        elif path.suffix == ".wav":
+            import wave
+            with wave.open(str(path), "rb") as w:
+                return w.getnframes() / float(w.getframerate())
+        elif path.suffix == ".npy":
+            return np.load(path, mmap_mode="r").shape[-1] / 16000.0
+    except Exception:       # noqa: BLE001 -- ordering is an optimisation; any unreadable header falls back to the size
+        pass
+    return float(path.stat().st_size)
+
+
+def plan_batches(pairs, batch_size: int, rank: int = 0, world: int = 1):
+    """The batches of this rank, clips ordered by duration (length-sorted chunks balance the decode lengths).
+    The sorted list is cut into batches of `batch_size` and the batches are dealt round-robin over the ranks: inside a
+    batch the clips are of similar length -- its utterance groups finish together and finished rows stop costing cross-K/V
+    bandwidth early (per-row completion in WhisperDecoding.main_loop) -- while every rank gets short and long batches alike
+    (a contiguous slice of the sorted list would hand rank 0 all the short clips)."""
+    order = sorted(range(len(pairs)), key=lambda i: (clip_seconds(pairs[i][0]), str(pairs[i][0])))
+    batches = [[pairs[i] for i in order[k:k + batch_size]] for k in range(0, len(order), batch_size)]
+    return batches[rank::world]
+
+
 def clean_hypothesis(text: str) -> str:
     """What the reference does to the engine output before normalising (W/summarize.py:125-127)."""
     punctuations = re.findall(r"[.,!?]", text)
@@ -211,7 +247,11 @@ def main(args) -> Optional[dict]:
     whisper_encoding = WhisperEncoding(engine_dir)
     whisper_decoding = WhisperDecoding(engine_dir, vocab_path=args.vocab)
     pairs = discover(args.dataset_dir)
-    lo, hi = dp.shard_bounds(len(pairs), rank, world)
+    if args.no_sort_by_duration or args.batch_size <= 1:
+        lo, hi = dp.shard_bounds(len(pairs), rank, world)
+        mine = pairs[lo:hi]
+    else:        # batches of similar-length clips, dealt over the ranks (plan_batches); the WER does not depend on the order
+        mine = [pair for batch in plan_batches(pairs, args.batch_size, rank, world) for pair in batch]
     report = {}
     runs = []
     if args.test_torch:
@@ -222,9 +262,9 @@ def main(args) -> Optional[dict]:
     for name, evaluate in runs:
         if name == "whisper-mi355" and args.overlap_encoder:
             hyps, refs, seconds = transcribe_dataset_stream(
-                pairs[lo:hi], lambda mels: eval_engines_stream(whisper_encoding, whisper_decoding, mels), args.batch_size, device)
+                mine, lambda mels: eval_engines_stream(whisper_encoding, whisper_decoding, mels), args.batch_size, device)
         else:
-            hyps, refs, seconds = transcribe_dataset(pairs[lo:hi], evaluate, args.batch_size, device)
+            hyps, refs, seconds = transcribe_dataset(mine, evaluate, args.batch_size, device)
         if world > 1:
             gathered = [None] * world
             dist.all_gather_object(gathered, (hyps, refs, seconds))
@@ -251,6 +291,8 @@ def parse_arguments(argv=None):
     parser.add_argument('--checkpoint_file', type=str, default='./large-v2.pt')
     parser.add_argument('--batch_size', type=int, default=32, help='utterances decoded together (the reference: 1)')
     parser.add_argument('--vocab', type=str, default=None, help='path to multilingual.tiktoken / gpt2.tiktoken')
+    parser.add_argument('--no_sort_by_duration', action='store_true',
+                        help='keep the directory order instead of batching clips of similar duration (plan_batches)')
     parser.add_argument('--overlap_encoder', action='store_true',
                         help='run the encoder of the next batch beside the decode loop of the current one (eval_engines_stream)')
     return parser.parse_args(argv)

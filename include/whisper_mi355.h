@@ -43,6 +43,9 @@ typedef struct wm_dims {
     int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
 } wm_dims;
 
+/* ABI version of this header: 2 (round 3: wm_gemm takes a workspace before the stream; wm_decoder_io / wm_greedy_io carry
+ * the per-row `done` flags).  Callers built against another version must refuse to run (native.py does). */
+#define WM_ABI_VERSION 2
 int wm_version(void);
 const char* wm_last_error(void);
 int wm_device_count(int* out);
@@ -110,6 +113,13 @@ typedef struct wm_decoder_io {
      * table (row T is read), `n_past` only an upper bound for validation.  Requires n_new == 1 and
      * in-place KV append.  wm_step_advance increments the counter on the stream.                   */
     const int32_t* n_past_dev;
+    /* optional list of the utterances that are still decoding (NULL = all of them): device int32 [1 + batch], word 0 =
+     * their number n, words 1..n = their indices in ascending order (wm_step_finish maintains it from the `done` flags of
+     * wm_greedy_step).  The reference stops its (single) utterance at EOT (W/decoding.py:817-819); in a batch the rows that
+     * have finished drop out of the attention kernels this way: their cross K/V (245.76 MB per token at large-v2) and
+     * their KV cache are no longer read, their rows of `logits` are left unspecified (finite) -- wm_greedy_step keeps such a
+     * row at EOT whatever its logits.  A live row's result does not depend on which other rows are live. */
+    const int32_t* live_rows;
 } wm_decoder_io;
 size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new);
 int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream);
@@ -147,9 +157,18 @@ typedef struct wm_greedy_io {
     int32_t apply_rules; /* 0: plain arg-max */
     int32_t* n_done;
     const int32_t* n_past_dev; /* optional device step counter: cur_len = *n_past_dev + 1 */
+    int32_t* done;             /* optional int32 [batch]: set to 1 when the row's new token is EOT (never cleared here) */
+    const int32_t* row_limit;  /* optional int32 [batch]: row b samples at most row_limit[b] tokens, then ends with EOT
+                                  without adding to its log-probability -- a per-utterance `sample_len` (the reference has
+                                  one for the whole loop, W/decoding.py:328, whose loop ends the same way: no EOT
+                                  log-probability, finalize pads the EOT) */
 } wm_greedy_io;
 int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream);
 int wm_step_advance(int32_t* counter, wm_stream_t stream);
+/* End of a decode step of one utterance group: *counter += 1 (when counter is given) and the list of rows still decoding
+ * is rebuilt from the flags: live[0] = number of rows with done[b] == 0, live[1..] = their indices, ascending.
+ * batch <= 1024. */
+int wm_step_finish(int32_t* counter, const int32_t* done, int batch, int32_t* live, wm_stream_t stream);
 
 /* ---- kernel-level entry points (parity tests, micro-benchmarks, roofline measurement) -----------*/
 /* C[M,N] = act(A[M,K] x W[N,K]^T * scale + bias) (+ residual); W fp16 or int8 (w8) row-major [N][K].
@@ -210,7 +229,9 @@ int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const 
                  void* out, int ldo, wm_stream_t stream);
 /* qkv fp16 [B*T, 3*H*64] with q and k pre-multiplied by 64^-0.25; out fp16 [B*T, H*64]. */
 int wm_attn_encoder(const void* qkv, int ld, int B, int T, int H, void* out, int ldo, wm_stream_t stream);
-/* Decode cross-attention: q fp32 [B*L, H*64] (un-scaled, bias included), kv fp16 [B,2,H,Tk,64]. */
+/* Decode cross-attention: q fp32 [B*L, H*64] (un-scaled, bias included), kv fp16 [B,2,H,Tk,64].
+ * nsplit = 1: one workgroup per (utterance, head), exact two-pass softmax.  1 < nsplit <= 16: the key range is cut into nsplit
+ * pieces (ws: >= B*H*nsplit*L*66 floats) and the partial softmaxes are merged; nsplit > 16 is an error.                      */
 int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void* kv, void* out,
                          int nsplit, float* ws, wm_stream_t stream);
 /* the same with int8 K/V codes [B,2,H,Tk,64] and one scale (value = fp16(code) * kv_scale, rounded to fp16) */

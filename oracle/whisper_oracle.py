@@ -306,6 +306,7 @@ class OracleModel:
     # decoder blocks and the cross-K/V projection.  Not: convs, embedding, logits matmul.
     def __init__(self, dims: Dims, state_dict: Dict[str, torch.Tensor], cfg: OracleConfig):
         self.dims, self.cfg = dims, cfg
+        self.keep_pre_quant: Optional[Dict[int, list]] = None     # tests set {}: per layer, every call's new k / v [B,2,H,L,64]
         self.p: Dict[str, torch.Tensor] = {}
         self.q: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
         for k, v in state_dict.items():
@@ -444,6 +445,8 @@ class OracleModel:
             k_new = k.view(B, L, H, C // H).permute(0, 2, 1, 3)
             v_new = v.view(B, L, H, C // H).permute(0, 2, 1, 3)
             new = torch.stack([k_new, v_new], dim=1)          # [B,2,H,L,64]
+            if self.keep_pre_quant is not None:               # tests: the values the int8 cache codes are rounded FROM
+                self.keep_pre_quant.setdefault(i, []).append(new.clone())
             if cfg.int8_kv:
                 t = cfg.kv_scales[i]
                 new_q = kv_quantize(new, t)

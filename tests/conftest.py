@@ -25,8 +25,9 @@ def pytest_sessionstart(session):
     """The C-ABI library is built in-tree (git-ignored).  `make` runs on every session: a timestamp no-op when the
     library is current, a rebuild after any edit of csrc/ (a stale .so would let the GPU suite pass for kernels
     that no longer exist).  hipcc cross-compiles gfx950 without a GPU, exactly as __graft_entry__.build() does.
-    Without hipcc, or when the build fails, only the tests that need the library fail or are skipped -- the oracle
-    and host-logic tests still run."""
+    Without hipcc only the tests that need the library are skipped -- the oracle and host-logic tests still run.
+    With hipcc present a FAILED build ends the session with an error: skipping would report a green run for kernels
+    that do not compile."""
     global _BUILD_ERROR
     import shutil
     import subprocess
@@ -37,7 +38,7 @@ def pytest_sessionstart(session):
         return
     r = subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
-        _BUILD_ERROR = "building libwhisper_mi355.so failed:\n" + r.stdout[-2000:]
+        pytest.exit("building libwhisper_mi355.so failed:\n" + r.stdout[-3000:], returncode=2)
 
 
 def pytest_collection_modifyitems(config, items):

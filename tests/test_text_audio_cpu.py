@@ -269,3 +269,38 @@ def test_bpe_encode_matches_independent_implementation_and_known_gpt2_ids(golden
     for text, ids in fx["gpt2_known"]:
         assert gp.encode(text) == ids, text
     assert sum(len(ids) for _, ids in fx["multilingual"]) > 10000          # not a vacuous fixture
+
+
+def test_clips_are_batched_by_duration_and_dealt_over_the_ranks(golden_dir, tmp_path):
+    """summarize.plan_batches (length-sorted chunks): durations come from the headers (FLAC STREAMINFO,
+    .npy shape, wav header) without decoding; clips of similar length share a batch; the batches are dealt
+    round-robin over the ranks so that every rank sees short and long batches; nothing is lost or duplicated."""
+    import wave
+    import summarize as S
+    rng = np.random.Generator(np.random.Philox(3))
+    want = {}
+    for k, n in enumerate([16000, 4000, 52000, 9000, 30000, 2500, 41000]):
+        x = _smooth(rng, n, 1, 16)
+        (tmp_path / f"a{k}.flac").write_bytes(encode_flac(x, 16, [dict(block=min(4096, n - o), kind="fixed2") for o in range(0, n, 4096)]))
+        want[f"a{k}.flac"] = n / 16000.0
+    np.save(tmp_path / "b0.npy", np.zeros(24000, dtype=np.float32)); want["b0.npy"] = 1.5
+    with wave.open(str(tmp_path / "c0.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(bytes(2 * 12000))
+    want["c0.wav"] = 0.75
+    shutil.copy(os.path.join(golden_dir, FLAC_FIXTURE), tmp_path / "d0.flac"); want["d0.flac"] = 33360 / 16000.0
+    for name, sec in want.items():
+        assert abs(S.clip_seconds(tmp_path / name) - sec) < 1e-9, name
+    pairs = [(tmp_path / name, name.upper()) for name in sorted(want)]
+    single = S.plan_batches(pairs, 4)
+    flat = [p for b in single for p in b]
+    assert sorted(map(str, (p[0] for p in flat))) == sorted(map(str, (p[0] for p in pairs)))       # a permutation
+    secs = [want[p[0].name] for p in flat]
+    assert secs == sorted(secs) and [len(b) for b in single] == [4, 4, 2]
+    assert all(p[1] == p[0].name.upper() for p in flat)                                             # references stay attached
+    per_rank = [S.plan_batches(pairs, 2, r, 2) for r in range(2)]
+    assert [len(b) for b in per_rank[0]] == [2, 2, 2] and [len(b) for b in per_rank[1]] == [2, 2]
+    seen = sorted(str(p[0]) for r in per_rank for b in r for p in b)
+    assert seen == sorted(str(p[0]) for p in pairs)
+    # every rank gets short AND long batches (a contiguous slice of the sorted list would not)
+    means = [[np.mean([want[p[0].name] for p in b]) for b in r] for r in per_rank]
+    assert min(means[0]) < 0.6 and max(means[0]) > 2.0 and min(means[1]) < 1.0 and max(means[1]) > 1.8
