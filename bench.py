@@ -419,22 +419,27 @@ def main():
             b.record()
             torch.cuda.synchronize()
             enc_alone_ms = a.elapsed_time(b)
-    # (b) the SECOND figure: utterances that end after LibriSpeech-like token counts (per-row completion).  One warm-up
-    # step (it captures the graphs of the live-row loop), then two measured steps, each the whole path like the headline's.
+    # (b) the SECOND figure: a LibriSpeech-sized job whose utterances end after LibriSpeech-like token counts (per-row
+    # completion).  5 x B lengths are drawn, sorted (summarize.py batches clips by duration) and cut into 5 batches; inside a
+    # batch the rows are dealt over the decoder's utterance groups (WhisperDecoding.balanced_order).  Every batch runs the
+    # whole path like the headline's steps (one stage after the other); the first batch's pass is repeated once untimed
+    # before the clock starts (it captures the graphs of the live-row loop).
     ragged = None
     if args.length_dist != "forced":
-        limits = librispeech_like_lengths(B, T)
-        lim_dev = torch.as_tensor(limits, dtype=torch.int32, device=dev)
+        n_jobs = 5
+        all_limits = librispeech_like_lengths(n_jobs * B, T)
+        deal = np.asarray(dec.balanced_order(B))
+        batches = [all_limits[k * B:(k + 1) * B][deal] for k in range(n_jobs)]
 
-        def ragged_step():
+        def ragged_step(limits):
             xa_r = enc.get_audio_features_async(mel)
             dec.detect_language(xa_r)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            tokens, sum_lp, _ = dec.main_loop(xa_r, row_limit=lim_dev)
+            tokens, sum_lp, _ = dec.main_loop(xa_r, row_limit=torch.as_tensor(limits, dtype=torch.int32))
             e1.record()
             return tokens, e0, e1
-        tokens_r, _, _ = ragged_step()
+        tokens_r, _, _ = ragged_step(batches[0])
         torch.cuda.synchronize()
         eot = dec.tokenizer.eot
         got = (tokens_r[:, dec.sample_begin:] != eot).sum(dim=1).cpu().numpy()
@@ -442,24 +447,27 @@ def main():
             dist.barrier()
         t_r = time.perf_counter()
         loops = []
-        for _ in range(2):
-            _, e0, e1 = ragged_step()
+        for limits in batches:
+            _, e0, e1 = ragged_step(limits)
             loops.append((e0, e1))
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        r_elapsed = dp.max_over_ranks(time.perf_counter() - t_r, dev) / 2
-        r_loop_ms = float(np.mean([a.elapsed_time(b) for a, b in loops]))
+        r_elapsed = dp.max_over_ranks(time.perf_counter() - t_r, dev)
+        loop_ms = [a.elapsed_time(b) for a, b in loops]
         kvb = 1 if args.config == "int8x" else 2
         row_bytes = dims["n_text_layer"] * dims["n_text_head"] * 2 * dims["n_audio_ctx"] * 64 * kvb       # cross K/V of one utterance, one token
-        live_bytes = float(limits.sum() + B) * row_bytes       # every row is streamed once per token it samples (+ the step that ends it)
-        ragged = {"length_dist": "librispeech-like (log-normal durations, 3.6 tokens/s + 2 timestamps, sorted by duration; bench.py: librispeech_like_lengths)",
-                  "useful_tokens_per_s": round(float(limits.sum()) * world / r_elapsed, 1),
-                  "tokens_per_utterance": {"mean": round(float(limits.mean()), 1), "min": int(limits.min()), "max": int(limits.max())},
-                  "tokens_match_the_limits": bool((got == limits).all()),
-                  "ms_per_step": round(r_elapsed * 1e3, 1), "decode_loop_ms": round(r_loop_ms, 1),
-                  "decode_loop_vs_live_row_bytes": round(r_loop_ms * 1e-3 / (live_bytes / 5.66e12), 3),
-                  "note": "whole path per step as in the headline (encoder + cross-K/V + language pass + prefill + decode loop), one stage after "
+        live_bytes = [float(l.sum() + B) * row_bytes for l in batches]     # a row is streamed once per token it samples (+ the step that ends it)
+        ragged = {"length_dist": "librispeech-like: 5 x B lengths (log-normal durations, 3.6 tokens/s + 2 timestamps; bench.py: librispeech_like_lengths), "
+                                 "sorted and cut into 5 batches as summarize.py batches clips by duration, rows dealt over the utterance groups",
+                  "useful_tokens_per_s": round(float(all_limits.sum()) * world / r_elapsed, 1),
+                  "tokens_per_utterance": {"mean": round(float(all_limits.mean()), 1), "min": int(all_limits.min()), "max": int(all_limits.max()),
+                                           "per_batch_max": [int(l.max()) for l in batches]},
+                  "tokens_match_the_limits": bool((got == batches[0]).all()),
+                  "ms_per_batch": round(r_elapsed * 1e3 / n_jobs, 1), "decode_loop_ms": [round(x, 1) for x in loop_ms],
+                  "decode_loop_vs_live_row_bytes": round(sum(loop_ms) * 1e-3 / (sum(live_bytes) / 5.66e12), 3),
+                  "decode_loop_vs_live_row_bytes_per_batch": [round(m * 1e-3 / (b / 5.66e12), 3) for m, b in zip(loop_ms, live_bytes)],
+                  "note": "whole path per batch as in the headline (encoder + cross-K/V + language pass + prefill + decode loop), one stage after "
                           "the other; rows that reach their length emit EOT, drop out of the attention kernels (live-row lists) and finished "
                           "groups are no longer stepped.  decode_loop_vs_live_row_bytes = decode loop time / (cross-K/V bytes of the rows still "
                           "decoding, summed over the steps, / 5.66 TB/s -- the rate of the forced loop's whole step)"}

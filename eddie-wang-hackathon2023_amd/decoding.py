@@ -657,6 +657,23 @@ class WhisperDecoding:
             n_micro = self.micro_batches if n_batch >= 8 * self.micro_batches else 1
         return n_micro, [(g * n_batch // n_micro, (g + 1) * n_batch // n_micro) for g in range(n_micro)]
 
+    def balanced_order(self, n_batch: int) -> List[int]:
+        """For a batch whose rows are sorted by expected decode length: the permutation that deals them over the
+        utterance groups (contiguous slices of the batch, `_groups`) like cards, so that every group holds short and long
+        rows alike.  All groups then shrink together as rows finish -- their K/V streams and chains keep overlapping --
+        instead of the group of the longest clips running on alone.  `batch[i] = sorted_batch[order[i]]`."""
+        n_micro, bounds = self._groups(n_batch)
+        room = [hi - lo for lo, hi in bounds]
+        members = [[] for _ in bounds]
+        g = 0
+        for i in range(n_batch):
+            while room[g] == 0:
+                g = (g + 1) % n_micro
+            members[g].append(i)
+            room[g] -= 1
+            g = (g + 1) % n_micro
+        return [i for m in members for i in m]
+
     def _cross_persistent(self, xa, st):
         """Cross K/V of `xa` in the state's persistent buffers (stable addresses: the captured decode
         graphs point at them).  Computed once per encoder run (`_features_key`: detect_language and main_loop

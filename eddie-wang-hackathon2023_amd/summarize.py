@@ -92,14 +92,17 @@ def clip_seconds(audio_file) -> float:
     return float(path.stat().st_size)
 
 
-def plan_batches(pairs, batch_size: int, rank: int = 0, world: int = 1):
+def plan_batches(pairs, batch_size: int, rank: int = 0, world: int = 1, deal=None):
     """The batches of this rank, clips ordered by duration (length-sorted chunks balance the decode lengths).
     The sorted list is cut into batches of `batch_size` and the batches are dealt round-robin over the ranks: inside a
     batch the clips are of similar length -- its utterance groups finish together and finished rows stop costing cross-K/V
     bandwidth early (per-row completion in WhisperDecoding.main_loop) -- while every rank gets short and long batches alike
-    (a contiguous slice of the sorted list would hand rank 0 all the short clips)."""
+    (a contiguous slice of the sorted list would hand rank 0 all the short clips).  `deal(n) -> permutation` (optional:
+    WhisperDecoding.balanced_order) arranges each batch so that the decoder's utterance groups get short and long clips alike."""
     order = sorted(range(len(pairs)), key=lambda i: (clip_seconds(pairs[i][0]), str(pairs[i][0])))
     batches = [[pairs[i] for i in order[k:k + batch_size]] for k in range(0, len(order), batch_size)]
+    if deal is not None:
+        batches = [[b[j] for j in deal(len(b))] for b in batches]
     return batches[rank::world]
 
 
@@ -251,7 +254,7 @@ def main(args) -> Optional[dict]:
         lo, hi = dp.shard_bounds(len(pairs), rank, world)
         mine = pairs[lo:hi]
     else:        # batches of similar-length clips, dealt over the ranks (plan_batches); the WER does not depend on the order
-        mine = [pair for batch in plan_batches(pairs, args.batch_size, rank, world) for pair in batch]
+        mine = [pair for batch in plan_batches(pairs, args.batch_size, rank, world, whisper_decoding.balanced_order) for pair in batch]
     report = {}
     runs = []
     if args.test_torch:

@@ -21,6 +21,9 @@ import torch
 DIMS = {
     "large-v2": dict(n_mels=80, n_audio_ctx=1500, n_audio_state=1280, n_audio_head=20, n_audio_layer=32,
                      n_vocab=51865, n_text_ctx=448, n_text_state=1280, n_text_head=20, n_text_layer=32),
+    # large-v2's width and vocabulary at a depth that builds in seconds: scheduling tests and probes (queues, data parallelism)
+    "large-v2-6layer": dict(n_mels=80, n_audio_ctx=1500, n_audio_state=1280, n_audio_head=20, n_audio_layer=6,
+                            n_vocab=51865, n_text_ctx=448, n_text_state=1280, n_text_head=20, n_text_layer=6),
     "tiny.en": dict(n_mels=80, n_audio_ctx=1500, n_audio_state=384, n_audio_head=6, n_audio_layer=4,
                     n_vocab=51864, n_text_ctx=448, n_text_state=384, n_text_head=6, n_text_layer=4),
     "tiny": dict(n_mels=80, n_audio_ctx=1500, n_audio_state=384, n_audio_head=6, n_audio_layer=4,

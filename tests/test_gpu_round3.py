@@ -254,7 +254,11 @@ def test_int8_kv_codes_differ_only_at_rounding_boundaries(tmpdir_module, weight_
     summation orders.  So the codes must be EQUAL except where the oracle's own x sits within fp16 rounding noise of a
     code boundary (n + 1/2) t -- and that is checked element by element, with no percentage budget: for every code of the
     first layer (its inputs are exact: embedding + LayerNorm + one Linear) that differs, |difference| is one code and the
-    oracle's pre-quantisation value lies within two fp16 ulps of the boundary between the two codes."""
+    oracle's pre-quantisation value lies within two fp16 ulps of the boundary between the two codes.
+    With weight-only int8 Linears the k / v values themselves carry the weight-only arithmetic's freedom (the engine
+    scales the fp32 sum of a . q once per channel, the oracle multiplies by per-element dequantised weights fp16(q . s) --
+    both inside the reference's 1.5 colmax / 128 tolerance, R/tests/quantization/_utils.py:66-88): the values agree to a
+    few fp16 ulps instead of one, and the proof uses 6 ulps there (measured worst case: 3.8)."""
     dims = Dims(**synthetic.DIMS["micro"])
     sd = synthetic_state_dict(dims, 7)
     mel = synthetic_mel(8, 2 * dims.n_audio_ctx, dims.n_mels, 1234)
@@ -282,7 +286,7 @@ def test_int8_kv_codes_differ_only_at_rounding_boundaries(tmpdir_module, weight_
     x = pre[idx]
     boundary = (np.minimum(got[idx], want[idx]) + 0.5) * t                    # the boundary between the two codes, in value units
     dist = np.abs(x - boundary)
-    assert (dist <= 2 * _ulp16(x) + 1e-12).all(), (dist / _ulp16(x)).max()
+    assert (dist <= (6 if weight_only else 2) * _ulp16(x) + 1e-12).all(), (dist / _ulp16(x)).max()
     # deeper layers see inputs that already differ by fp16 noise amplified through a block: still never more than one code
     for layer in range(1, dims.n_text_layer):
         assert (kv[layer].cpu().int() - ref["self_kv"][layer].int()).abs().max() <= 1
@@ -389,3 +393,45 @@ def test_fused_linear_refuses_widths_it_would_overrun(lib):
         call(mode=1, n_valid=50)
     call(mode=3, n_valid=50)                                            # the logits mode is the one with a ragged last block
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------ data-parallel readiness
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_line(extra, cache, timeout=1500):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--model", "large-v2-6layer", "--config", "int8", "--decode-steps", "24",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--length-dist", "forced", "--encoder-cus", "0",
+           "--engine-cache", cache] + extra
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_rccl_streams_do_not_cost_the_decode_loop_its_queues(tmp_path):
+    """The decode loop's utterance groups each own a hardware queue (streams created with a full CU mask are never
+    multiplexed).  RCCL creates streams of its own; DESIGN.md section 5 records 23.5 instead of 18.1 ms per step when a stray
+    stream made two groups share a queue.  The same three-group job with torch.distributed over RCCL initialised
+    (--force-dist: scatter and gather run as collectives) must step as fast as the plain one."""
+    cache = str(tmp_path / "engines")
+    plain = _bench_line(["--gpus", "1", "--batch", "192"], cache)
+    rccl = _bench_line(["--gpus", "1", "--batch", "192", "--force-dist"], cache)
+    print(f"ms per step: plain {plain['ms_per_step']}, with RCCL initialised {rccl['ms_per_step']}")
+    assert rccl["n_gpus"] == 1 and rccl["ms_per_step"] < 1.08 * plain["ms_per_step"]
+
+
+def test_two_gpus_scale_like_one(tmp_path):
+    """`bench.py --gpus 2` (it starts its two ranks itself: one process per GPU, utterances scattered / token ids gathered
+    over RCCL, nothing reduced) on boxes that have two GPUs: the per-GPU rate must stay within 5 % of the one-GPU run --
+    weak scaling of a path with no data-path collective.  Skipped on one-GPU boxes (the pool this suite runs on)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    cache = str(tmp_path / "engines")
+    one = _bench_line(["--gpus", "1", "--batch", "192"], cache)
+    two = _bench_line(["--gpus", "2", "--batch", "192"], cache)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["value"] / 2 > 0.95 * one["value"], (one["value"], two["value"])

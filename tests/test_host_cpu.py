@@ -320,3 +320,21 @@ def test_int4_weight_only_quantiser_and_packing():
     assert (tiles[1, 1, 16 * 2 + 5, 0] >> 4) == q[16 + 5, 128 + 64 + 2] + 8   # nibble 1 = input 2
     with pytest.raises(ValueError):
         W.tile_linear_int4(q[:, :192])
+
+
+def test_balanced_order_deals_sorted_rows_over_the_groups(tmp_path):
+    """WhisperDecoding.balanced_order: a batch sorted by expected length is permuted so that every utterance group (a
+    contiguous slice, _groups) gets short and long rows alike -- a permutation, group sizes respected, per-group means equal
+    to within one step of the sorted sequence."""
+    from decoding import WhisperDecoding
+    out = tmp_path / "eng"
+    B.build_from_checkpoint(synthetic.synthetic_checkpoint("micro", 0), B.parse_arguments(["--output_dir", str(out), "--log_level", "error"]))
+    dec = WhisperDecoding(out, only_torch=True)
+    for n in (1, 7, 16, 100, 576, 577):
+        order = dec.balanced_order(n)
+        assert sorted(order) == list(range(n))
+        n_micro, bounds = dec._groups(n)
+        means = [np.mean(order[lo:hi]) for lo, hi in bounds]
+        assert max(means) - min(means) <= n_micro + 2, (n, means)      # (ragged group sizes: the odd row out is the longest)
+        for lo, hi in bounds:
+            assert order[lo:hi] == sorted(order[lo:hi])            # inside a group the rows stay in sorted order
