@@ -24,6 +24,8 @@
 //    registers into padded rows: with 246 VGPRs the 16 staging registers were spilled -- scratch stores right behind the
 //    global loads, i.e. every tile waited for its successor's HBM round trip (4 scratch stores + 2 loads per tile, found in
 //    the ISA in round 2).  Each wave owns QB blocks of 16 queries and re-uses every K / V fragment for all of them.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -128,31 +130,59 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
             }
         }
         // ---- mask the tail, round to fp16, online softmax (per lane = per query) ------------------
+        // The four query blocks go through every stage TOGETHER: first all local maxima, then one round of cross-lane
+        // exchanges for the four of them (xor 16), then the other (xor 32) -- two LDS round trips per tile.  Taken block by
+        // block (round 2) every block paid its own four dependent ds_bpermute + wait pairs: 16 exposed round trips per
+        // tile, more wave time than the tile's 64 MFMAs.  The row SUMS are not exchanged per tile at all: a lane keeps the
+        // partial sum over the keys it owns (the rescale factor alpha is common to a query's four lanes), the four partial
+        // sums meet once, after the last tile.
         const int key0 = t * KT_KEYS + 4 * g;          // + 16 kb + r
         half8v pf[2][QB];                              // P^T fragments per 32-key chunk
         constexpr float LOG2E = 1.4426950408889634f;
+        float mx[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            // the maximum is taken on the raw scores and rounded once (rounding is monotonic); scores and
-            // probabilities are rounded to fp16 in pairs (v_cvt_pk_f16_f32), exp(s - m) is one mixed-precision
-            // fma + v_exp_f32 on the fp16 score, the row sum one v_dot2 per pair
-            float mx = -INFINITY;
+            // the maximum is taken on the raw scores and rounded once (rounding is monotonic)
+            float m = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (TAIL && key0 + 16 * kb + r >= p.T) sacc[kb][qb][r] = -INFINITY;
-                    mx = fmaxf(mx, sacc[kb][qb][r]);
+                    m = fmaxf(m, sacc[kb][qb][r]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx[qb] = m;
+        }
+        {
+            float o16[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) o16[qb] = __shfl_xor(mx[qb], 16);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) mx[qb] = fmaxf(mx[qb], o16[qb]);
+            float o32[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) o32[qb] = __shfl_xor(mx[qb], 32);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) mx[qb] = fmaxf(mx[qb], o32[qb]);
+        }
+        float mL[QB], alpha[QB];
+        bool moved = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
             const float m_old = m_run[qb];
-            const float m_new = fmaxf(m_old, r16(mx));
+            const float m_new = fmaxf(m_old, r16(mx[qb]));
             // explicit roundings (no fp-contract freedom): both template instantiations must give the same bits,
             // the result of a clip must not depend on how many clips share the launch
-            const float mL = __fmul_rn(m_new, LOG2E);
-            const float alpha = __builtin_amdgcn_exp2f(__fsub_rn(__fmul_rn(m_old, LOG2E), mL));   // exp(m_old - m_new); 0 on the first tile
+            mL[qb] = __fmul_rn(m_new, LOG2E);
+            alpha[qb] = __builtin_amdgcn_exp2f(__fsub_rn(__fmul_rn(m_old, LOG2E), mL[qb]));   // exp(m_old - m_new); 0 on the first tile
+            moved |= (m_new != m_old);
             m_run[qb] = m_new;
+        }
+        const bool any_moved = __builtin_amdgcn_ballot_w64(moved) != 0;     // wave-uniform
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            // scores and probabilities are rounded to fp16 in pairs (v_cvt_pk_f16_f32), exp(s - m) is one mixed-precision
+            // fma + v_exp_f32 on the fp16 score, the row sum one v_dot2 per pair
             float ps = 0.f;
             const half2v one2 = {(h16)1.0f, (h16)1.0f};
 #pragma unroll
@@ -160,20 +190,20 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
                     const half2v s2 = __builtin_convertvector(float2v{sacc[kb][qb][r], sacc[kb][qb][r + 1]}, half2v);
-                    const float p0 = __builtin_amdgcn_exp2f(__fmaf_rn((float)s2[0], LOG2E, -mL));
-                    const float p1 = __builtin_amdgcn_exp2f(__fmaf_rn((float)s2[1], LOG2E, -mL));
+                    const float p0 = __builtin_amdgcn_exp2f(__fmaf_rn((float)s2[0], LOG2E, -mL[qb]));
+                    const float p1 = __builtin_amdgcn_exp2f(__fmaf_rn((float)s2[1], LOG2E, -mL[qb]));
                     const half2v p2 = __builtin_convertvector(float2v{p0, p1}, half2v);
                     ps = __builtin_amdgcn_fdot2(p2, one2, ps, false);
                     pf[kb >> 1][qb][(kb & 1) * 4 + r] = p2[0];
                     pf[kb >> 1][qb][(kb & 1) * 4 + r + 1] = p2[1];
                 }
-            ps += __shfl_xor(ps, 16);
-            ps += __shfl_xor(ps, 32);
-            l_run[qb] = __fmaf_rn(l_run[qb], alpha, ps);
-            if (__builtin_amdgcn_ballot_w64(m_new != m_old)) {      // wave-uniform: skip the accumulator round trip while
+            l_run[qb] = __fmaf_rn(l_run[qb], alpha[qb], ps);     // this lane's keys only; the four lanes of a query meet at the end
+        }
+        if (any_moved) {                            // skip the accumulator round trip while no query's maximum moved (alpha == 1 exactly)
 #pragma unroll
-                for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;  // no query's maximum moved (alpha == 1 exactly)
-            }
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) o[db][qb] *= alpha[qb];
         }
         // ---- O^T += V^T . P^T ------------------------------------------------------------------------
 #pragma unroll
@@ -204,8 +234,11 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qrow = q_base + qb * 16 + li;
+        float l = l_run[qb];                                     // the four lanes of a query hold the sums over their own keys
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
         if (qrow >= p.T) continue;
-        const float inv = 1.0f / l_run[qb];
+        const float inv = 1.0f / l;
         h16* dst = p.out + ((size_t)b * p.T + qrow) * p.ldo + h * 64;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
@@ -233,8 +266,10 @@ int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream) {
     // the faster variant at every batch size for T = 1500 (B = 1: 60 vs 67 us, B = 128: 21 vs 36 us per clip-layer).
     // The choice depends on T only, never on the batch: the two instantiations agree to one fp16 ulp, not bit for bit,
     // and the result of a clip must not depend on how many clips share the launch (tests: batch independence).
-    if (p.T > 128 && p.max_wgs > 0 && p.max_wgs < ((p.T + 255) / 256) * p.H * p.B) {
-        hipLaunchKernelGGL((attn_encoder_kernel<4, true>), dim3(p.max_wgs), dim3(256), 0, stream, p);
+    static const int lab_wgs = [] { const char* v = getenv("WM_ATTN_MAX_WGS"); return v ? atoi(v) : 0; }();        // probes only (scripts/kv_beside_probe.py)
+    const int max_wgs = p.max_wgs > 0 ? p.max_wgs : lab_wgs;
+    if (p.T > 128 && max_wgs > 0 && max_wgs < ((p.T + 255) / 256) * p.H * p.B) {
+        hipLaunchKernelGGL((attn_encoder_kernel<4, true>), dim3(max_wgs), dim3(256), 0, stream, p);
     } else if (p.T > 128) {
         dim3 grid((p.T + 255) / 256, p.H, p.B);
         hipLaunchKernelGGL(attn_encoder_kernel<4>, grid, dim3(256), 0, stream, p);

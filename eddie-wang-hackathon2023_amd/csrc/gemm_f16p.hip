@@ -364,7 +364,9 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     const int n_tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     int grid = (n_cu / 8) * 8;
     if (grid < 8) grid = 8;
-    if (p.max_wgs > 0 && p.max_wgs < grid) grid = p.max_wgs >= 8 ? (p.max_wgs / 8) * 8 : 8;
+    static const int lab_wgs = [] { const char* v = getenv("WM_GEMM_MAX_WGS"); return v ? atoi(v) : 0; }();      // probes only (scripts/kv_beside_probe.py)
+    const int max_wgs = p.max_wgs > 0 ? p.max_wgs : lab_wgs;
+    if (max_wgs > 0 && max_wgs < grid) grid = max_wgs >= 8 ? (max_wgs / 8) * 8 : 8;
     const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
     if (grid > need) grid = need;
     const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f;

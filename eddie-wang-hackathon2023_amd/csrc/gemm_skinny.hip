@@ -24,6 +24,8 @@
 // Parallelism: grid = ceil(n_blocks / 4) x ksplit workgroups.  K slices write fp32 partial slabs
 // part[s][m][n] (already multiplied by the per-channel scale); the consumer kernel sums the slabs
 // in a fixed order (deterministic, unlike atomics) together with bias / residual / LN / GELU.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -212,10 +214,32 @@ int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
     return max(1, s);
 }
 
+// Waves per workgroup for the multi-tile shapes (3 or more MFMA row tiles).  8 waves share one staged activation chunk
+// (half the L2 traffic for A), but an 8-wave workgroup needs two waves' registers on every SIMD (2 x 136 at 12 row tiles):
+// it cannot be dispatched to a CU on which three workgroups of another group's K/V stream (3 x 96 registers per SIMD) are
+// resident -- which is every CU once the encoder of the next batch holds part of the chip -- and then the groups' chains
+// no longer overlap the other groups' streams.  4-wave workgroups (one wave per SIMD) fit.  The arithmetic does not depend
+// on the choice (same K slices, same order).  WM_SKINNY_NW=4|8 overrides.
+static int skinny_nw() {
+    static const int nw = [] { const char* v = getenv("WM_SKINNY_NW"); const int x = v ? atoi(v) : 8; return x == 4 ? 4 : 8; }();
+    return nw;
+}
+
 template <int WB>
 static int launch_mt(const GemmSkinnyParams& p, hipStream_t stream) {
     const int mt = (p.M + 15) / 16;
     const int g4 = ((p.n_blocks + 3) / 4) * p.ksplit, g8 = ((p.n_blocks + 7) / 8) * p.ksplit;
+    if (skinny_nw() == 4 && mt >= 3) {
+        switch (mt) {
+            case 3: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 3, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+            case 4: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 4, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+            case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 6, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+            case 7: case 8: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 8, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+            case 9: case 10: case 11: case 12: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 12, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 16, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+        }
+        return 0;
+    }
     switch (mt) {
         case 1: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 1, 4>), dim3(g4), dim3(256), 0, stream, p); break;
         case 2: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 2, 4>), dim3(g4), dim3(256), 0, stream, p); break;
