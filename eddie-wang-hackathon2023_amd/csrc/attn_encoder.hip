@@ -49,13 +49,17 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int C = p.H * 64;
-    int item = blockIdx.x;                     // PERSIST only (the launch never has more workgroups than items)
+    // Items (query tile, head, clip) are numbered so that the query tiles of one (clip, head) share blockIdx % 8 -- one XCD under
+    // round-robin placement (speed only) -- and follow each other closely: the head's K and V (384 KB at T = 1500) then leave
+    // HBM once and serve the other query tiles from that XCD's L2 (with the tiles of a head dealt over the XCDs the kernel
+    // fetched 2.2x its algorithmic bytes: profiles/r3g_pmc_stage_b192_pass2.txt).  item = 8 * j + x: head (j / nx) * 8 + x, tile j % nx.
+    const int nx = (p.T + 64 * QB - 1) / (64 * QB), n_heads = p.H * p.B;
+    const int n_items = 8 * ((n_heads + 7) / 8) * nx;
+    int item = blockIdx.x;
     do {
-    int bx, h, b;
-    if constexpr (PERSIST) {
-        const int nx = (p.T + 64 * QB - 1) / (64 * QB);
-        bx = item % nx; h = (item / nx) % p.H; b = item / (nx * p.H);
-    } else { bx = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
+    const int hh = ((item >> 3) / nx) * 8 + (item & 7), bx = (item >> 3) % nx;
+    if (hh < n_heads) {                        // (wave-uniform; the padding items of the last group of eight heads)
+    const int h = hh % p.H, b = hh / p.H;
     const int q_base = bx * (64 * QB) + wid * (16 * QB);
     const h16* base = p.qkv + (size_t)b * p.T * p.ld;
 
@@ -255,8 +259,9 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
             *(half4v*)(dst + db * 16 + g * 4) = w;
         }
     }
-    if constexpr (PERSIST) item += gridDim.x;
-    } while (PERSIST && item < ((p.T + 64 * QB - 1) / (64 * QB)) * p.H * p.B);
+    }
+    item += gridDim.x;
+    } while (PERSIST && item < n_items);
 }
 
 int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream) {
@@ -268,14 +273,13 @@ int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream) {
     // and the result of a clip must not depend on how many clips share the launch (tests: batch independence).
     static const int lab_wgs = [] { const char* v = getenv("WM_ATTN_MAX_WGS"); return v ? atoi(v) : 0; }();        // probes only (scripts/kv_beside_probe.py)
     const int max_wgs = p.max_wgs > 0 ? p.max_wgs : lab_wgs;
+    const int heads8 = 8 * ((p.H * p.B + 7) / 8);            // items: see the kernel (8 heads x nx query tiles per group)
     if (p.T > 128 && max_wgs > 0 && max_wgs < ((p.T + 255) / 256) * p.H * p.B) {
-        hipLaunchKernelGGL((attn_encoder_kernel<4, true>), dim3(max_wgs), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_encoder_kernel<4, true>), dim3(max_wgs >= 8 ? max_wgs / 8 * 8 : max_wgs), dim3(256), 0, stream, p);
     } else if (p.T > 128) {
-        dim3 grid((p.T + 255) / 256, p.H, p.B);
-        hipLaunchKernelGGL(attn_encoder_kernel<4>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_encoder_kernel<4>, dim3(heads8 * ((p.T + 255) / 256)), dim3(256), 0, stream, p);
     } else {
-        dim3 grid((p.T + 127) / 128, p.H, p.B);
-        hipLaunchKernelGGL(attn_encoder_kernel<2>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_encoder_kernel<2>, dim3(heads8 * ((p.T + 127) / 128)), dim3(256), 0, stream, p);
     }
     WM_LAUNCH_CHECK(stream, "attn_encoder");
     return 0;

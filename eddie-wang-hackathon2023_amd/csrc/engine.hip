@@ -616,10 +616,26 @@ int small_path_max_rows() {               // WM_SMALL_PATH=<rows> / wm_set_small
     return r;
 }
 
+// Groups of more rows than that take the row-split form of the same fused Linears (gemm_rows.hip) for every projection whose
+// input is n_state wide: 10 launches per layer instead of 12, fp32 slabs only behind the MLP's second Linear.  WM_ROWS_PATH=0 /
+// wm_set_rows_path(0): the split-K chain (gemm_skinny + row kernel) for every Linear, as in rounds 1-2.
+std::atomic<int> g_rows_path{-1};
+int rows_path_enabled() {
+    int r = g_rows_path.load(std::memory_order_relaxed);
+    if (r < 0) {
+        const char* v = getenv("WM_ROWS_PATH");
+        r = v ? (atoi(v) != 0) : 1;
+        g_rows_path.store(r, std::memory_order_relaxed);
+    }
+    return r;
+}
+
 struct GroupStep {
     const wm_engine* e; const wm_decoder_io* io; DecWs w;
     int B, L, T, C, H, M;
-    bool small = false;                          // the fused small-batch path
+    bool small = false;                          // the fused small-batch path (gemv_small.hip)
+    bool rows = false;                           // the fused row-split path (gemm_rows.hip)
+    bool fused() const { return small || rows; }
 
     // one Linear of the small-batch path.  mode as epilogue.h; ln_g != null: LayerNorm of the input rows (the residual stream)
     // inside the kernel
@@ -631,10 +647,18 @@ struct GroupStep {
         p.out32 = w.part; p.ld32 = l.N;
         p.out16 = out16; p.ld16 = ld16; p.n_valid = l.N;
         p.x = w.x; p.ldx = C;
-        return launch_gemv_small(p, s);
+        return small ? launch_gemv_small(p, s) : launch_gemm_rows(p, s);
     }
 
     Profiler* prof = nullptr;
+
+    // diagnostic (WM_TIMELINE_FINE=1 with wm_debug_timeline): a stamp behind EVERY kernel of the chain, code 1000 + 32 * layer + position
+    // (scripts/chain_probe.py turns them into in-situ durations per chain position); the K/V launch keeps its own pair of stamps
+    void mark(int layer, int pos, hipStream_t s) {
+        static const bool fine = [] { const char* v = getenv("WM_TIMELINE_FINE"); return v && v[0] == '1'; }();
+        if (fine && prof->timeline)
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, prof->timeline, prof->timeline_cap, (long long)(uintptr_t)io->logits, (long long)(1000 + 32 * layer + pos));
+    }
 
     int init(const wm_engine* e_, const wm_decoder_io* io_) {
         e = e_; io = io_;
@@ -653,6 +677,7 @@ struct GroupStep {
         w = carve_decoder(e, B, L, io->workspace);
         WM_REQUIRE(io->workspace_bytes >= w.total, "decoder workspace too small: %zu < %zu", io->workspace_bytes, w.total);
         small = M <= small_path_max_rows();
+        rows = !small && rows_path_enabled() && !e->dec.empty() && gemm_rows_supports(C, e->dec[0].qkv.wcode);
         return 0;
     }
 
@@ -670,7 +695,7 @@ struct GroupStep {
         EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
                        (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev};
         if (launch_embed(ep, s)) return 2;
-        if (small) return 0;                         // the first LayerNorm happens inside the qkv projection
+        if (fused()) return 0;                       // the first LayerNorm happens inside the qkv projection
         return launch_layernorm(w.x, C, M, C, e->dec[0].ln1g, e->dec[0].ln1b, w.xn, C, s);
     }
 
@@ -678,10 +703,12 @@ struct GroupStep {
     int pre_cross(int i, hipStream_t s) {
         const DecLayer& Lr = e->dec[i];
         int ks = 0;
-        if (small) {
+        mark(i, 0, s);
+        if (fused()) {
             if (gemv(Lr.qkv, w.x, C, 0, Lr.ln1g, Lr.ln1b, nullptr, 0, s)) return 2;      // LN + qkv sums -> w.part [M][3C]
             ks = 1;
         } else if (skinny_all(Lr.qkv, w.xn, C, M, w.part, &ks, s)) return 2;
+        mark(i, 1, s);
         AttnSelfParams p{};
         p.part = w.part; p.ksplit = ks; p.ldp = Lr.qkv.N; p.part_sstride = (long)M * Lr.qkv.N; p.bias = Lr.qkv.b;
         p.B = B; p.L = L; p.T = T; p.H = H;
@@ -696,15 +723,21 @@ struct GroupStep {
         p.t_dev = io->n_past_dev;
         p.live = io->live_rows;
         if (launch_attn_self(p, s)) return 2;
-        if (small) {
+        mark(i, 2, s);
+        if (fused()) {
             if (gemv(Lr.out, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;    // x += out(ctx)
+            mark(i, 3, s);
             if (gemv(Lr.cq, w.x, C, 0, Lr.lncg, Lr.lncb, nullptr, 0, s)) return 2;       // LN + q sums -> w.part [M][C]
+            mark(i, 5, s);
             cq_ks = 1;
             return 0;
         }
         if (skinny_all(Lr.out, w.ctx, C, M, w.part, &ks, s)) return 2;
+        mark(i, 3, s);
         if (finish(Lr.out, ks, 0, Lr.lncg, Lr.lncb, w.xn, C, C, s)) return 2;
+        mark(i, 4, s);
         if (skinny_all(Lr.cq, w.xn, C, M, w.part, &cq_ks, s)) return 2;
+        mark(i, 5, s);
         return 0;
     }
     int cq_ks = 0;
@@ -739,18 +772,35 @@ struct GroupStep {
         const DecLayer& Lr = e->dec[i];
         const wm_dims& d = e->dims;
         int ks = 0;
-        if (small) {
+        mark(i, 6, s);
+        if (fused()) {
             if (gemv(Lr.cout, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;
+            mark(i, 7, s);
             if (gemv(Lr.mlp1, w.x, C, 1, Lr.ln2g, Lr.ln2b, w.hid, 4 * C, s)) return 2;     // LN + GELU
-            return gemv(Lr.mlp2, w.hid, 4 * C, 2, nullptr, nullptr, nullptr, 0, s);
+            mark(i, 10, s);
+            if (small) return gemv(Lr.mlp2, w.hid, 4 * C, 2, nullptr, nullptr, nullptr, 0, s);
+            // K = 4 n_state: the hidden rows of a 32-row block do not fit one workgroup's LDS -- K slices over workgroups, the
+            // row kernel adds them to the residual stream (no LayerNorm there: the next projection normalises its own input)
+            if (skinny_all(Lr.mlp2, w.hid, 4 * C, M, w.part, &ks, s)) return 2;
+            mark(i, 11, s);
+            const int rc = finish(Lr.mlp2, ks, 3, nullptr, nullptr, nullptr, 0, C, s);
+            mark(i, 12, s);
+            return rc;
         }
         if (skinny_all(Lr.cout, w.ctx, C, M, w.part, &ks, s)) return 2;
+        mark(i, 7, s);
         if (finish(Lr.cout, ks, 0, Lr.ln2g, Lr.ln2b, w.xn, C, C, s)) return 2;
+        mark(i, 8, s);
         if (skinny_all(Lr.mlp1, w.xn, C, M, w.part, &ks, s)) return 2;
+        mark(i, 9, s);
         if (finish(Lr.mlp1, ks, 1, nullptr, nullptr, w.hid, 4 * C, 4 * C, s)) return 2;
+        mark(i, 10, s);
         if (skinny_all(Lr.mlp2, w.hid, 4 * C, M, w.part, &ks, s)) return 2;
+        mark(i, 11, s);
         const bool last = (i + 1 == d.n_text_layer);
-        return finish(Lr.mlp2, ks, 0, last ? e->lnfg : e->dec[i + 1].ln1g, last ? e->lnfb : e->dec[i + 1].ln1b, w.xn, C, C, s);
+        const int rc = finish(Lr.mlp2, ks, 0, last ? e->lnfg : e->dec[i + 1].ln1g, last ? e->lnfb : e->dec[i + 1].ln1b, w.xn, C, C, s);
+        mark(i, 12, s);
+        return rc;
     }
 
     // logits = ln(x) . E^T (fp16 out, whisper/model.py:288-290)
@@ -764,6 +814,7 @@ struct GroupStep {
             p.mode = 3; p.out16 = (h16*)io->logits; p.ld16 = d.n_vocab; p.n_valid = d.n_vocab;
             return launch_gemv_small(p, s);
         }
+        if (rows && launch_layernorm(w.x, C, M, C, e->lnfg, e->lnfb, w.xn, C, s)) return 2;
         for (int r0 = 0; r0 < M; r0 += SKINNY_MAX_M) {
             GemmSkinnyParams p{};
             p.A = w.xn + (size_t)r0 * C; p.lda = C; p.M = (M - r0) < SKINNY_MAX_M ? (M - r0) : SKINNY_MAX_M; p.K = C;
@@ -969,6 +1020,24 @@ int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_b
     return launch_gemm_skinny(p, (hipStream_t)stream);
 }
 int wm_gemm_skinny_default_ksplit(int M, int K, int n_blocks, int w8) { return skinny_default_ksplit(M, K, n_blocks, w8); }
+
+int wm_set_rows_path(int enabled) {
+    const int prev = rows_path_enabled();
+    g_rows_path.store(enabled ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+
+int wm_gemm_rows(const wm_gemv_io* io, wm_stream_t stream) {
+    WM_REQUIRE(io && io->a && io->wt, "wm_gemm_rows: null argument");
+    GemvSmallParams p{};
+    p.A = (const h16*)io->a; p.lda = io->lda; p.M = io->m; p.K = io->k; p.Wt = io->wt; p.n_blocks = io->n_blocks; p.w8 = io->w8;
+    p.scale = (const h16*)io->scale;
+    p.ln_g = (const h16*)io->ln_gamma; p.ln_b = (const h16*)io->ln_beta;
+    p.mode = io->mode; p.bias = (const h16*)io->bias; p.gelu_kind = io->gelu_kind;
+    p.out32 = io->out32; p.ld32 = io->ld32; p.out16 = (h16*)io->out16; p.ld16 = io->ld16; p.n_valid = io->n_valid;
+    p.x = (h16*)io->x; p.ldx = io->ldx;
+    return launch_gemm_rows(p, (hipStream_t)stream);
+}
 
 int wm_set_small_batch_rows(int rows) {
     const int prev = small_path_max_rows();

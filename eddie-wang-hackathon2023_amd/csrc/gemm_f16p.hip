@@ -77,6 +77,25 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     if (my_tiles == 0) return;
     const int nk = p.K / BK;                         // stages per tile
     const int total_stages = my_tiles * nk;
+    // Order of a band's tiles.  In plain row-major order the workgroups of an XCD, which march over K roughly in step, hold
+    // ~32 / nt_n row panels against ALL nt_n channel tiles: each A panel is fetched once, but the whole weight matrix streams
+    // through the XCD's 4 MB L2 once per row panel (N = 5120, K = 1280: 13 MB of W per 0.66 MB of A -- the kernel fetched 11x
+    // its algorithmic bytes, 8.4 GB per launch at M = 288 000, 2 TB/s of fabric traffic that the decode loop beside it pays
+    // for: profiles/r3g_pmc_stage_b192_pass2.txt).  Instead the band's full tile rows are taken R at a time (R row panels =
+    // <= 2.75 MB stay in L2), channel tile by channel tile: the weights stream past R panels at once -- 1 / R of the traffic.
+    // Head and tail of the band (partial tile rows) keep the plain order.  Same tiles, same arithmetic; only the order changes.
+    const int R = max(1, min(8, (int)((2816u << 10) / ((unsigned)p.K * BM * 2u))));
+    const int row_first = (lo + nt_n - 1) / nt_n, row_last = hi / nt_n;              // full tile rows [row_first, row_last)
+    const int q_head = min(hi, row_first * nt_n) - lo, q_mid = max(0, row_last - row_first) * nt_n;
+    auto tile_of = [&](int q, int& tm, int& tn) {     // q-th tile of the band -> (row panel, channel tile)
+        if (q < q_head) { const int tile = lo + q; tm = tile / nt_n; tn = tile - tm * nt_n; return; }
+        const int q2 = q - q_head;
+        if (q2 >= q_mid) { const int tile = row_last * nt_n + (q2 - q_mid); tm = tile / nt_n; tn = tile - tm * nt_n; return; }
+        const int sr = q2 / (R * nt_n), rem = q2 - sr * (R * nt_n);
+        const int rows_here = min(R, (row_last - row_first) - sr * R);
+        tn = rem / rows_here;
+        tm = row_first + sr * R + (rem - tn * rows_here);
+    };
 
     // ---- loader: per stage this wave requests 2 A pieces and 2 W pieces of 16 rows x 64 B, as two "halves" (one A and one
     // W piece each).  Addresses are a wave-uniform base per tile (advanced by 64 B per stage) plus a 32-bit lane offset ---
@@ -93,8 +112,8 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         w_lane[q] = (uint32_t)r * (uint32_t)p.K * 2u + c * 16;
     }
     auto set_tile = [&](int t) {                     // loader -> tile number t of this workgroup, K offset 0
-        const int tile = lo + j0 + t * per_xcd;
-        const int tm = tile / nt_n, tn = tile - tm * nt_n;
+        int tm, tn;
+        tile_of(j0 + t * per_xcd, tm, tn);
         const size_t off0 = row_offset(tm * BM);
         a_base = (const unsigned char*)(p.A + off0);
         w_base = (const unsigned char*)p.W + (size_t)tn * BN * p.K * 2;
@@ -204,8 +223,8 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         if (++ks < nk) continue;
 
         // ================================ epilogue (as gemm_f16.hip) =====================================================
-        const int tile = lo + j0 + t * per_xcd;
-        const int tm = tile / nt_n, tn = tile - tm * nt_n;
+        int tm, tn;
+        tile_of(j0 + t * per_xcd, tm, tn);
         const int row0 = tm * BM, col0 = tn * BN;
         const int hs_b0 = !SIMPLE && p.out_mode == 1 ? row0 / p.hs_T : 0, hs_t0 = !SIMPLE && p.out_mode == 1 ? row0 - hs_b0 * p.hs_T : 0;     // wave-uniform
         // every lane-dependent quantity of the epilogue is derived from `le`, which the compiler cannot see through: nothing

@@ -64,6 +64,12 @@ struct GemvSmallParams {
 constexpr int GEMV_SMALL_MAX_M = 32;
 int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
 
+// ---------------------------------------------------------------- gemm_rows.hip
+// The same contract (GemvSmallParams, modes 0-2, optional LayerNorm prologue; ksplit unused) for ANY number of rows: the rows
+// are split over workgroups (16 or 32 rows x 64 channels each), the whole K per wave.  K <= 1536 (the input block sits in LDS).
+bool gemm_rows_supports(int K, int w8);
+int launch_gemm_rows(const GemvSmallParams& p, hipStream_t stream);
+
 // ---------------------------------------------------------------- rowops.hip
 struct RowFinishParams {
     // y = sum_s part[s][m][:] + bias ; y16 = fp16(y)

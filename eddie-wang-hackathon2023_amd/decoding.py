@@ -582,6 +582,16 @@ class WhisperDecoding:
         cfg = self.decoder_config
         n_layer, n_head, cap, V = cfg['num_layers'], cfg['num_heads'], cfg['num_text_ctx'], cfg['vocab_size']
         kv_dtype = torch.int8 if self.use_int8_kv_cache else torch.float16
+        if device.type == 'cuda':
+            # the batch ceiling is a property of the free memory, said up front instead of an allocator error half way through
+            per_row = self.state_bytes_per_utterance()
+            free, _ = torch.cuda.mem_get_info(device)
+            if n_batch * per_row > free:
+                raise RuntimeError(
+                    f"WhisperDecoding: a batch of {n_batch} utterances needs {n_batch * per_row / 2**30:.1f} GiB of decoder state "
+                    f"({per_row / 2**20:.1f} MiB per utterance: self-attention cache + cross-attention K/V of {n_layer} layers), "
+                    f"{free / 2**30:.1f} GiB are free on {device}: at most {int(free // per_row)} utterances per batch fit "
+                    f"(another WhisperDecoding's buffer set in this process counts against it)")
         tk = self.tokenizer
         suppress = []
         for f in self.logit_filters:
@@ -610,6 +620,16 @@ class WhisperDecoding:
         )
         self._state[n_batch] = st
         return st
+
+    def state_bytes_per_utterance(self) -> int:
+        """Device bytes of decoder state one utterance of a batch holds (what `_fast_state` allocates per row): the
+        self-attention cache [2, H, n_text_ctx, 64] and the cross-attention K/V [2, H, n_audio_ctx, 64] of every layer
+        (245.76 MB at large-v2 with fp16 cross K/V), tokens and the prefill logits."""
+        cfg = self.decoder_config
+        n_layer, n_head, cap, V = cfg['num_layers'], cfg['num_heads'], cfg['num_text_ctx'], cfg['vocab_size']
+        kv = 2 * n_head * cap * 64 * (1 if self.use_int8_kv_cache else 2)
+        cross = 2 * n_head * cfg['num_audio_ctx'] * 64 * (1 if self.use_int8_cross_kv else 2)
+        return n_layer * (kv + cross) + (cap + 1) * 4 + self.initial_token_length * V * 2 + 64
 
     def _group_streams(self, n, dev):
         """Side streams of the utterance groups (never the legacy default stream: graphs are captured on them).

@@ -8,7 +8,7 @@ Numbers come from per-tensor numpy PCG64 streams, so the same seed gives the sam
 Linear weights are N(0, (gain / sqrt(fan_in))^2), the tied embedding N(0, (logit_std/sqrt(C))^2),
 LayerNorm gains 1 + U(-.1, .1): see DESIGN.md "synthetic weights" for why the customary 0.02 is
 not used (greedy decoding degenerates to repeating one token, parity tests become vacuous).
-tests/test_synthetic.py pins this generator to the oracle's independent copy.
+tests/test_host_cpu.py (test_synthetic_weights_match_the_oracle_generator) pins this generator to the oracle's independent copy.
 """
 from __future__ import annotations
 

@@ -45,7 +45,7 @@ typedef struct wm_dims {
 
 /* ABI version of this header: 2 (round 3: wm_gemm takes a workspace before the stream; wm_decoder_io / wm_greedy_io carry
  * the per-row `done` flags).  Callers built against another version must refuse to run (native.py does). */
-#define WM_ABI_VERSION 2
+#define WM_ABI_VERSION 3
 int wm_version(void);
 const char* wm_last_error(void);
 int wm_device_count(int* out);
@@ -224,6 +224,18 @@ int wm_gemv_fused(const wm_gemv_io* io, wm_stream_t stream);
  * the batch it is in on either side of the switch; across it the two paths agree to fp32 summation order (a last-bit
  * difference of fp16 values in rare cases).  Captured graphs keep the path they were captured with.                    */
 int wm_set_small_batch_rows(int rows);
+/* The same Linear (same wm_gemv_io, modes 0-2, optional LayerNorm prologue) for ANY number of rows m: the rows are split over
+ * workgroups (16 or 32 rows x 64 channels each, the whole k per wave, the input block in LDS by DMA), so a row's sums never
+ * leave the accumulators and there are neither fp32 slabs nor a row kernel.  k <= 1536.  What decoder calls with more rows
+ * than the small-batch switch run for every projection whose input is n_state wide (csrc/gemm_rows.hip); replaces the same
+ * reference code as wm_gemv_fused (the small-M branch of WeightOnlyQuantMatmulPlugin::enqueue,
+ * weightOnlyQuantMatmulPlugin.cpp:182-197, + the element-wise layers around it).  A row's result does not depend on m or on
+ * the row's position.                                                                                                      */
+int wm_gemm_rows(const wm_gemv_io* io, wm_stream_t stream);
+/* 1 (default, or WM_ROWS_PATH): decoder calls above the small-batch switch use wm_gemm_rows where it applies; 0: the split-K
+ * chain (wm_gemm_skinny + row kernel) for every Linear, as rounds 1-2 did.  Returns the previous value.  The two forms agree
+ * to fp32 summation order.  Captured graphs keep the path they were captured with.                                          */
+int wm_set_rows_path(int enabled);
 /* fp16 LayerNorm rows, fp32 statistics, eps 1e-5 (layernormKernels.cu:62-188). */
 int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta,
                  void* out, int ldo, wm_stream_t stream);

@@ -1,0 +1,187 @@
+"""Round 3: the row-split fused Linear (csrc/gemm_rows.hip, wm_gemm_rows) and the decoder path built on it, on a real MI355X
+through the C ABI.
+
+  * the kernel, mode by mode, against fp32 restatements with the reference's rounding points (the Linear's fp16 output,
+    then the element-wise op in fp32, rounded: quantization/layer.py:311-312, functional.py:2044-2056, whisper/model.py:61-122)
+    and its LayerNorm prologue against torch's fp32 LayerNorm (W/torch_model.py:25-27) -- the tolerances of
+    test_gemv_fused_small_batch_path, the same contract;
+  * a row's result does not depend on the number of rows in the launch nor on the row's position (bit for bit);
+  * the decoder on the row-split path against the split-K chain of rounds 1-2 (same calls, teacher-forced): logits far inside
+    the parity tolerance, greedy ids equal; every other engine-vs-oracle test of the suite runs on the row-split path too (it is
+    the default above the small-batch switch).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import native  # noqa: E402
+import synthetic  # noqa: E402
+import weight as W  # noqa: E402
+from decoding import WhisperDecoding  # noqa: E402
+from encoding import WhisperEncoding  # noqa: E402
+from oracle.whisper_oracle import Dims, symmetric_quantize_int4, symmetric_quantize_int8, synthetic_mel  # noqa: E402
+from test_gpu_model import LOGIT_TOL_INT8_KV, build_engine  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return native.load_library()
+
+
+@pytest.fixture(scope="module")
+def tmpdir_module(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("engines_rows"))
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda().contiguous()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rng(seed):
+    return np.random.Generator(np.random.Philox(seed))
+
+
+@pytest.mark.parametrize("M,w8,K,N", [(9, 1, 1280, 1280), (16, 0, 1280, 1280), (17, 1, 1280, 3840), (33, 4, 1280, 1280), (192, 1, 1280, 1280),
+                                        (200, 1, 1280, 5120), (192, 0, 1280, 3840), (70, 1, 384, 1152), (40, 1, 128, 384), (576, 1, 1280, 1280),
+                                        (48, 4, 1280, 5120), (100, 0, 512, 512)])
+def test_gemm_rows_kernel(lib, M, w8, K, N):
+    r = rng(9100 + M + w8 + K + N)
+    A = (r.standard_normal((M, K)) * 0.7 + 0.2).astype(np.float16)
+    Wf = (r.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+    bias = (r.standard_normal(N) * 0.1).astype(np.float16)
+    if w8 == 4:
+        q, sc = symmetric_quantize_int4(Wf); tiles = W.tile_linear_int4(q)
+        Wd = q.astype(np.float32) * sc.astype(np.float32)[:, None]
+    elif w8:
+        q, sc = symmetric_quantize_int8(Wf); tiles = W.tile_linear(q)
+        Wd = q.astype(np.float32) * sc.astype(np.float32)[:, None]
+    else:
+        sc, tiles, Wd = None, W.tile_linear(Wf), Wf.astype(np.float32)
+    t_dev, s_dev, a_dev, b_dev = dev(tiles.view(np.uint8)), (dev(sc) if sc is not None else None), dev(A), dev(bias)
+
+    def call(mode, a, m=M, **kw):
+        io = native.WmGemvIO()
+        io.a, io.lda, io.m, io.k = a.data_ptr(), K, m, K
+        io.wt, io.n_blocks, io.w8 = t_dev.data_ptr(), N // 16, w8
+        io.scale = s_dev.data_ptr() if s_dev is not None else None
+        io.mode, io.bias, io.gelu_kind = mode, b_dev.data_ptr(), 1
+        for k_, v in kw.items():
+            setattr(io, k_, v)
+        native.check(lib.wm_gemm_rows(C.byref(io), stream()), "wm_gemm_rows")
+        torch.cuda.synchronize()
+
+    # ---- mode 0: the fp32 sums
+    out32 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    call(0, a_dev, out32=out32.data_ptr(), ld32=N)
+    want = A.astype(np.float32) @ Wd.T
+    scale_ = max(1.0, np.abs(want).max())
+    assert np.abs(out32.cpu().numpy() - want).max() < 2e-5 * scale_ * max(1.0, np.sqrt(K / 1280))
+    # a row's sums do not depend on the launch: the first rows alone, and a row moved to another position
+    few = min(M, 5)
+    solo = torch.zeros((few, N), dtype=torch.float32, device="cuda")
+    call(0, a_dev, m=few, out32=solo.data_ptr(), ld32=N)
+    assert torch.equal(solo, out32[:few])
+    perm = torch.from_numpy(r.permutation(M)).cuda()
+    moved = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    call(0, a_dev[perm].contiguous(), out32=moved.data_ptr(), ld32=N)
+    assert torch.equal(moved, out32[perm])
+    y16 = (out32.cpu().numpy() + bias.astype(np.float32)).astype(np.float16).astype(np.float32)     # the Linear's fp16 output
+
+    # ---- mode 1: bias + erf GELU
+    h = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+    call(1, a_dev, out16=h.data_ptr(), ld16=N, n_valid=N)
+    ref = torch.nn.functional.gelu(torch.from_numpy(y16)).half().float().numpy()
+    assert np.abs(h.float().cpu().numpy() - ref).max() <= 2.0 ** -10 * max(1.0, np.abs(ref).max())
+
+    # ---- mode 2: residual stream in place (rounding points are the reference's: exact)
+    x0 = (r.standard_normal((M, N)) * 1.5).astype(np.float16)
+    x = dev(x0)
+    call(2, a_dev, x=x.data_ptr(), ldx=N)
+    assert np.array_equal(x.cpu().numpy(), (x0.astype(np.float32) + y16).astype(np.float16))
+
+    # ---- LayerNorm of the input rows in the prologue
+    gam = (1 + r.uniform(-0.1, 0.1, K)).astype(np.float16)
+    bet = r.uniform(-0.1, 0.1, K).astype(np.float16)
+    g_dev, be_dev = dev(gam), dev(bet)
+    out_ln = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    call(0, a_dev, out32=out_ln.data_ptr(), ld32=N, ln_gamma=g_dev.data_ptr(), ln_beta=be_dev.data_ptr())
+    xn = torch.nn.functional.layer_norm(torch.from_numpy(A.astype(np.float32)), (K,), torch.from_numpy(gam.astype(np.float32)),
+                                        torch.from_numpy(bet.astype(np.float32)), 1e-5).half()
+    out_pre = torch.zeros((M, N), dtype=torch.float32, device="cuda")             # the same Linear on torch's LayerNorm output
+    call(0, xn.cuda(), out32=out_pre.data_ptr(), ld32=N)
+    want_ln = xn.float().numpy() @ Wd.T
+    assert float((out_pre - out_ln).abs().max()) < 1e-3 * max(1.0, np.abs(want_ln).max())
+    assert np.abs(out_ln.cpu().numpy() - want_ln).max() < 2e-3 * max(1.0, np.abs(want_ln).max())
+    # and the prologue is gemv_small's arithmetic: the small-batch kernel's LayerNorm'ed sums of the same rows agree to fp32
+    # summation order (its waves split K)
+    m_small = min(M, 8)
+    io = native.WmGemvIO()
+    small = torch.zeros((m_small, N), dtype=torch.float32, device="cuda")
+    io.a, io.lda, io.m, io.k = a_dev.data_ptr(), K, m_small, K
+    io.wt, io.n_blocks, io.w8 = t_dev.data_ptr(), N // 16, w8
+    io.scale = s_dev.data_ptr() if s_dev is not None else None
+    io.mode, io.bias, io.gelu_kind = 0, b_dev.data_ptr(), 1
+    io.out32, io.ld32, io.ln_gamma, io.ln_beta = small.data_ptr(), N, g_dev.data_ptr(), be_dev.data_ptr()
+    native.check(lib.wm_gemv_fused(C.byref(io), stream()), "wm_gemv_fused")
+    torch.cuda.synchronize()
+    assert float((small - out_ln[:m_small]).abs().max()) < 2e-5 * max(1.0, np.abs(want_ln).max()) * max(1.0, np.sqrt(K / 1280))
+
+
+def test_gemm_rows_refuses_what_it_cannot_hold(lib):
+    """K above 1536 (the input block would not fit the workgroup's LDS rows) and ragged column blocks are errors."""
+    a = torch.zeros((20, 5120), dtype=torch.float16, device="cuda")
+    w = torch.zeros(80 * 80 * 1024, dtype=torch.uint8, device="cuda")
+    out = torch.zeros((20, 1280), dtype=torch.float32, device="cuda")
+    io = native.WmGemvIO()
+    io.a, io.lda, io.m, io.k = a.data_ptr(), 5120, 20, 5120
+    io.wt, io.n_blocks, io.w8 = w.data_ptr(), 80, 1
+    io.mode, io.out32, io.ld32 = 0, out.data_ptr(), 1280
+    assert lib.wm_gemm_rows(C.byref(io), stream()) != 0 and b"K=5120" in lib.wm_last_error()
+    io.k, io.lda, io.ld32 = 1280, 1280, 1000
+    assert lib.wm_gemm_rows(C.byref(io), stream()) != 0 and b"ld32" in lib.wm_last_error()
+
+
+@pytest.mark.parametrize("batch", [12, 40])
+def test_rows_path_agrees_with_split_k_path(tmpdir_module, lib, batch):
+    """The same teacher-forced decoder calls (prefill of 3 tokens, then single tokens) on the row-split path and on the split-K
+    chain, weight-only int8 + int8 KV: logits agree far inside the parity tolerance (the two forms add a row's K products in
+    another order), greedy ids are equal wherever the margin exceeds it, and on the row-split path a row does not depend on
+    the batch it is in."""
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmpdir_module, "micro-fullvocab", 3, weight_only=True, int8_kv=True, kv_scales=[0.05] * dims.n_text_layer)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(batch, 2 * dims.n_audio_ctx, dims.n_mels, 5).cuda())
+    cross = dec.xa2cross_key_value(xa)
+    feed = [torch.tensor([[50258, 50259, 50359]] * batch).cuda()] + [torch.tensor([[t]] * batch).cuda() for t in (50364, 1200, 900, 31)]
+
+    def run(rows_path, sel=slice(0, batch)):
+        prev = lib.wm_set_rows_path(rows_path)
+        try:
+            outs, past = [], None
+            n = len(range(*sel.indices(batch)))
+            for x in feed:
+                lg, past = dec.decode(x[sel], [c[sel].contiguous() for c in cross], past)
+                outs.append(lg[:, -1].float().clone())
+            assert outs[0].shape[0] == n
+            return torch.stack(outs)
+        finally:
+            lib.wm_set_rows_path(prev)
+
+    a, b = run(1), run(0)
+    assert float((a - b).abs().max()) < 0.25 * LOGIT_TOL_INT8_KV
+    ia, ib = a.argmax(-1), b.argmax(-1)
+    top2 = a.topk(2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    assert bool(((ia == ib) | (margin < 0.5 * LOGIT_TOL_INT8_KV)).all())
+    if batch == 12:                                            # (same key-range split of the cross-attention as 9 rows: DESIGN.md 2)
+        few = run(1, slice(0, 9))                              # 9 rows: still above the small-batch switch
+        assert torch.equal(few, a[:, :9])
