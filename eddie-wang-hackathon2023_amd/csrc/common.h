@@ -92,6 +92,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += wave_dpp<0xB1>(v);             // quad_perm [1,0,3,2] = lane ^ 1
     return v;
 }
+// The same butterfly without the leading wait states, for kernels in which NO matrix instruction of the wave can be in flight at
+// the call: kernels without MFMAs, or reductions that all precede the wave's first MFMA (gemm_rows.hip's LayerNorm prologue:
+// two reductions per row and 8 rows per wave -- the 38 idle cycles per reduction were a sixth of that prologue).  Same values,
+// same order: bit-identical to wave_sum.
+__device__ __forceinline__ float wave_sum_pre_mfma(float v) {
+    int x = __builtin_bit_cast(int, v), y;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
+    v = __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+    x = __builtin_bit_cast(int, v);
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
+    v = __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+    v += wave_dpp<0x128>(v);
+    v += wave_dpp<0x124>(v);
+    v += wave_dpp<0x4E>(v);
+    v += wave_dpp<0xB1>(v);
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
     int x = __builtin_bit_cast(int, v), y;
     wave_swap32(x, y);

@@ -142,9 +142,9 @@ int get_lin(const wm_engine* e, const std::string& base, bool tiled, bool quanti
     Tensor w, s, b;
     if (find(e, base + (tiled ? ".t" : ".w"), &w)) return 1;
     l->w = w.ptr;
-    // row-major (non-tiled) matrices belong to the M >> 16 stages: a weight-only blob's int8 copies of them were
-    // expanded to fp16 while the engine was created (upload_expanding), so only tiled matrices are still quantised
-    const bool q = quantisable && e->w8() && tiled;
+    // row-major (non-tiled) matrices belong to the M >> 16 stages: a weight-only blob's int8 copies of them stay int8 at
+    // rest (round 3) and are expanded per use into the caller's workspace (big())
+    const bool q = quantisable && e->w8();
     const bool packed4 = w.dtype == 4;
     if ((w.dtype == 1 || packed4) != q || (packed4 && !tiled)) {
         set_error("tensor %s: dtype does not match the engine's weight-only flag", base.c_str());
@@ -238,74 +238,24 @@ int resolve(wm_engine* e) {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// Device residency of a blob's tensors.  Decoder engines (tile-linear weights, streamed as stored) and fp16
-// engines: one allocation, one copy.  Weight-only ENCODER / CROSS-K/V engines: their row-major int8 matrices feed
-// MFMA-bound GEMMs (M = 1500 x batch), which multiply fp16(fp16(q) * scale) -- the reference kernels' per-element
-// dequantisation -- so each is expanded ONCE, here, and only the expansion stays resident: the blob is staged in a
-// temporary buffer, every other tensor is copied next to the expansions, the int8 codes and their scales are dropped.
-// (Round 1 kept both copies: a weight-only encoder then held MORE memory than an fp16 one.)
+// Device residency of a blob's tensors: one allocation, one copy, for every engine kind.  Weight-only ENCODER / CROSS-K/V
+// engines keep their row-major int8 matrices and scales as stored (round 3; rounds 1-2 expanded them to fp16 at load, which
+// left a weight-only engine with the memory of an fp16 one: 3.09 -> 2.35 GB where the reference's chart saves 1.7 GB,
+// /root/reference/README.md:178-180).  Their GEMMs are MFMA-bound (M = 1500 x batch) and multiply fp16(fp16(q) * scale) -- the
+// reference kernels' per-element dequantisation (fpA_intB_gemm_template.h:47-140 does it in registers) -- so each matrix is
+// expanded right before its GEMM into a scratch block of the caller's workspace (big(): one pass over 1.6-6.6 MB, ~0.1 % of an
+// encoder pass, the expansion staying in L2 / Infinity Cache for the GEMM behind it): same values, same GEMM, bit-identical.
 int upload(wm_engine* e, const BlobHeader* h, const BlobTensor* tt, const unsigned char* data) {
     auto name_of = [&](uint32_t i) { char nm[65]; memcpy(nm, tt[i].name, 64); nm[64] = 0; return std::string(nm); };
-    const bool expanding = (e->kind == WM_ENGINE_ENCODER || e->kind == WM_ENGINE_CROSS_KV) && (e->flags & WM_FLAG_WEIGHT_ONLY_INT8);
-    if (!expanding) {
-        WM_CHECK_HIP(hipMalloc((void**)&e->dev, h->data_bytes ? h->data_bytes : 256));
-        WM_CHECK_HIP(hipMemcpy(e->dev, data, h->data_bytes, hipMemcpyHostToDevice));
-        e->dev_bytes = h->data_bytes;
-        for (uint32_t i = 0; i < h->n_tensors; ++i) {
-            Tensor t;
-            t.ptr = e->dev + tt[i].offset; t.dtype = tt[i].dtype; t.nbytes = tt[i].nbytes;
-            memcpy(t.shape, tt[i].shape, sizeof(t.shape));
-            e->t[name_of(i)] = t;
-        }
-        return 0;
-    }
-    std::map<std::string, uint32_t> index;
-    for (uint32_t i = 0; i < h->n_tensors; ++i) index[name_of(i)] = i;
-    auto is_code = [&](uint32_t i) { return tt[i].dtype == 1 && tt[i].ndim == 2; };
-    auto scale_of = [&](const std::string& w_name) {          // "x.w" -> index of "x.s", or -1
-        auto it = index.find(w_name.substr(0, w_name.size() - 2) + ".s");
-        return it == index.end() ? -1 : (int)it->second;
-    };
-    std::vector<char> dropped(h->n_tensors, 0);
-    std::vector<size_t> new_off(h->n_tensors, 0);
-    for (uint32_t i = 0; i < h->n_tensors; ++i)
-        if (is_code(i)) {
-            const std::string nm = name_of(i);
-            const int si = nm.size() > 2 && nm.compare(nm.size() - 2, 2, ".w") == 0 ? scale_of(nm) : -1;
-            WM_REQUIRE(si >= 0, "weight-only tensor %s has no scales", nm.c_str());
-            dropped[si] = 1;
-        }
-    size_t total = 0;
+    WM_CHECK_HIP(hipMalloc((void**)&e->dev, h->data_bytes ? h->data_bytes : 256));
+    WM_CHECK_HIP(hipMemcpy(e->dev, data, h->data_bytes, hipMemcpyHostToDevice));
+    e->dev_bytes = h->data_bytes;
     for (uint32_t i = 0; i < h->n_tensors; ++i) {
-        if (dropped[i]) continue;
-        new_off[i] = total;
-        total = align_up(total + (is_code(i) ? tt[i].nbytes * sizeof(h16) : tt[i].nbytes));
-    }
-    unsigned char* stage = nullptr;
-    WM_CHECK_HIP(hipMalloc((void**)&e->dev, total ? total : 256));
-    hipError_t err = hipMalloc((void**)&stage, h->data_bytes ? h->data_bytes : 256);
-    if (err == hipSuccess) err = hipMemcpy(stage, data, h->data_bytes, hipMemcpyHostToDevice);
-    int rc = 0;
-    for (uint32_t i = 0; i < h->n_tensors && err == hipSuccess && rc == 0; ++i) {
-        if (dropped[i]) continue;
         Tensor t;
-        t.ptr = e->dev + new_off[i]; t.dtype = tt[i].dtype; t.nbytes = tt[i].nbytes;
+        t.ptr = e->dev + tt[i].offset; t.dtype = tt[i].dtype; t.nbytes = tt[i].nbytes;
         memcpy(t.shape, tt[i].shape, sizeof(t.shape));
-        if (is_code(i)) {
-            const int si = scale_of(name_of(i));
-            rc = launch_dequant_w8((const int8_t*)(stage + tt[i].offset), (const h16*)(stage + tt[si].offset), (h16*)(e->dev + new_off[i]),
-                                   (int)tt[i].shape[0], (int)tt[i].shape[1], 0);
-            t.dtype = 0; t.nbytes = tt[i].nbytes * sizeof(h16);
-        } else {
-            err = hipMemcpy(e->dev + new_off[i], stage + tt[i].offset, tt[i].nbytes, hipMemcpyDeviceToDevice);
-        }
         e->t[name_of(i)] = t;
     }
-    if (err == hipSuccess && rc == 0) err = hipDeviceSynchronize();
-    if (stage) (void)hipFree(stage);
-    if (rc) return rc;
-    WM_CHECK_HIP(err);
-    e->dev_bytes = total;
     return 0;
 }
 
@@ -320,7 +270,7 @@ struct Carver {            // bump allocator over the caller's workspace
 };
 
 // ---- encoder -------------------------------------------------------------------------------------
-struct EncWs { h16 *melT, *c1, *x, *xn, *qkv, *ctx, *hid; size_t total; };
+struct EncWs { h16 *melT, *c1, *x, *xn, *qkv, *ctx, *hid, *wq; size_t total; };
 EncWs carve_encoder(const wm_engine* e, int B, void* ws) {
     const wm_dims& d = e->dims;
     const size_t T = d.n_audio_ctx, Tin = 2 * T, C = d.n_audio_state;
@@ -333,20 +283,26 @@ EncWs carve_encoder(const wm_engine* e, int B, void* ws) {
     w.qkv = c.take<h16>(B * T * 3 * C);
     w.ctx = c.take<h16>(B * T * C);
     w.hid = c.take<h16>(B * T * 4 * C);
+    w.wq = e->w8() ? c.take<h16>(4 * C * C) : nullptr;        // fp16 expansion of the int8 matrix in use (the widest: 4C x C)
     w.total = align_up(c.off);
     return w;
 }
 
 int big(const Lin& l, const wm_engine* e, const h16* A, int lda, int M, h16* Cout, int ldc, int act,
-        const h16* residual, int ldr, hipStream_t s, GemmBigParams* custom = nullptr, int max_wgs = 0) {
+        const h16* residual, int ldr, hipStream_t s, GemmBigParams* custom = nullptr, int max_wgs = 0, h16* wq = nullptr) {
     GemmBigParams p{};
     if (custom) p = *custom;
-    WM_REQUIRE(l.s == nullptr, "big GEMM: int8 weights must have been expanded at engine creation");
-    p.A = A; p.lda = lda; p.M = M; p.K = l.K; p.W = l.w; p.N = l.N;
+    const void* W = l.w;
+    if (l.s) {             // int8 at rest: fp16(fp16(q) * scale) into the scratch block, then the fp16 MFMA GEMM
+        WM_REQUIRE(wq, "big GEMM: int8 weights need a scratch block for their expansion");
+        if (launch_dequant_w8((const int8_t*)l.w, l.s, wq, l.N, l.K, s)) return 2;
+        W = wq;
+    }
+    p.A = A; p.lda = lda; p.M = M; p.K = l.K; p.W = W; p.N = l.N;
     p.bias = l.b; p.C = Cout; p.ldc = ldc; p.act = act;
     if (!custom) { p.residual = residual; p.ldr = ldr; }
     p.max_wgs = max_wgs;
-    return launch_gemm_f16(p, s);        // int8 [N][K] weights were expanded at engine creation (expand_lin)
+    return launch_gemm_f16(p, s);
 }
 
 }  // namespace
@@ -460,26 +416,33 @@ int wm_encoder_forward_shared(const wm_engine* e, const void* mel, int B, void* 
         {
             GemmBigParams p{};
             p.colscale_n = 2 * C; p.colscale = qk_scale;
-            if (big(L.qkv, e, w.xn, C, M, w.qkv, 3 * C, 0, nullptr, 0, s, &p, cu_budget)) return 2;
+            if (big(L.qkv, e, w.xn, C, M, w.qkv, 3 * C, 0, nullptr, 0, s, &p, cu_budget, w.wq)) return 2;
         }
         AttnEncParams ap{w.qkv, 3 * C, B, T, H, w.ctx, C, 2 * cu_budget};      // two workgroups fill a CU's registers
         if (launch_attn_encoder(ap, s)) return 2;
-        if (big(L.out, e, w.ctx, C, M, w.x, C, 0, w.x, C, s, nullptr, cu_budget)) return 2;
+        if (big(L.out, e, w.ctx, C, M, w.x, C, 0, w.x, C, s, nullptr, cu_budget, w.wq)) return 2;
         if (launch_layernorm(w.x, C, M, C, L.ln2g, L.ln2b, w.xn, C, s)) return 2;
-        if (big(L.mlp1, e, w.xn, C, M, w.hid, 4 * C, e->gelu(), nullptr, 0, s, nullptr, cu_budget)) return 2;
-        if (big(L.mlp2, e, w.hid, 4 * C, M, w.x, C, 0, w.x, C, s, nullptr, cu_budget)) return 2;
+        if (big(L.mlp1, e, w.xn, C, M, w.hid, 4 * C, e->gelu(), nullptr, 0, s, nullptr, cu_budget, w.wq)) return 2;
+        if (big(L.mlp2, e, w.hid, 4 * C, M, w.x, C, 0, w.x, C, s, nullptr, cu_budget, w.wq)) return 2;
     }
     if (launch_layernorm(w.x, C, M, C, e->lnpg, e->lnpb, (h16*)out, C, s)) return 2;
     return 0;
 }
 
 // ================================================================================================ cross K/V
-size_t wm_cross_kv_workspace_bytes(const wm_engine* e, int batch) { (void)e; (void)batch; return 256; }
+size_t wm_cross_kv_workspace_bytes(const wm_engine* e, int batch) {
+    (void)batch;
+    if (!e || e->kind != WM_ENGINE_CROSS_KV) return 0;
+    size_t widest = 0;                                       // fp16 expansion of one layer's int8 [2C][C] matrix
+    for (const Lin& l : e->ckv) if (l.s) widest = widest > (size_t)l.N * l.K ? widest : (size_t)l.N * l.K;
+    return align_up(256 + widest * sizeof(h16));
+}
 
 int wm_cross_kv(const wm_engine* e, const void* xa, int B, void* const* out_layers, void* workspace,
                 size_t workspace_bytes, wm_stream_t stream_) {
-    (void)workspace; (void)workspace_bytes;
     WM_REQUIRE(e && e->kind == WM_ENGINE_CROSS_KV, "wm_cross_kv: not a cross-attention K/V engine");
+    WM_REQUIRE(workspace_bytes >= wm_cross_kv_workspace_bytes(e, B) && (workspace || !e->w8()), "wm_cross_kv: workspace too small: %zu < %zu",
+               workspace_bytes, wm_cross_kv_workspace_bytes(e, B));
     WM_REQUIRE(xa && out_layers && B >= 1, "wm_cross_kv: null argument or empty batch");
     hipStream_t s = (hipStream_t)stream_;
     const wm_dims& d = e->dims;
@@ -489,7 +452,7 @@ int wm_cross_kv(const wm_engine* e, const void* xa, int B, void* const* out_laye
         GemmBigParams p{};
         p.out_mode = 1; p.hs_T = T; p.hs_H = H; p.hs_kv = -1;
         if (e->i8cross()) p.q8_inv_scale = 1.0f / e->ckv_scale[i];     // out_layers[i] is int8 [B,2,H,T,64]
-        if (big(e->ckv[i], e, (const h16*)xa, C, B * T, (h16*)out_layers[i], 0, 0, nullptr, 0, s, &p)) return 2;
+        if (big(e->ckv[i], e, (const h16*)xa, C, B * T, (h16*)out_layers[i], 0, 0, nullptr, 0, s, &p, 0, (h16*)workspace)) return 2;
     }
     return 0;
 }
@@ -616,16 +579,22 @@ int small_path_max_rows() {               // WM_SMALL_PATH=<rows> / wm_set_small
     return r;
 }
 
-// Groups of more rows than that take the row-split form of the same fused Linears (gemm_rows.hip) for every projection whose
-// input is n_state wide: 10 launches per layer instead of 12, fp32 slabs only behind the MLP's second Linear.  WM_ROWS_PATH=0 /
-// wm_set_rows_path(0): the split-K chain (gemm_skinny + row kernel) for every Linear, as in rounds 1-2.
-std::atomic<int> g_rows_path{-1};
-int rows_path_enabled() {
-    int r = g_rows_path.load(std::memory_order_relaxed);
+// Groups of at least rows_path_min_rows() rows (above the small-batch switch) take the row-split form of the same fused Linears
+// (gemm_rows.hip) for every projection whose input is n_state wide: 10 launches per layer instead of 12, fp32 slabs only
+// behind the MLP's second Linear.  Default 40 rows (WM_ROWS_MIN; WM_ROWS_PATH=0 or wm_set_rows_path(0): never -- the split-K
+// chain, gemm_skinny + row kernel, for every Linear as in rounds 1-2).  Measured per token step, large-v2 int8, split-K chain vs
+// row-split form (profiles/r3k_batch_sweep.txt): 12 rows 2.81 / 2.99 ms, 2 x 16 rows 3.55 / 3.69, 2 x 32 rows 4.69 / 5.09,
+// 3 x 43 rows 7.42 / 7.21, 3 x 192 rows 25.2 / 23.4 -- below ~40 rows a group's step is a chain of latencies and the split-K
+// GEMM + row kernel pair (two short launches on 40-160 workgroups) is the quicker link; above, the hand-overs' bytes decide.
+std::atomic<int> g_rows_min{-1};          // -1: not yet read from the environment; 0: never
+int rows_path_min_rows() {
+    int r = g_rows_min.load(std::memory_order_relaxed);
     if (r < 0) {
-        const char* v = getenv("WM_ROWS_PATH");
-        r = v ? (atoi(v) != 0) : 1;
-        g_rows_path.store(r, std::memory_order_relaxed);
+        const char* on = getenv("WM_ROWS_PATH");
+        const char* v = getenv("WM_ROWS_MIN");
+        r = (on && atoi(on) == 0) ? 0 : (v ? atoi(v) : 40);
+        if (r < 0) r = 0;
+        g_rows_min.store(r, std::memory_order_relaxed);
     }
     return r;
 }
@@ -677,7 +646,7 @@ struct GroupStep {
         w = carve_decoder(e, B, L, io->workspace);
         WM_REQUIRE(io->workspace_bytes >= w.total, "decoder workspace too small: %zu < %zu", io->workspace_bytes, w.total);
         small = M <= small_path_max_rows();
-        rows = !small && rows_path_enabled() && !e->dec.empty() && gemm_rows_supports(C, e->dec[0].qkv.wcode);
+        rows = !small && rows_path_min_rows() > 0 && M >= rows_path_min_rows() && !e->dec.empty() && gemm_rows_supports(C, e->dec[0].qkv.wcode);
         return 0;
     }
 
@@ -695,7 +664,7 @@ struct GroupStep {
         EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
                        (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev};
         if (launch_embed(ep, s)) return 2;
-        if (fused()) return 0;                       // the first LayerNorm happens inside the qkv projection
+        if (small) return 0;                         // the first LayerNorm happens inside the qkv projection
         return launch_layernorm(w.x, C, M, C, e->dec[0].ln1g, e->dec[0].ln1b, w.xn, C, s);
     }
 
@@ -704,8 +673,11 @@ struct GroupStep {
         const DecLayer& Lr = e->dec[i];
         int ks = 0;
         mark(i, 0, s);
-        if (fused()) {
+        if (small) {
             if (gemv(Lr.qkv, w.x, C, 0, Lr.ln1g, Lr.ln1b, nullptr, 0, s)) return 2;      // LN + qkv sums -> w.part [M][3C]
+            ks = 1;
+        } else if (rows) {     // xn = LayerNorm(x) came with the row kernel that closed the previous layer (or from begin())
+            if (gemv(Lr.qkv, w.xn, C, 0, nullptr, nullptr, nullptr, 0, s)) return 2;
             ks = 1;
         } else if (skinny_all(Lr.qkv, w.xn, C, M, w.part, &ks, s)) return 2;
         mark(i, 1, s);
@@ -779,11 +751,13 @@ struct GroupStep {
             if (gemv(Lr.mlp1, w.x, C, 1, Lr.ln2g, Lr.ln2b, w.hid, 4 * C, s)) return 2;     // LN + GELU
             mark(i, 10, s);
             if (small) return gemv(Lr.mlp2, w.hid, 4 * C, 2, nullptr, nullptr, nullptr, 0, s);
-            // K = 4 n_state: the hidden rows of a 32-row block do not fit one workgroup's LDS -- K slices over workgroups, the
-            // row kernel adds them to the residual stream (no LayerNorm there: the next projection normalises its own input)
+            // K = 4 n_state: the hidden rows of a 32-row block do not fit one workgroup's LDS -- K slices over workgroups (and row
+            // splits), the row kernel adds them to the residual stream and applies the next layer's first LayerNorm, whose
+            // output 60-80 column groups of the qkv projection would otherwise each recompute
             if (skinny_all(Lr.mlp2, w.hid, 4 * C, M, w.part, &ks, s)) return 2;
             mark(i, 11, s);
-            const int rc = finish(Lr.mlp2, ks, 3, nullptr, nullptr, nullptr, 0, C, s);
+            const bool last_ = (i + 1 == d.n_text_layer);
+            const int rc = finish(Lr.mlp2, ks, 0, last_ ? e->lnfg : e->dec[i + 1].ln1g, last_ ? e->lnfb : e->dec[i + 1].ln1b, w.xn, C, C, s);
             mark(i, 12, s);
             return rc;
         }
@@ -814,7 +788,6 @@ struct GroupStep {
             p.mode = 3; p.out16 = (h16*)io->logits; p.ld16 = d.n_vocab; p.n_valid = d.n_vocab;
             return launch_gemv_small(p, s);
         }
-        if (rows && launch_layernorm(w.x, C, M, C, e->lnfg, e->lnfb, w.xn, C, s)) return 2;
         for (int r0 = 0; r0 < M; r0 += SKINNY_MAX_M) {
             GemmSkinnyParams p{};
             p.A = w.xn + (size_t)r0 * C; p.lda = C; p.M = (M - r0) < SKINNY_MAX_M ? (M - r0) : SKINNY_MAX_M; p.K = C;
@@ -1021,9 +994,9 @@ int wm_gemm_skinny(const void* A, int lda, int M, int K, const void* Wt, int n_b
 }
 int wm_gemm_skinny_default_ksplit(int M, int K, int n_blocks, int w8) { return skinny_default_ksplit(M, K, n_blocks, w8); }
 
-int wm_set_rows_path(int enabled) {
-    const int prev = rows_path_enabled();
-    g_rows_path.store(enabled ? 1 : 0, std::memory_order_relaxed);
+int wm_set_rows_path(int min_rows) {
+    const int prev = rows_path_min_rows();
+    g_rows_min.store(min_rows < 0 ? 0 : min_rows, std::memory_order_relaxed);
     return prev;
 }
 

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     // for: profiles/r3g_pmc_stage_b192_pass2.txt).  Instead the band's full tile rows are taken R at a time (R row panels =
     // <= 2.75 MB stay in L2), channel tile by channel tile: the weights stream past R panels at once -- 1 / R of the traffic.
     // Head and tail of the band (partial tile rows) keep the plain order.  Same tiles, same arithmetic; only the order changes.
-    const int R = max(1, min(8, (int)((2816u << 10) / ((unsigned)p.K * BM * 2u))));
+    const int R = p.tile_rows > 0 ? p.tile_rows : max(1, min(8, (int)((2816u << 10) / ((unsigned)p.K * BM * 2u))));
     const int row_first = (lo + nt_n - 1) / nt_n, row_last = hi / nt_n;              // full tile rows [row_first, row_last)
     const int q_head = min(hi, row_first * nt_n) - lo, q_mid = max(0, row_last - row_first) * nt_n;
     auto tile_of = [&](int q, int& tm, int& tn) {     // q-th tile of the band -> (row panel, channel tile)
@@ -389,7 +389,10 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
     if (grid > need) grid = need;
     const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f;
-    hipLaunchKernelGGL(kerns[p.act + (simple ? 3 : 0)], dim3(grid), dim3(512), LDS_BYTES, stream, p);
+    static const int lab_rows = [] { const char* v = getenv("WM_GEMM_TILE_ROWS"); return v ? atoi(v) : 0; }();    // A/B runs: 1 = the plain row-major tile order
+    GemmBigParams q = p;
+    if (q.tile_rows <= 0) q.tile_rows = lab_rows;
+    hipLaunchKernelGGL(kerns[p.act + (simple ? 3 : 0)], dim3(grid), dim3(512), LDS_BYTES, stream, q);
     WM_LAUNCH_CHECK(stream, "gemm_f16p");
     return 0;
 }

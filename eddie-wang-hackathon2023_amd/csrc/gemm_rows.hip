@@ -30,6 +30,8 @@
 // do not depend on the launch shape.  (They are not the split-K path's sums bit for bit -- that path adds 2-4 partial sums.)
 // K is limited by the LDS block (16 * MT * K * 2 bytes <= 160 KB): the projections that read the residual stream or the
 // attention output (K = n_state); the MLP's second Linear (K = 4 n_state) stays on gemm_skinny.hip + the row kernel.
+#include <stdlib.h>
+
 #include <atomic>
 #include <type_traits>
 
@@ -40,13 +42,15 @@
 namespace wm {
 
 namespace rows {
-constexpr int NW = 4;                   // waves per workgroup = 16-channel blocks per workgroup
 constexpr int RING = 10;                // weight tiles (1 KiB per wave) in flight per wave
 constexpr int XP = 3;                   // 16-byte pieces of a row per lane (K <= 1536)
 }  // namespace rows
 
-template <int WB, int MT, bool LN>      // WB: weight bits (16, 8, 4); MT: 16-row MFMA tiles per workgroup; LN: LayerNorm of the input rows
-__global__ __launch_bounds__(256) void gemm_rows_kernel(GemvSmallParams p, int n_cg, int n_ms) {
+// WB: weight bits (16, 8, 4); MT: 16-row MFMA tiles per workgroup; LN: LayerNorm of the input rows; NW: waves per workgroup = 16-channel
+// blocks per workgroup (4, or 8 for wide outputs: half the workgroups -- one round over the chip at N = 5120 -- and half as many
+// copies of the input block and of its LayerNorm, which every channel group redoes)
+template <int WB, int MT, bool LN, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemvSmallParams p, int n_cg, int n_ms) {
     using namespace rows;
     constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);   // inputs per 1 KiB weight tile
     constexpr int NM = KT / 32;                               // MFMAs (32-deep) per tile
@@ -108,43 +112,76 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemvSmallParams p, int n
     // ---- LayerNorm of the wave's rows, in place in LDS (W/torch_model.py:25-27: fp32 two-pass statistics over the fp16 row,
     // eps 1e-5, affine, rounded to fp16 -- gemv_small.hip's arithmetic, statement for statement) --------------------------------
     if constexpr (LN) {
+        // two rows per trip: their dependent chains (the element-order sums, the reductions) interleave; a row is converted to
+        // fp32 once and stays in registers for the three passes; gamma / beta are read and converted once per pair of rows
+        static_assert(RB % 2 == 0, "rows per wave must be even");
+        const float fK = (float)p.K;
 #pragma unroll 1
-        for (int jr = 0; jr < RB; ++jr) {
-            unsigned char* xr = s_x + (wid + jr * NW) * row_bytes;
-            half8v x[XP];
+        for (int jr = 0; jr < RB; jr += 2) {
+            unsigned char* xr[2] = {s_x + (wid + jr * NW) * row_bytes, s_x + (wid + (jr + 1) * NW) * row_bytes};
+            float xf[2][XP][8];
 #pragma unroll
-            for (int u = 0; u < XP; ++u) x[u] = *(const half8v*)(xr + (min(lane + 64 * u, 64 * np - 1) << 4));
-            float sum = 0.f;
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int u = 0; u < XP; ++u) {
-                if (lane + 64 * u < pieces_per_row) {
+                for (int u = 0; u < XP; ++u) {
+                    const half8v x = *(const half8v*)(xr[q] + (min(lane + 64 * u, 64 * np - 1) << 4));
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sum += (float)x[u][e];
+                    for (int e = 0; e < 8; ++e) xf[q][u][e] = (float)x[e];
                 }
-            }
-            const float mean = wave_sum(sum) / (float)p.K;
-            float sq = 0.f;
+            float mean[2], rstd[2];
 #pragma unroll
-            for (int u = 0; u < XP; ++u) {
-                if (lane + 64 * u < pieces_per_row) {
+            for (int q = 0; q < 2; ++q) {
+                float sum = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = (float)x[u][e] - mean; sq += d * d; }
+                for (int u = 0; u < XP; ++u) {
+                    if (lane + 64 * u < pieces_per_row) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum += xf[q][u][e];
+                    }
                 }
+                mean[q] = wave_sum_pre_mfma(sum) / fK;
             }
-            const float rstd = rsqrtf(wave_sum(sq) / (float)p.K + 1e-5f);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float sq = 0.f;
+#pragma unroll
+                for (int u = 0; u < XP; ++u) {
+                    if (lane + 64 * u < pieces_per_row) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = xf[q][u][e] - mean[q]; sq += d * d; }
+                    }
+                }
+                rstd[q] = rsqrtf(wave_sum_pre_mfma(sq) / fK + 1e-5f);
+            }
 #pragma unroll
             for (int u = 0; u < XP; ++u) {
                 const int cu = min(lane + 64 * u, 64 * np - 1) << 4;
                 const half8v gm = *(const half8v*)(s_g + cu), bt = *(const half8v*)(s_g + np * 1024 + cu);
-                half8v y;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (h16)(((float)x[u][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
-                if (lane + 64 * u < pieces_per_row) *(half8v*)(xr + ((lane + 64 * u) << 4)) = y;
+                for (int q = 0; q < 2; ++q) {
+                    half8v y;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = (h16)((xf[q][u][e] - mean[q]) * rstd[q] * (float)gm[e] + (float)bt[e]);
+                    if (lane + 64 * u < pieces_per_row) *(half8v*)(xr[q] + ((lane + 64 * u) << 4)) = y;
+                }
             }
         }
     }
     __syncthreads();
     if (!wave_active) return;
+
+    // mode 2 adds into the residual stream: this lane's 4 x MT values of x are requested HERE, before the K loop, so that the
+    // epilogue is stores only (next to the other groups' streams a dependent read-modify-write round trip at the end of every
+    // out / cout projection cost more than its K loop).  The loads are unconditional -- a run-time branch around a load makes
+    // hipcc wait for each one -- other modes read a few bytes of the input block instead and drop them.
+    const bool add_x = p.mode == 2;
+    const h16* xsrc = add_x ? p.x + (nb * 16 + rl) : p.A + (lane & 7);
+    const int xld = add_x ? p.ldx : 0;
+    h16 xres[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xres[mt][r] = xsrc[(size_t)min(row0 + mt * 16 + g * 4 + r, p.M - 1) * xld];
 
     // ---- K loop: RING tiles per round, every index a compile-time constant (register arrays indexed at run time live
     // in scratch memory); a tile's slot is refilled as soon as its MFMAs are issued ----------------------------------------
@@ -210,12 +247,21 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemvSmallParams p, int n
     const int col = nb * 16 + rl;
     const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
     FusedEpilogue ep{p.mode, p.bias, p.gelu_kind, p.out32, p.ld32, p.out16, p.ld16, p.n_valid, p.x, p.ldx};
+    const float bias2 = add_x && p.bias ? (float)p.bias[col] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         float y[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[r] = acc[mt][r] * sc;
-        fused_epilogue_tile(ep, p.M, nb, ms * MT + mt, lane, y);
+        if (add_x) {                               // epilogue.h's mode 2 on the prefetched residual values: x = fp16(x + fp16(y + bias))
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + mt * 16 + g * 4 + r;
+                if (row < p.M) p.x[(size_t)row * p.ldx + col] = (h16)r16((float)xres[mt][r] + r16(y[r] + bias2));
+            }
+        } else {
+            fused_epilogue_tile(ep, p.M, nb, ms * MT + mt, lane, y);
+        }
     }
 }
 
@@ -240,16 +286,20 @@ int launch_gemm_rows(const GemvSmallParams& p, hipStream_t stream) {
     WM_REQUIRE(p.mode != 0 || p.ld32 >= n_full, "gemm_rows: ld32=%d < 16 * n_blocks = %d", p.ld32, n_full);
     WM_REQUIRE(p.mode != 1 || p.ld16 >= n_full, "gemm_rows: ld16=%d < 16 * n_blocks = %d", p.ld16, n_full);
     WM_REQUIRE(p.mode != 2 || p.ldx >= n_full, "gemm_rows: ldx=%d < 16 * n_blocks = %d", p.ldx, n_full);
-    // rows per workgroup: 32 (two MFMA row tiles) from 17 rows on; the choice does not touch a row's arithmetic
-    const int MT = p.M > 16 ? 2 : 1;
+    // rows per workgroup: 32 (two MFMA row tiles) from 17 rows on; 8 waves (128 channels) per workgroup from 2560 channels on:
+    // choices by the shapes only, and none of them touches a row's arithmetic
+    static const int lab_mt = [] { const char* v = getenv("WM_ROWS_MT"); return v ? atoi(v) : 0; }();      // A/B runs: 1 | 2
+    static const int lab_nw = [] { const char* v = getenv("WM_ROWS_NW"); return v ? atoi(v) : 0; }();      // A/B runs: 4 | 8
+    const int MT = lab_mt == 1 ? 1 : (p.M > 16 ? 2 : 1);
+    const int NW = lab_nw == 4 || lab_nw == 8 ? lab_nw : (p.n_blocks >= 160 ? 8 : 4);
     const int n_ms = (p.M + 16 * MT - 1) / (16 * MT), n_cg = (p.n_blocks + NW - 1) / NW;
     const int np = ((p.K >> 3) + 63) >> 6;
     const size_t lds = (size_t)16 * MT * (np * 1024 + 16) + (p.ln_g ? 2 * np * 1024 : 0);
     using Kern = void (*)(GemvSmallParams, int, int);
-    static const Kern kerns[3][2][2] = {
-        {{gemm_rows_kernel<16, 1, false>, gemm_rows_kernel<16, 1, true>}, {gemm_rows_kernel<16, 2, false>, gemm_rows_kernel<16, 2, true>}},
-        {{gemm_rows_kernel<8, 1, false>, gemm_rows_kernel<8, 1, true>}, {gemm_rows_kernel<8, 2, false>, gemm_rows_kernel<8, 2, true>}},
-        {{gemm_rows_kernel<4, 1, false>, gemm_rows_kernel<4, 1, true>}, {gemm_rows_kernel<4, 2, false>, gemm_rows_kernel<4, 2, true>}}};
+#define WM_ROWS_KERNS(WB) {{{gemm_rows_kernel<WB, 1, false, 4>, gemm_rows_kernel<WB, 1, false, 8>}, {gemm_rows_kernel<WB, 1, true, 4>, gemm_rows_kernel<WB, 1, true, 8>}}, \
+                           {{gemm_rows_kernel<WB, 2, false, 4>, gemm_rows_kernel<WB, 2, false, 8>}, {gemm_rows_kernel<WB, 2, true, 4>, gemm_rows_kernel<WB, 2, true, 8>}}}
+    static const Kern kerns[3][2][2][2] = {WM_ROWS_KERNS(16), WM_ROWS_KERNS(8), WM_ROWS_KERNS(4)};      // [weights][MT - 1][LN][NW == 8]
+#undef WM_ROWS_KERNS
     // the dynamic-LDS limit is an attribute of the function ON A DEVICE (one process may drive several GPUs)
     static std::atomic<bool> attr_set[64];
     int dev = 0;
@@ -259,11 +309,12 @@ int launch_gemm_rows(const GemvSmallParams& p, hipStream_t stream) {
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 2; ++b)
                 for (int c = 0; c < 2; ++c)
-                    WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[a][b][c], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    for (int d = 0; d < 2; ++d)
+                        WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[a][b][c][d], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[slot].store(true, std::memory_order_release);
     }
     const int grid = 8 * ((n_cg + 7) / 8) * n_ms;
-    const Kern k = kerns[p.w8 == 4 ? 2 : (p.w8 ? 1 : 0)][MT - 1][p.ln_g ? 1 : 0];
+    const Kern k = kerns[p.w8 == 4 ? 2 : (p.w8 ? 1 : 0)][MT - 1][p.ln_g ? 1 : 0][NW == 8 ? 1 : 0];
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), lds, stream, p, n_cg, n_ms);
     WM_LAUNCH_CHECK(stream, "gemm_rows");
     return 0;

@@ -46,6 +46,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
     constexpr int TPC = KC / KT;              // tiles per chunk
     __shared__ __attribute__((aligned(16))) unsigned char sA[MT * 16 * A_ROW];
 
+    // blockIdx.y: row split -- rows [MT * 16 * y, +MT * 16) of the launch (slab mode at many rows: a workgroup then stages a
+    // third of the activation slice; the K = 5120 Linear at 192 rows ran on 40 workgroups that each moved 480 KB of
+    // activations through LDS, 30 us alone and 62 us next to the other groups' streams -- the longest link of the chain).
+    // Rows are independent: the split changes nothing in a row's arithmetic.
+    const int row0 = blockIdx.y * (MT * 16);
+    p.A += (size_t)row0 * p.lda;
+    if (p.part) p.part += (size_t)row0 * (p.n_blocks * 16);
+    if (p.out) p.out += (size_t)row0 * p.ldc;
+    if (p.part_sstride == 0) p.part_sstride = (long)p.M * p.n_blocks * 16;
+    p.M = min(p.M - row0, MT * 16);
+
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nwg_n = (p.n_blocks + NW - 1) / NW;
     const int bn = blockIdx.x % nwg_n, ks = blockIdx.x / nwg_n;
@@ -225,30 +236,38 @@ static int skinny_nw() {
     return nw;
 }
 
+// Row tiles per workgroup above 64 rows in slab mode (WM_SKINNY_MT=4|6|8|12|16 overrides; 16 = rounds 1-2: no row split)
+static int skinny_split_mt() {
+    static const int mt = [] { const char* v = getenv("WM_SKINNY_MT"); const int x = v ? atoi(v) : 4; return (x == 4 || x == 6 || x == 8 || x == 12 || x == 16) ? x : 4; }();
+    return mt;
+}
+
 template <int WB>
 static int launch_mt(const GemmSkinnyParams& p, hipStream_t stream) {
-    const int mt = (p.M + 15) / 16;
-    const int g4 = ((p.n_blocks + 3) / 4) * p.ksplit, g8 = ((p.n_blocks + 7) / 8) * p.ksplit;
+    int mt = (p.M + 15) / 16;
+    int n_ms = 1;
+    if (p.part && !p.out && mt > skinny_split_mt()) { n_ms = (mt + skinny_split_mt() - 1) / skinny_split_mt(); mt = skinny_split_mt(); }
+    const dim3 g4(((p.n_blocks + 3) / 4) * p.ksplit, n_ms), g8(((p.n_blocks + 7) / 8) * p.ksplit, n_ms);
     if (skinny_nw() == 4 && mt >= 3) {
         switch (mt) {
-            case 3: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 3, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-            case 4: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 4, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-            case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 6, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-            case 7: case 8: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 8, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-            case 9: case 10: case 11: case 12: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 12, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-            default: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 16, 4>), dim3(g4), dim3(256), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 3, 4>), g4, dim3(256), 0, stream, p); break;
+            case 4: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 4, 4>), g4, dim3(256), 0, stream, p); break;
+            case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 6, 4>), g4, dim3(256), 0, stream, p); break;
+            case 7: case 8: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 8, 4>), g4, dim3(256), 0, stream, p); break;
+            case 9: case 10: case 11: case 12: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 12, 4>), g4, dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 16, 4>), g4, dim3(256), 0, stream, p); break;
         }
         return 0;
     }
     switch (mt) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 1, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 2, 4>), dim3(g4), dim3(256), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 3, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 4, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 6, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        case 7: case 8: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 8, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        case 9: case 10: case 11: case 12: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 12, 8>), dim3(g8), dim3(512), 0, stream, p); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 16, 8>), dim3(g8), dim3(512), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 1, 4>), g4, dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 2, 4>), g4, dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 3, 8>), g8, dim3(512), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 4, 8>), g8, dim3(512), 0, stream, p); break;
+        case 5: case 6: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 6, 8>), g8, dim3(512), 0, stream, p); break;
+        case 7: case 8: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 8, 8>), g8, dim3(512), 0, stream, p); break;
+        case 9: case 10: case 11: case 12: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 12, 8>), g8, dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<WB, 16, 8>), g8, dim3(512), 0, stream, p); break;
     }
     return 0;
 }

@@ -23,6 +23,7 @@ struct GemmBigParams {
     // > 0: at most this many (persistent, one per CU) workgroups -- the launch then leaves the other CUs to whatever runs
     // beside it (wm_encoder_forward_shared); the tiles and their arithmetic are the same, only who computes them changes
     int max_wgs;
+    int tile_rows;                           // persistent kernel: row panels per step of the tile order (0: chosen from K; 1: plain row-major)
 };
 int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // dispatch: gemm_f16p.hip when it supports the shape, else gemm_f16.hip's kernel
 int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream);     // persistent 256x256 tiles, continuous LDS-DMA stream, alternating wave groups

@@ -193,7 +193,7 @@ def _linear(out: Dict[str, np.ndarray], name: str, w, b, use_weight_only: bool, 
             npad = (n + 15) // 16 * 16
             s = torch.cat([s, torch.zeros(npad - n, dtype=torch.float16, device=s.device)])
             q = _tile_linear_int4_t(q) if bits == 4 else _tile_linear_t(q)     # row-major int4 codes stay one per byte:
-                                                                               # those matrices are expanded to fp16 at load
+                                                                               # those matrices are expanded to fp16 per use (engine.hip: big())
         out[name + (".t" if tiled else ".w")] = q.cpu().numpy()
         out[name + ".s"] = s.cpu().numpy()
     else:

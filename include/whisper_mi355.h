@@ -232,10 +232,11 @@ int wm_set_small_batch_rows(int rows);
  * weightOnlyQuantMatmulPlugin.cpp:182-197, + the element-wise layers around it).  A row's result does not depend on m or on
  * the row's position.                                                                                                      */
 int wm_gemm_rows(const wm_gemv_io* io, wm_stream_t stream);
-/* 1 (default, or WM_ROWS_PATH): decoder calls above the small-batch switch use wm_gemm_rows where it applies; 0: the split-K
- * chain (wm_gemm_skinny + row kernel) for every Linear, as rounds 1-2 did.  Returns the previous value.  The two forms agree
- * to fp32 summation order.  Captured graphs keep the path they were captured with.                                          */
-int wm_set_rows_path(int enabled);
+/* Decoder calls with at least min_rows activation rows (and more than the small-batch switch) use wm_gemm_rows where it
+ * applies; default 40 (WM_ROWS_MIN), 0 (or WM_ROWS_PATH=0) = never: the split-K chain (wm_gemm_skinny + row kernel) for every
+ * Linear, as rounds 1-2 did.  Returns the previous value.  On either side of the switch a row's result does not depend on the
+ * batch it is in; across it the two forms agree to fp32 summation order.  Captured graphs keep the path they were captured with. */
+int wm_set_rows_path(int min_rows);
 /* fp16 LayerNorm rows, fp32 statistics, eps 1e-5 (layernormKernels.cu:62-188). */
 int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta,
                  void* out, int ldo, wm_stream_t stream);

@@ -21,7 +21,7 @@ eng = Path(args.engine_cache) / f"large-v2-{a.config}-seed0"
 if not (eng / "decoder_config.json").exists():
     eng.parent.mkdir(parents=True, exist_ok=True); bench.build_engines(args, eng)
 lib = native.load_library()
-lib.wm_set_rows_path(a.rows_path)
+lib.wm_set_rows_path(40 if a.rows_path else 0)
 enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
 dec.micro_batches = a.groups or None
 d = synthetic.DIMS["large-v2"]

@@ -373,8 +373,10 @@ def one_decode_path():
     in another order, so across the switch rows agree to fp32 summation order, not bit for bit."""
     lib = native.load_library()
     prev = lib.wm_set_small_batch_rows(0)
+    prev_rows = lib.wm_set_rows_path(0)          # likewise the row-split form (from 40 rows on by default): one arithmetic for every size
     yield
     lib.wm_set_small_batch_rows(prev)
+    lib.wm_set_rows_path(prev_rows)
 
 
 def test_small_batch_path_agrees_with_big_batch_path(tmpdir_module):
