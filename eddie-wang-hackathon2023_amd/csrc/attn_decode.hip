@@ -664,7 +664,12 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
     }
     const int n_items = p.H * p.B * p.nsplit;
     // default: at most 2 workgroups per CU, and every workgroup the same number of items (3840 items on 512 workgroups
-    // would be 8 for some and 7 for the rest: the launch ends with half the chip idle; 480 x 8 does not)
+    // would be 8 for some and 7 for the rest: the launch ends with half the chip idle; 480 x 8 does not).
+    // Round 3 re-measured the count with the row-split chain (WM_CROSS_PERSIST_WGS, profiles/r3n_ab_kv_wgs_*.json): 480 / 384 / 320 /
+    // 240 workgroups -> token step 23.5 / 23.8 / 23.8 / 23.2 ms at B = 576, chain between two launches 284 / 249 / 208 / 223 us,
+    // launches 434 / 479 / 516 / 490 us: with fewer workgroups the chains' round trips queue behind fewer requests and the
+    // launches take that much longer -- the sum is what every schedule conserves.  Alone the launch reads 6.6 TB/s with two
+    // workgroups per CU and 5.8 with one (252.9 vs 222.7 us, profiles/r3q_bench_kernel_stats.csv), so two it stays.
     int persist_wgs = 0;
     if (persist_env >= 0) persist_wgs = persist_env;
     else if (n_items >= 4 * n_cu) {

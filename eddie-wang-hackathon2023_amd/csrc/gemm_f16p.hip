@@ -130,8 +130,12 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     auto issue_half = [&](int half) {                // this wave's A piece and W piece number `half` of stream stage `issued`
         if (issued >= total_stages) return;
         unsigned char* slot = smem + (issued % STAGES) * STAGE + (wid + NWAVE * half) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
-                                         (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
+        if (p.nt_flags & 1)        // (wave-uniform) A panels as non-temporal requests: lab knob WM_GEMM_NT, see launch_gemm_f16p
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
+                                             (__attribute__((address_space(3))) void*)slot, 16, 0, 2);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
+                                             (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_lane[half]),
                                          (__attribute__((address_space(3))) void*)(slot + A_PART), 16, 0, 0);
         if (half == 1) {
@@ -297,9 +301,15 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                     if constexpr (SIMPLE) {
                         if (row < p.M) {
                             h16* crow = p.C + (size_t)row * p.ldc + colp;
+                            if (p.nt_flags & 4) {          // (wave-uniform) lab knob: non-temporal stores of C
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                *(half4v*)(crow + j * 16) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
+                                for (int j = 0; j < 4; ++j)
+                                    __builtin_nontemporal_store(half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]}, (half4v*)(crow + j * 16));
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    *(half4v*)(crow + j * 16) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
+                            }
                         }
                     } else if (row < p.M) {
                         if (p.out_mode == 0) {
@@ -390,8 +400,10 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     if (grid > need) grid = need;
     const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f;
     static const int lab_rows = [] { const char* v = getenv("WM_GEMM_TILE_ROWS"); return v ? atoi(v) : 0; }();    // A/B runs: 1 = the plain row-major tile order
+    static const int lab_nt = [] { const char* v = getenv("WM_GEMM_NT"); return v ? atoi(v) : 0; }();             // A/B runs: 1 = A panels nt, 4 = C stores nt, 5 = both
     GemmBigParams q = p;
     if (q.tile_rows <= 0) q.tile_rows = lab_rows;
+    q.nt_flags = lab_nt;
     hipLaunchKernelGGL(kerns[p.act + (simple ? 3 : 0)], dim3(grid), dim3(512), LDS_BYTES, stream, q);
     WM_LAUNCH_CHECK(stream, "gemm_f16p");
     return 0;

@@ -23,6 +23,7 @@ struct GemmBigParams {
     // > 0: at most this many (persistent, one per CU) workgroups -- the launch then leaves the other CUs to whatever runs
     // beside it (wm_encoder_forward_shared); the tiles and their arithmetic are the same, only who computes them changes
     int max_wgs;
+    int nt_flags;                            // lab (WM_GEMM_NT): 1 = A panels by non-temporal DMA, 4 = non-temporal stores of plain row-major C
     int tile_rows;                           // persistent kernel: row panels per step of the tile order (0: chosen from K; 1: plain row-major)
 };
 int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // dispatch: gemm_f16p.hip when it supports the shape, else gemm_f16.hip's kernel

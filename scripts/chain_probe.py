@@ -15,6 +15,7 @@ from encoding import WhisperEncoding
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=576); ap.add_argument("--steps", type=int, default=6); ap.add_argument("--groups", type=int, default=0)
 ap.add_argument("--rows-path", type=int, default=1); ap.add_argument("--config", default="int8")
+ap.add_argument("--beside-encoder", type=int, default=0, help="CUs of an encoder pass of the same batch running beside the loop (bench.py's pipelined steps)")
 a = ap.parse_args()
 args = argparse.Namespace(model="large-v2", config=a.config, seed=0, engine_cache="/tmp/wm_bench_engines")
 eng = Path(args.engine_cache) / f"large-v2-{a.config}-seed0"
@@ -33,7 +34,15 @@ cap = 8 * 16 * n_layer * (a.steps + 4)
 buf = torch.zeros(1 + 3 * cap, dtype=torch.int64, device="cuda")
 native.check(lib.wm_debug_timeline(buf.data_ptr(), cap))
 dec.sample_len = a.steps
-t0 = time.perf_counter(); dec.main_loop(xa, ignore_eot=True); torch.cuda.synchronize()
+if a.beside_encoder:
+    dec.main_loop(xa, ignore_eot=True); torch.cuda.synchronize()      # graph capture synchronises the device: capture first, measure afterwards
+    buf.zero_()
+    enc.prefetch(mel, a.beside_encoder)
+    time.sleep(0.05)
+t0 = time.perf_counter(); dec.main_loop(xa, ignore_eot=True)
+if a.beside_encoder:
+    enc.collect()
+torch.cuda.synchronize()
 native.check(lib.wm_debug_timeline(None, 0))
 n = min(int(buf[0].item()) & 0xffffffff, cap)
 ev = buf[1:1 + 3 * n].view(-1, 3).cpu().numpy()
@@ -52,7 +61,7 @@ for tag in sorted(set(ev[:, 0].tolist())):
         if k1 == 0: continue                       # layer start: the gap to the previous layer's last stamp is the stamp itself
         acc.setdefault(k1, []).append((t1_ - t0_) / 100.0)
 tot = 0.0
-print(f"B={a.batch} groups={len(set(ev[:, 0].tolist()))} rows_path={a.rows_path}: in-situ microseconds per launch (mean over layers, steps, groups; each includes one stamp launch)")
+print(f"B={a.batch} groups={len(set(ev[:, 0].tolist()))} rows_path={a.rows_path} beside_encoder_cus={a.beside_encoder}: in-situ microseconds per launch (mean over layers, steps, groups; each includes one stamp launch)")
 for k in [1, 2, 3, 4, 5, "K0", "K1", 6, 7, 8, 9, 10, 11, 12]:
     if k in acc:
         m = float(np.mean(acc[k])); tot += m
