@@ -11,6 +11,7 @@ for (N, K, act, res) in [(3840, 1280, 0, 0), (1280, 1280, 0, 1), (5120, 1280, 1,
         A = (torch.randint(-1000, 1001, (M, K), device="cuda") / 1000.0).half()
         W = (torch.randint(-1000, 1001, (N, K), device="cuda") / 30000.0).half()
     else:
+        torch.manual_seed(N + K)
         A = (torch.randn(M, K, device="cuda") * 0.5).half()
         W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
     bias = torch.randn(N, device="cuda").half()
@@ -28,4 +29,5 @@ for (N, K, act, res) in [(3840, 1280, 0, 0), (1280, 1280, 0, 1), (5120, 1280, 1,
     for _ in range(REPS): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / REPS
-    print(f"M={M} N={N} K={K} act={act} res={res}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.0f} TFLOP/s", flush=True)
+    chk = int(C.view(torch.int16).to(torch.int64).sum().item())          # output checksum: equal across kernel variants = bit-identical
+    print(f"M={M} N={N} K={K} act={act} res={res}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.0f} TFLOP/s  checksum {chk}", flush=True)

@@ -718,6 +718,25 @@ def test_full_size_large_v2_matches_oracle_on_gpu(tmpdir_module):
     print(f"full size: max|xa - oracle| = {d_xa:.4f}, max|cross K/V| = {d_ckv:.4f}, max|logits| = {worst:.4f}, ids {n_ok}/{n_safe}")
     assert d_xa < 5e-2 and d_ckv < 5e-2 and worst < LOGIT_TOL_INT8_KV, (d_xa, d_ckv, worst)
     assert n_ok == n_safe and n_safe > 0
+    # The same oracle run against the ROW-SPLIT decode path (gemm_rows.hip: what groups of 40 rows and more -- the bench's 192 --
+    # take by default): each clip six times in a batch of 12, the path forced from 9 rows on.  Same tolerance at full depth, and
+    # the six copies of a clip are bit-identical (a row does not see its position).
+    lib = native.load_library()
+    prev = lib.wm_set_rows_path(9)
+    try:
+        idx = torch.arange(2, device="cuda").repeat_interleave(6)
+        cross_r = [c[idx].contiguous() for c in cross]
+        logits_r, kv_r = dec.decode(torch.tensor([prompt] * 2).cuda()[idx], cross_r)
+        worst_r = float((logits_r.float() - ref["logits"][0][idx]).abs().max())
+        assert torch.equal(logits_r[0:6], logits_r[0:1].expand(6, -1, -1)) and torch.equal(logits_r[6:12], logits_r[6:7].expand(6, -1, -1))
+        for s_ in range(n_steps - 1):
+            logits_r, kv_r = dec.decode(ref["ids"][idx, s_:s_ + 1], cross_r, kv_r)
+            worst_r = max(worst_r, float((logits_r[:, 0].float() - ref["logits"][s_ + 1][idx, 0]).abs().max()))
+            assert torch.equal(logits_r[0:6], logits_r[0:1].expand(6, -1, -1))
+    finally:
+        lib.wm_set_rows_path(prev)
+    print(f"full size, row-split path: max|logits - oracle| = {worst_r:.4f}")
+    assert worst_r < LOGIT_TOL_INT8_KV, worst_r
 
 
 def test_full_size_large_v2_properties(tmpdir_module, one_decode_path):
