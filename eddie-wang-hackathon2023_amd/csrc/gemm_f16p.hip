@@ -56,16 +56,11 @@ constexpr int MAX_N = 8192;                                          // the bias
 
 // SIMPLE: plain row-major output and residual (the encoder layers' four GEMMs): the epilogue then carries none of the
 // strided-view / head-split / int8 address arithmetic (integer divisions, their branches) the general form is compiled with.
-// LATE (lab, WM_GEMM_LATE_DMA=1): the two DMA requests of a half are issued in the MIDDLE OF THE MULTIPLY interval instead of the load
-// interval in front of it.  The counters say the matrix pipes are busy half of the time: the load interval of one wave group (fragment
-// reads + two DMA requests at 100-185 cycles each + the stage wait) is about twice as long as the 256 cycles the other group multiplies.
-template <int STAGES, int ACT, bool SIMPLE = false, bool LATE = false>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU
+template <int STAGES, int ACT, bool SIMPLE = false>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU
 __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     using namespace f16p;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    // DMA pieces of this wave that may still be in flight when stage s + 1 must have landed (LATE: this stage's second half is
-    // requested after the wait, two pieces fewer)
-    constexpr int WAIT = 4 * STAGES - 10 - (LATE ? 2 : 0);
+    constexpr int WAIT = 4 * STAGES - 10;            // DMA pieces of this wave that may still be in flight when stage s + 1 must have landed
     constexpr int N_STORES = 32;                     // store instructions of one wave's epilogue (8 pieces x 4)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -193,26 +188,22 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + j * 1024);
-        if constexpr (!LATE) issue_half(1);          // completes stage cons + STAGES - 2
+        issue_half(1);                               // completes stage cons + STAGES - 2
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx[j], af[i], acc[i][j], 0, 0, 0);
-            if constexpr (LATE) {
-                if (i == 1) { __builtin_amdgcn_sched_barrier(0); issue_half(1); __builtin_amdgcn_sched_barrier(0); }
-            }
-        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- second half ------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + (4 + j) * 1024);
-        if constexpr (!LATE) issue_half(0);          // opens stage cons + STAGES - 1
+        issue_half(0);                               // opens stage cons + STAGES - 1
         // Stage cons + 1 is read by waves 0-3 two barriers from here (one for waves 4-7): this wave's pieces of it must have
         // landed before the next barrier.  Its last pieces were requested STAGES - 3 stages ago; WAIT younger requests may stay
         // in flight -- plus, on the first stage after an epilogue, the epilogue's stores, which sit behind those pieces in the
@@ -225,14 +216,10 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx[j], af[i], acc[i][4 + j], 0, 0, 0);
-            if constexpr (LATE) {
-                if (i == 1) { __builtin_amdgcn_sched_barrier(0); issue_half(0); __builtin_amdgcn_sched_barrier(0); }
-            }
-        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -391,16 +378,14 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     const int slot = (dev >= 0 && dev < 64) ? dev : 0;
     int n_cu = n_cu_dev[slot].load(std::memory_order_relaxed);
     using Kern = void (*)(GemmBigParams);
-    static const Kern kerns[12] = {gemm_f16p_kernel<STAGES, 0>, gemm_f16p_kernel<STAGES, 1>, gemm_f16p_kernel<STAGES, 2>,
-                                   gemm_f16p_kernel<STAGES, 0, true>, gemm_f16p_kernel<STAGES, 1, true>, gemm_f16p_kernel<STAGES, 2, true>,
-                                   gemm_f16p_kernel<STAGES, 0, false, true>, gemm_f16p_kernel<STAGES, 1, false, true>, gemm_f16p_kernel<STAGES, 2, false, true>,
-                                   gemm_f16p_kernel<STAGES, 0, true, true>, gemm_f16p_kernel<STAGES, 1, true, true>, gemm_f16p_kernel<STAGES, 2, true, true>};
+    static const Kern kerns[6] = {gemm_f16p_kernel<STAGES, 0>, gemm_f16p_kernel<STAGES, 1>, gemm_f16p_kernel<STAGES, 2>,
+                                  gemm_f16p_kernel<STAGES, 0, true>, gemm_f16p_kernel<STAGES, 1, true>, gemm_f16p_kernel<STAGES, 2, true>};
     constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE + MAX_N * 2;
     if (n_cu == 0) {
         int v = 0;
         WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
         n_cu = v > 0 ? v : 256;
-        for (int a = 0; a < 12; ++a)
+        for (int a = 0; a < 6; ++a)
             WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         n_cu_dev[slot].store(n_cu, std::memory_order_relaxed);
     }
@@ -419,8 +404,7 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     GemmBigParams q = p;
     if (q.tile_rows <= 0) q.tile_rows = lab_rows;
     q.nt_flags = lab_nt;
-    static const int lab_late = [] { const char* v = getenv("WM_GEMM_LATE_DMA"); return v ? atoi(v) : 0; }();
-    hipLaunchKernelGGL(kerns[p.act + (simple ? 3 : 0) + (lab_late ? 6 : 0)], dim3(grid), dim3(512), LDS_BYTES, stream, q);
+    hipLaunchKernelGGL(kerns[p.act + (simple ? 3 : 0)], dim3(grid), dim3(512), LDS_BYTES, stream, q);
     WM_LAUNCH_CHECK(stream, "gemm_f16p");
     return 0;
 }
