@@ -104,8 +104,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemvSmallParams p, i
     }
     const u32x4* wt = (const u32x4*)p.Wt + (size_t)(wave_active ? nb : 0) * kt_total * 64 + lane;
     u32x4 wreg[RING];
+    // (the counted wait below relies on the order: every DMA request, THEN exactly RING weight loads -- pinned for the scheduler;
+    // scripts/check_rows_isa.py verifies it in the generated code of every variant)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < RING; ++i) wreg[i] = wt[(size_t)min(i, kt_total - 1) * 64];
+    __builtin_amdgcn_sched_barrier(0);
     // this wave's rows (and gamma / beta) have landed once at most the weight requests behind them are outstanding
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RING) : "memory");
 

@@ -185,3 +185,42 @@ def test_rows_path_agrees_with_split_k_path(tmpdir_module, lib, batch):
     if batch == 12:                                            # (same key-range split of the cross-attention as 9 rows: DESIGN.md 2)
         few = run(9, slice(0, 9))                              # 9 rows: still above the small-batch switch
         assert torch.equal(few, a[:, :9])
+
+
+def test_gemm_rows_is_stable_next_to_a_memory_stream(lib):
+    """The kernel's LDS hand-overs (DMA'd rows -> in-place LayerNorm -> fragment reads) are ordered by a counted wait and one
+    barrier; a misplaced wait would show as rare wrong rows that come and go with memory load (clean runs on an idle chip prove
+    nothing).  200 launches of the LayerNorm variant next to a device-wide copy stream on another queue, every output compared
+    with the first launch's bit for bit."""
+    r = rng(4242)
+    M, K, N = 192, 1280, 5120
+    A = dev((r.standard_normal((M, K)) * 0.7).astype(np.float16))
+    q, sc = symmetric_quantize_int8((r.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16))
+    t_dev, s_dev = dev(W.tile_linear(q).view(np.uint8)), dev(sc)
+    gam, bet = dev((1 + r.uniform(-0.1, 0.1, K)).astype(np.float16)), dev(r.uniform(-0.1, 0.1, K).astype(np.float16))
+    bias = dev((r.standard_normal(N) * 0.1).astype(np.float16))
+    outs = [torch.zeros((M, N), dtype=torch.float16, device="cuda") for _ in range(2)]
+    io = native.WmGemvIO()
+    io.a, io.lda, io.m, io.k = A.data_ptr(), K, M, K
+    io.wt, io.n_blocks, io.w8, io.scale = t_dev.data_ptr(), N // 16, 1, s_dev.data_ptr()
+    io.mode, io.bias, io.gelu_kind = 1, bias.data_ptr(), 1
+    io.ln_gamma, io.ln_beta, io.ld16, io.n_valid = gam.data_ptr(), bet.data_ptr(), N, N
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    big2 = torch.empty_like(big)
+    side = torch.cuda.Stream()
+    io.out16 = outs[0].data_ptr()
+    native.check(lib.wm_gemm_rows(C.byref(io), stream()))
+    torch.cuda.synchronize()
+    ref = outs[0].clone()
+    assert bool(torch.isfinite(ref.float()).all()) and float(ref.float().abs().max()) > 0.1
+    for it in range(200):
+        if it % 10 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    big2.copy_(big, non_blocking=True)
+        outs[1].zero_()
+        io.out16 = outs[1].data_ptr()
+        native.check(lib.wm_gemm_rows(C.byref(io), stream()))
+        torch.cuda.current_stream().synchronize()
+        assert torch.equal(outs[1], ref), it
+    torch.cuda.synchronize()

@@ -338,3 +338,18 @@ def test_balanced_order_deals_sorted_rows_over_the_groups(tmp_path):
         assert max(means) - min(means) <= n_micro + 2, (n, means)      # (ragged group sizes: the odd row out is the longest)
         for lo, hi in bounds:
             assert order[lo:hi] == sorted(order[lo:hi])            # inside a group the rows stay in sorted order
+
+
+def test_gemm_rows_generated_code_keeps_the_request_order():
+    """csrc/gemm_rows.hip waits for its input rows with a COUNTED `s_waitcnt vmcnt(10)`: correct only while every LDS-DMA request of
+    the prologue precedes the ten weight loads in the generated code.  The order is pinned with sched_barriers in the source;
+    this checks the ISA of all 24 variants (hipcc -S, no GPU)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_rows_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert r.stdout.count("ok ") == 24
