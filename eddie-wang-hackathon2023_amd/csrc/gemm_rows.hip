@@ -14,22 +14,31 @@
 // runs on 40-160 workgroups that each stage a 192-row activation slice, and needs a second launch to finish its rows --
 // twelve launches per layer, each a few dependent memory round trips that cost ~3x their unloaded time next to the other
 // groups' K/V streams.  Here the ROWS are split over workgroups instead of K:
-//   * a workgroup = 16 * MT rows x 64 output channels (4 waves, one 16-channel block each), the whole K per wave: the
-//     sums of a row never leave the accumulators, so the epilogue (bias, GELU, residual add, fp16 rounding points as
-//     epilogue.h) runs in the same launch;
+//   * a workgroup = 16 * MT rows x 64 output channels (4 waves, one 16-channel block each; 8 waves x 16 from 2560
+//     channels on), the whole K per wave: the sums of a row never leave the accumulators, so the epilogue (bias, GELU,
+//     residual add, fp16 rounding points as epilogue.h) runs in the same launch; the residual values of the in-place
+//     mode are requested before the K loop;
 //   * its input rows (16 * MT x K fp16) go global -> LDS by DMA (global_load_lds, 1 KiB per wave instruction, no
 //     registers) into rows of whole KiB + 16 bytes (the MFMA A-fragment reads -- 16 rows x one 16-byte chunk -- are then
 //     conflict-free); with LayerNorm every wave normalises the rows it requested in place (statistics by wave
-//     reductions, the affine step, one LDS write: gemv_small's arithmetic) while its weights are in flight.  The
-//     kernel stays under 128 registers: a 4-wave workgroup then fits on a CU beside four waves per SIMD of the other
-//     groups' K/V streams (4 x 96 + 128 = 512), which an 8-wave split-K workgroup (2 x 136) does not;
+//     reductions, the affine step, one LDS write: gemv_small's arithmetic, two rows per trip) while its weights are in
+//     flight.  The kernel stays under 128 registers: a 4-wave workgroup then fits on a CU beside four waves per SIMD of
+//     the other groups' K/V streams (4 x 96 + 128 = 512), which an 8-wave split-K workgroup (2 x 136) does not.  Every
+//     channel group repeats the LayerNorm of its rows (~300 VALU instructions per row for one wave): the engine uses the
+//     prologue for the projections behind an in-place residual add (cq, mlp1) and feeds qkv the rows the row kernel
+//     behind mlp2 has normalised anyway;
 //   * weights go HBM / L2 -> VGPRs in MFMA B-operand order (one wave-wide 16-byte load = one 1 KiB tile), a ring of
 //     R tiles in flight per wave; the row splits of one channel group are given equal blockIdx % 8, i.e. one XCD under
 //     round-robin placement (speed only), so the group's weights leave HBM once and are re-read from that XCD's L2.
 // A row's sums are one fp32 accumulation chain over K in tile order, whatever the batch or the row split it is in: results
 // do not depend on the launch shape.  (They are not the split-K path's sums bit for bit -- that path adds 2-4 partial sums.)
-// K is limited by the LDS block (16 * MT * K * 2 bytes <= 160 KB): the projections that read the residual stream or the
-// attention output (K = n_state); the MLP's second Linear (K = 4 n_state) stays on gemm_skinny.hip + the row kernel.
+// K <= 1536 (a lane holds three 16-byte pieces of a row; the input block, 16 * MT rows of ceil(K / 512) KiB + 16 bytes, must fit the
+// LDS): the projections that read the residual stream or the attention output (K = n_state); the MLP's second Linear
+// (K = 4 n_state) stays on gemm_skinny.hip (K slices and row splits over workgroups) + the row kernel.
+// Measured (MI355X, large-v2 int8, three groups of 192 rows, in situ per launch, profiles/r3k_chain_rows.log against
+// r3j_chain_splitk.log): out / cout 23-29 us against 35-39 + 22-24 (GEMM + row kernel), cq 30 against 28 (+ the row kernel
+// above), mlp1 66 against 46 + 28, qkv 38 against 41; token step 25.2 -> 23.4-23.7 ms.  Below ~40 rows per group the split-K
+// pair is the quicker link (profiles/r3k_batch_sweep.txt): the engine switches there (engine.hip: rows_path_min_rows).
 #include <stdlib.h>
 
 #include <atomic>
