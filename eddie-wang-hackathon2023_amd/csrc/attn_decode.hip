@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
         k = r16(k + (p.bias ? (float)p.bias[C + h * 64 + lane] : 0.f));
         v = r16(v + (p.bias ? (float)p.bias[2 * C + h * 64 + lane] : 0.f));
         if (p.amax) {     // calibration hook: max |q|,|k|,|v| of this layer (smoothquant.py:117-175, F8)
-            const float a = wave_max(fmaxf(fabsf(q), fmaxf(fabsf(k), fabsf(v))));
+            const float a = wave_max_nomfma(fmaxf(fabsf(q), fmaxf(fabsf(k), fabsf(v))));
             if (lane == 0) atomicMax((unsigned int*)p.amax, __float_as_uint(a));   // a >= 0: bit order = value order
         }
         s_knew[i][lane] = (h16)k;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
             if (j < MAXT) s_p[j] = sc;
             mx = fmaxf(mx, sc);
         }
-        mx = wave_max(mx);
+        mx = wave_max_nomfma(mx);
         float sum = 0.f;
         __syncthreads();
         for (int j = lane; j < nk; j += 64) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
             s_p[j] = e;
             sum += e;
         }
-        sum = wave_sum(sum);
+        sum = wave_sum_nomfma(sum);
         const float inv = 1.0f / sum;
         __syncthreads();
         for (int j = lane; j < nk; j += 64) s_p[j] = r16(s_p[j] * inv);
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     issue(bufA, V, k_begin, nkeys, first);               // first V block: in flight across the softmax
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-        const float m = wave_max(mx[i]);
+        const float m = wave_max_nomfma(mx[i]);
         if (lane == 0) s_red[i][wid][0] = m;
     }
     __syncthreads();
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
             s_sc[i][j] = e;
             s += e;
         }
-        s = wave_sum(s);
+        s = wave_sum_nomfma(s);
         if (lane == 0) s_red[i][wid][1] = s;
     }
     __syncthreads();
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams 
     float ov[CROSS_MAX_SPLIT];                    // (no per-element test around a load; splits past the end re-read the last one, weight 0)
 #pragma unroll
     for (int s = 0; s < CROSS_MAX_SPLIT; ++s) ov[s] = w[min(s, p.nsplit - 1) * stride + 2 + d];
-    const float m = wave_max(ms);
+    const float m = wave_max_nomfma(ms);
     const float f = d < p.nsplit ? __expf(ms - m) : 0.f;
     const float lf = ls * f;
     float den = 0.f, num = 0.f;

@@ -65,8 +65,10 @@ __device__ __forceinline__ float wave_dpp(float v) {
 // sums with fewer than five wait states there).  LLVM's gfx940/950 tables ask for up to 18 wait states between a 16-pass XDL
 // write / SrcC read and a VALU write of the same register, so the helpers wait 19 (s_nop 7 + 7 + 2): safe wherever they are
 // inlined, MFMA kernels included -- 11 more idle cycles per reduction, nothing next to the memory round trips these kernels
-// are made of.  Users today: gemv_small (an MFMA kernel; the reductions run in the LayerNorm prologue, before its first
-// MFMA), rowops, greedy, attn_decode (cross kernel, merge kernel, self kernel: no MFMA).  attn_encoder keeps __shfl_xor.
+// are made of.  No kernel needs the guarded forms today: gemv_small / gemm_rows reduce in their LayerNorm prologues, before the
+// wave's first MFMA (wave_sum_pre_mfma), rowops, greedy and attn_decode have no MFMA at all (wave_sum_nomfma / wave_max_nomfma:
+// the same butterfly without the wait states); attn_encoder keeps __shfl_xor.  The guarded forms stay for any reduction that
+// does follow an MFMA.
 #define WM_SWAP_GUARD "s_nop 7\n\ts_nop 7\n\ts_nop 2\n\t"
 __device__ __forceinline__ void wave_swap32(int& x, int& y) {
     asm volatile(WM_SWAP_GUARD "v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
@@ -107,6 +109,20 @@ __device__ __forceinline__ float wave_sum_pre_mfma(float v) {
     v += wave_dpp<0x124>(v);
     v += wave_dpp<0x4E>(v);
     v += wave_dpp<0xB1>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_nomfma(float v) { return wave_sum_pre_mfma(v); }     // kernels without matrix instructions
+__device__ __forceinline__ float wave_max_nomfma(float v) {
+    int x = __builtin_bit_cast(int, v), y;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
+    v = fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+    x = __builtin_bit_cast(int, v);
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));
+    v = fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+    v = fmaxf(v, wave_dpp<0x128>(v));
+    v = fmaxf(v, wave_dpp<0x124>(v));
+    v = fmaxf(v, wave_dpp<0x4E>(v));
+    v = fmaxf(v, wave_dpp<0xB1>(v));
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {

@@ -349,7 +349,82 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                 }
             }
         };
-        if (p.residual) finish(std::true_type{}); else finish(std::false_type{});
+        // SIMPLE (plain row-major output and residual: the encoder layers' four GEMMs), round 3: the same values with a third of the
+        // instructions.  The general form above converts this lane's bias values once per 16-row block and sends every output
+        // through fp32 -> fp16 -> fp32 -> fp16; it compiled to ~1000 instructions per wave and tile -- 17 000 cycles of a plain
+        // K = 1280 tile's 84 000 with two waves per SIMD in it together, 32 000 with a residual (from the shapes' rates: 160 S + E
+        // and 40 S + E cycles per tile at K = 5120 / 1280).  Here: bias to fp32 ONCE per tile (32 values per lane), packed adds,
+        // one conversion per output where nothing sits between the Linear's rounding and the store.
+        auto finish_simple = [&](auto res_tag, auto scale_tag) {
+            constexpr bool RES = decltype(res_tag)::value, SCALE = decltype(scale_tag)::value;
+            half4v r4[RES ? 4 : 1][RES ? 8 : 1];
+            if constexpr (RES) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + wr * 64 + i * 16 + rl;
+                    const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colw;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r4[i][j] = *(const half4v*)(rrow + j * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float2v bf[8][2];                                 // bias of this lane's channels colw + 16 j + (0..3), as fp32 pairs
+            float scj[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const half4v b4 = *(const half4v*)(bias_lds + j * 16);
+                bf[j][0] = float2v{(float)b4[0], (float)b4[1]};
+                bf[j][1] = float2v{(float)b4[2], (float)b4[3]};
+                scj[j] = (SCALE && colw + j * 16 < p.colscale_n) ? p.colscale : 1.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + wr * 64 + i * 16 + rl;
+                h16* crow = p.C + (size_t)(row < p.M ? row : p.M - 1) * p.ldc + colw;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float2v v0 = float2v{acc[i][j][0], acc[i][j][1]} + bf[j][0];
+                    float2v v1 = float2v{acc[i][j][2], acc[i][j][3]} + bf[j][1];
+                    half4v o;
+                    if constexpr (ACT == 0 && !RES && !SCALE) {          // the Linear's fp16 output is the result
+                        const half2v h0 = __builtin_convertvector(v0, half2v), h1 = __builtin_convertvector(v1, half2v);
+                        o = half4v{h0[0], h0[1], h1[0], h1[1]};
+                    } else {
+                        half2v h0 = __builtin_convertvector(v0, half2v), h1 = __builtin_convertvector(v1, half2v);     // the Linear's fp16 output
+                        v0 = __builtin_convertvector(h0, float2v); v1 = __builtin_convertvector(h1, float2v);
+                        if (ACT == 1) {
+                            v0 = gelu_erf2(v0); v1 = gelu_erf2(v1);
+                            h0 = __builtin_convertvector(v0, half2v); h1 = __builtin_convertvector(v1, half2v);
+                            v0 = __builtin_convertvector(h0, float2v); v1 = __builtin_convertvector(h1, float2v);
+                        } else if (ACT == 2) {
+                            v0 = float2v{r16(gelu_tanh(v0[0])), r16(gelu_tanh(v0[1]))};
+                            v1 = float2v{r16(gelu_tanh(v1[0])), r16(gelu_tanh(v1[1]))};
+                        }
+                        if constexpr (SCALE) {                // q, k * d^-0.25 (torch_model.py:93-95)
+                            v0 = float2v{r16(v0[0] * scj[j]), r16(v0[1] * scj[j])};
+                            v1 = float2v{r16(v1[0] * scj[j]), r16(v1[1] * scj[j])};
+                        }
+                        if constexpr (RES) {
+                            v0 += float2v{(float)r4[i][j][0], (float)r4[i][j][1]};
+                            v1 += float2v{(float)r4[i][j][2], (float)r4[i][j][3]};
+                        }
+                        h0 = __builtin_convertvector(v0, half2v); h1 = __builtin_convertvector(v1, half2v);
+                        o = half4v{h0[0], h0[1], h1[0], h1[1]};
+                    }
+                    if (row < p.M) *(half4v*)(crow + j * 16) = o;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (SIMPLE && ACT != 0) {
+            finish_simple(std::false_type{}, std::false_type{});                         // (the launcher sends GELU + residual / column scale to the general form)
+        } else if constexpr (SIMPLE) {     // (wave-uniform branches, once per tile)
+            if (p.residual) finish_simple(std::true_type{}, std::false_type{});          // no encoder GEMM has both a residual and a column scale
+            else if (scale_cols) finish_simple(std::false_type{}, std::true_type{});
+            else finish_simple(std::false_type{}, std::false_type{});
+        } else {
+            if (p.residual) finish(std::true_type{}); else finish(std::false_type{});
+        }
         // the store count the next stage wait adds is exact only for a tile without an M tail (rows past M skip their stores)
         if (row0 + BM <= p.M) after_epilogue = true; else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ks = 0;
@@ -398,7 +473,8 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     if (max_wgs > 0 && max_wgs < grid) grid = max_wgs >= 8 ? (max_wgs / 8) * 8 : 8;
     const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
     if (grid > need) grid = need;
-    const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f;
+    const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f && !(p.residual && p.colscale_n > 0) &&
+                        (p.act == 0 || (!p.residual && p.colscale_n <= 0));
     static const int lab_rows = [] { const char* v = getenv("WM_GEMM_TILE_ROWS"); return v ? atoi(v) : 0; }();    // A/B runs: 1 = the plain row-major tile order
     static const int lab_nt = [] { const char* v = getenv("WM_GEMM_NT"); return v ? atoi(v) : 0; }();             // A/B runs: 1 = A panels nt, 4 = C stores nt, 5 = both
     GemmBigParams q = p;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
                         for (int e = 0; e < 8; ++e) sum += (float)x[e];
                     }
                 }
-                const float mean = wave_sum(sum) / (float)p.K;
+                const float mean = wave_sum_pre_mfma(sum) / (float)p.K;
                 float sq = 0.f;
 #pragma unroll
                 for (int u = 0; u < XP; ++u) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
                         for (int e = 0; e < 8; ++e) { const float d = (float)x[e] - mean; sq += d * d; }
                     }
                 }
-                const float rstd = rsqrtf(wave_sum(sq) / (float)p.K + 1e-5f);
+                const float rstd = rsqrtf(wave_sum_pre_mfma(sq) / (float)p.K + 1e-5f);
                 const int r = r0 + j * nwave;
 #pragma unroll
                 for (int u = 0; u < XP; ++u) {

@@ -15,7 +15,7 @@ namespace wm {
 constexpr int ROW_THREADS = 256;
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
-    v = wave_sum(v);
+    v = wave_sum_nomfma(v);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
     if (lane == 0) red[wid] = v;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void layernorm_stream_kernel(const h16* x, int
                 const int j = w + 4 * k;
                 if (j < LNS_G && lane + 64 * w + 256 * k < n4) s += (xf[j][0] + xf[j][1]) + (xf[j][2] + xf[j][3]);
             }
-            tot += wave_sum(s);
+            tot += wave_sum_nomfma(s);
         }
         const float mean = tot / (float)N;
         float qt = 0.f;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void layernorm_stream_kernel(const h16* x, int
                     q += (a * a + bb * bb) + (cc * cc + d * d);
                 }
             }
-            qt += wave_sum(q);
+            qt += wave_sum_nomfma(q);
         }
         const float rstd = rsqrtf(qt / (float)N + 1e-5f);
         h16* orow = out + (size_t)(row0 + r) * ldo;
