@@ -226,6 +226,14 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         ++cons;
         if (++ks < nk) continue;
 
+        // Waves 4-7 run one barrier behind: their last barrier of the tile pairs with THIS one.  Without it (round 2) it paired with
+        // waves 0-3's first barrier of the next tile, i.e. waves 4-7 sat behind their finished last multiply until waves 0-3 had
+        // run their whole epilogue, and waves 0-3 then waited at their next barrier for waves 4-7's epilogue: the two epilogues ran
+        // one after the other -- 10 us of a plain K = 1280 tile's 47, 17-21 us with a residual (time stamps inside the kernel,
+        // profiles/r3w_gemm_tile_boundary_stamps_before.log).  Now both groups enter their epilogues together; waves 4-7 take their
+        // lag back with an extra barrier at the start of the next tile (below), as at the start of the kernel.
+        if (wid < 4) __builtin_amdgcn_s_barrier();
+
         // ================================ epilogue (as gemm_f16.hip) =====================================================
         int tm, tn;
         tile_of(j0 + t * per_xcd, tm, tn);
@@ -430,8 +438,8 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         ks = 0;
         if (++t == my_tiles) break;
         zero_acc();
+        if (wid >= 4) __builtin_amdgcn_s_barrier();  // one barrier behind waves 0-3 again
     }
-    if (wid < 4) __builtin_amdgcn_s_barrier();       // waves 4-7 ran one barrier behind
 }
 
 bool gemm_f16p_supports(const GemmBigParams& p) {
