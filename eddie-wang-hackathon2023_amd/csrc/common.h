@@ -138,6 +138,11 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, wave_dpp<0xB1>(v));
     return v;
 }
+// v_permlane16_swap: the odd 16-lane rows of a and the even rows of b change places (lane l of row 2k+1 <-> lane l of row 2k).
+// For data that no matrix instruction of the wave has in flight (freshly converted values in an epilogue).
+__device__ __forceinline__ void lane_rows_swap16(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ float r16(float x) { return (float)(h16)x; }   // round through fp16
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. far below an fp16 ulp of any GELU output that matters) on the

@@ -365,14 +365,23 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         // one conversion per output where nothing sits between the Linear's rounding and the store.
         auto finish_simple = [&](auto res_tag, auto scale_tag) {
             constexpr bool RES = decltype(res_tag)::value, SCALE = decltype(scale_tag)::value;
-            half4v r4[RES ? 4 : 1][RES ? 8 : 1];
+            // 16-BYTE accesses.  In the accumulator layout a lane owns 4 consecutive channels of a row (8 bytes) per 16-channel block,
+            // the lane 16 places on the next 4: every store instruction wrote 16 rows x 32 bytes, and the CU's store path, which
+            // works segment by segment, needed 3.5 us for a wave's 32 of them (time stamps inside the kernel: a ~600-instruction
+            // epilogue took 4.8 us).  Two adjacent blocks are therefore exchanged between the paired lane rows first
+            // (v_permlane16_swap: lanes of rows 0 / 2 end up with 8 consecutive channels of block 2 jp, rows 1 / 3 with those of
+            // block 2 jp + 1): 16 stores of 16 rows x 64 contiguous bytes, and the residual arrives by 16-byte loads in the same
+            // layout.  Element by element the same arithmetic as before.
+            const int odd = ge & 1;
+            const int colx = col0 + wc * 128 + 4 * (ge - odd) + 16 * odd;          // + 32 jp: this lane's first channel after the exchange
+            uint4 r8[RES ? 4 : 1][RES ? 4 : 1];
             if constexpr (RES) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = row0 + wr * 64 + i * 16 + rl;
-                    const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colw;
+                    const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colx;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) r4[i][j] = *(const half4v*)(rrow + j * 16);
+                    for (int jp = 0; jp < 4; ++jp) r8[i][jp] = *(const uint4*)(rrow + jp * 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -385,41 +394,59 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                 bf[j][1] = float2v{(float)b4[2], (float)b4[3]};
                 scj[j] = (SCALE && colw + j * 16 < p.colscale_n) ? p.colscale : 1.0f;
             }
+            // block j of row block i, everything in front of the residual add, as two packed fp16 pairs (accumulator layout)
+            auto block = [&](int i, int j, uint32_t& lo, uint32_t& hi) {
+                float2v v0 = float2v{acc[i][j][0], acc[i][j][1]} + bf[j][0];
+                float2v v1 = float2v{acc[i][j][2], acc[i][j][3]} + bf[j][1];
+                half2v h0 = __builtin_convertvector(v0, half2v), h1 = __builtin_convertvector(v1, half2v);     // the Linear's fp16 output
+                if constexpr (ACT != 0 || SCALE) {
+                    v0 = __builtin_convertvector(h0, float2v); v1 = __builtin_convertvector(h1, float2v);
+                    if (ACT == 1) {
+                        v0 = gelu_erf2(v0); v1 = gelu_erf2(v1);
+                        if constexpr (SCALE) {
+                            h0 = __builtin_convertvector(v0, half2v); h1 = __builtin_convertvector(v1, half2v);
+                            v0 = __builtin_convertvector(h0, float2v); v1 = __builtin_convertvector(h1, float2v);
+                        }
+                    } else if (ACT == 2) {
+                        v0 = float2v{gelu_tanh(v0[0]), gelu_tanh(v0[1])};
+                        v1 = float2v{gelu_tanh(v1[0]), gelu_tanh(v1[1])};
+                        if constexpr (SCALE) {
+                            h0 = __builtin_convertvector(v0, half2v); h1 = __builtin_convertvector(v1, half2v);
+                            v0 = __builtin_convertvector(h0, float2v); v1 = __builtin_convertvector(h1, float2v);
+                        }
+                    }
+                    if constexpr (SCALE) {                    // q, k * d^-0.25 (torch_model.py:93-95)
+                        v0 = float2v{v0[0] * scj[j], v0[1] * scj[j]};
+                        v1 = float2v{v1[0] * scj[j], v1[1] * scj[j]};
+                    }
+                    h0 = __builtin_convertvector(v0, half2v); h1 = __builtin_convertvector(v1, half2v);
+                }
+                lo = __builtin_bit_cast(uint32_t, h0); hi = __builtin_bit_cast(uint32_t, h1);
+            };
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + wr * 64 + i * 16 + rl;
-                h16* crow = p.C + (size_t)(row < p.M ? row : p.M - 1) * p.ldc + colw;
+                h16* crow = p.C + (size_t)(row < p.M ? row : p.M - 1) * p.ldc + colx;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float2v v0 = float2v{acc[i][j][0], acc[i][j][1]} + bf[j][0];
-                    float2v v1 = float2v{acc[i][j][2], acc[i][j][3]} + bf[j][1];
-                    half4v o;
-                    if constexpr (ACT == 0 && !RES && !SCALE) {          // the Linear's fp16 output is the result
-                        const half2v h0 = __builtin_convertvector(v0, half2v), h1 = __builtin_convertvector(v1, half2v);
-                        o = half4v{h0[0], h0[1], h1[0], h1[1]};
-                    } else {
-                        half2v h0 = __builtin_convertvector(v0, half2v), h1 = __builtin_convertvector(v1, half2v);     // the Linear's fp16 output
-                        v0 = __builtin_convertvector(h0, float2v); v1 = __builtin_convertvector(h1, float2v);
-                        if (ACT == 1) {
-                            v0 = gelu_erf2(v0); v1 = gelu_erf2(v1);
-                            h0 = __builtin_convertvector(v0, half2v); h1 = __builtin_convertvector(v1, half2v);
-                            v0 = __builtin_convertvector(h0, float2v); v1 = __builtin_convertvector(h1, float2v);
-                        } else if (ACT == 2) {
-                            v0 = float2v{r16(gelu_tanh(v0[0])), r16(gelu_tanh(v0[1]))};
-                            v1 = float2v{r16(gelu_tanh(v1[0])), r16(gelu_tanh(v1[1]))};
+                for (int jp = 0; jp < 4; ++jp) {
+                    uint32_t a0, a1, b0, b1;
+                    block(i, 2 * jp, a0, a1);
+                    block(i, 2 * jp + 1, b0, b1);
+                    lane_rows_swap16(a0, b0);                 // even lane rows: (a, b) = block 2 jp, own 4 channels | the next 4;
+                    lane_rows_swap16(a1, b1);                 // odd lane rows: block 2 jp + 1, the previous 4 | own
+                    uint4 o = make_uint4(a0, a1, b0, b1);
+                    if constexpr (RES) {
+                        const half8v x = __builtin_bit_cast(half8v, o), r = __builtin_bit_cast(half8v, r8[i][jp]);
+                        half8v y;
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const float2v t = float2v{(float)x[e], (float)x[e + 1]} + float2v{(float)r[e], (float)r[e + 1]};
+                            const half2v h = __builtin_convertvector(t, half2v);
+                            y[e] = h[0]; y[e + 1] = h[1];
                         }
-                        if constexpr (SCALE) {                // q, k * d^-0.25 (torch_model.py:93-95)
-                            v0 = float2v{r16(v0[0] * scj[j]), r16(v0[1] * scj[j])};
-                            v1 = float2v{r16(v1[0] * scj[j]), r16(v1[1] * scj[j])};
-                        }
-                        if constexpr (RES) {
-                            v0 += float2v{(float)r4[i][j][0], (float)r4[i][j][1]};
-                            v1 += float2v{(float)r4[i][j][2], (float)r4[i][j][3]};
-                        }
-                        h0 = __builtin_convertvector(v0, half2v); h1 = __builtin_convertvector(v1, half2v);
-                        o = half4v{h0[0], h0[1], h1[0], h1[1]};
+                        o = __builtin_bit_cast(uint4, y);
                     }
-                    if (row < p.M) *(half4v*)(crow + j * 16) = o;
+                    if (row < p.M) *(uint4*)(crow + jp * 32) = o;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -482,7 +509,8 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
     if (grid > need) grid = need;
     const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f && !(p.residual && p.colscale_n > 0) &&
-                        (p.act == 0 || (!p.residual && p.colscale_n <= 0));
+                        (p.act == 0 || (!p.residual && p.colscale_n <= 0)) &&
+                        p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));      // 16-byte epilogue accesses
     static const int lab_rows = [] { const char* v = getenv("WM_GEMM_TILE_ROWS"); return v ? atoi(v) : 0; }();    // A/B runs: 1 = the plain row-major tile order
     static const int lab_nt = [] { const char* v = getenv("WM_GEMM_NT"); return v ? atoi(v) : 0; }();             // A/B runs: 1 = A panels nt, 4 = C stores nt, 5 = both
     GemmBigParams q = p;
