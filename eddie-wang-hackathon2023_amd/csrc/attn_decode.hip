@@ -274,7 +274,7 @@ constexpr int CROSS_MAX_SPLIT = 16;                   // key-range splits the me
 // 64 B, a lane takes 16 dims (one 16-byte load), a wave-instruction covers 16 rows.  The values are exactly code * t (no
 // fp16 rounding of the dequantised tensor), so the scale factors out of both products: score = r16((q16 . code) * t *
 // d^-0.25) with v_dot2 on exact fp16 codes, out = r16(t * (p . code)) -- one VALU op per element instead of eight.
-template <int L, bool I8 = false>
+template <int L, bool I8 = false, int UNR_ = 0>
 __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     constexpr int DPL = I8 ? 16 : 8;                     // dims per lane
     constexpr int LPR = 64 / DPL;                        // lanes per row: 8 (fp16) / 4 (int8)
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
 #endif
     // loads per block; two blocks are in flight (see `pipeline`).  2 / 3 / 4 / 6: 6.52 / 6.74 / 6.88 / 6.46 TB/s alone,
     // 24.9 / 25.1 / 25.4 / 26.4 ms per decode step at B = 576 (a gentler stream costs the other groups' chains less)
-    constexpr int UNR = CROSS_UNR;
+    constexpr int UNR = UNR_ > 0 ? UNR_ : CROSS_UNR;
     __shared__ float s_sc[L][CROSS_MAX_KEYS];
     __shared__ float s_red[L][4][2];
     __shared__ float s_o[4][L][64];
@@ -639,6 +639,12 @@ __global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams 
     p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + d] = (h16)(num / den);
 }
 
+// lab (WM_CROSS_UNR=2): the single-token fp16 kernel with 2 loads per block instead of 4: 78 registers (80 allocated) instead of 92 (96)
+static bool cross_unr2() {
+    static const bool v = [] { const char* e = getenv("WM_CROSS_UNR"); return e && atoi(e) == 2; }();
+    return v;
+}
+
 int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     WM_REQUIRE(p.L >= 1 && p.L <= MAX_L, "attn_cross: L=%d out of range [1,%d]", p.L, MAX_L);
     WM_REQUIRE(p.Tk >= 1 && p.Tk <= CROSS_MAX_KEYS, "attn_cross: Tk=%d out of range", p.Tk);
@@ -690,9 +696,13 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
     } else if (ev_start && ev_stop && p.L == 1) {
         // in-situ roofline sample (bench.py): the events take the dispatch's own begin / end timestamps, as a
         // profiler would -- events recorded around an ordinary launch add ~45 us of marker latency to a 148 us kernel
-        hipExtLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, ev_start, ev_stop, 0, p);
+        if (cross_unr2()) hipExtLaunchKernelGGL((attn_cross_kernel<1, false, 2>), grid, dim3(256), 0, stream, ev_start, ev_stop, 0, p);
+        else hipExtLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, ev_start, ev_stop, 0, p);
     } else switch (p.L) {
-        case 1: hipLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, p); break;
+        case 1:
+            if (cross_unr2()) hipLaunchKernelGGL((attn_cross_kernel<1, false, 2>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL(attn_cross_kernel<1>, grid, dim3(256), 0, stream, p);
+            break;
         case 2: hipLaunchKernelGGL(attn_cross_kernel<2>, grid, dim3(256), 0, stream, p); break;
         case 3: hipLaunchKernelGGL(attn_cross_kernel<3>, grid, dim3(256), 0, stream, p); break;
         default: hipLaunchKernelGGL(attn_cross_kernel<4>, grid, dim3(256), 0, stream, p); break;

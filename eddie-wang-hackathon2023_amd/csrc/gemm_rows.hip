@@ -51,7 +51,7 @@
 namespace wm {
 
 namespace rows {
-constexpr int RING = 10;                // weight tiles (1 KiB per wave) in flight per wave
+constexpr int ring(int nw) { return nw == 8 ? 8 : 10; }     // weight tiles (1 KiB per wave) in flight per wave
 constexpr int XP = 3;                   // 16-byte pieces of a row per lane (K <= 1536)
 }  // namespace rows
 
@@ -59,11 +59,12 @@ constexpr int XP = 3;                   // 16-byte pieces of a row per lane (K <
 // blocks per workgroup (4, or 8 for wide outputs: half the workgroups -- one round over the chip at N = 5120 -- and half as many
 // copies of the input block and of its LayerNorm, which every channel group redoes)
 template <int WB, int MT, bool LN, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemvSmallParams p, int n_cg, int n_ms) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 5 : 4) void gemm_rows_kernel(GemvSmallParams p, int n_cg, int n_ms) {
     using namespace rows;
     constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);   // inputs per 1 KiB weight tile
     constexpr int NM = KT / 32;                               // MFMAs (32-deep) per tile
     constexpr int ROWS = 16 * MT, RB = ROWS / NW;             // rows per workgroup, rows per wave in the prologue
+    constexpr int RING = ring(NW);
     extern __shared__ __attribute__((aligned(1024))) unsigned char s_x[];      // [ROWS] rows of ceil(K / 512) KiB + 16 bytes
 
     // chain kernel next to the other groups' K/V streams (as gemm_skinny.hip)
@@ -127,23 +128,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemvSmallParams p, i
     if constexpr (LN) {
         // two rows per trip: their dependent chains (the element-order sums, the reductions) interleave; a row is converted to
         // fp32 once and stays in registers for the three passes; gamma / beta are read and converted once per pair of rows
-        static_assert(RB % 2 == 0, "rows per wave must be even");
+        // (8-wave workgroups take one row per trip: a wave has only 4 rows there, and the kernel has to stay within 96 registers to
+        // fit twice per SIMD beside the K/V streams' waves)
+        constexpr int RPT = NW == 8 ? 1 : 2;
+        static_assert(RB % RPT == 0, "rows per wave and rows per trip");
         const float fK = (float)p.K;
 #pragma unroll 1
-        for (int jr = 0; jr < RB; jr += 2) {
-            unsigned char* xr[2] = {s_x + (wid + jr * NW) * row_bytes, s_x + (wid + (jr + 1) * NW) * row_bytes};
-            float xf[2][XP][8];
+        for (int jr = 0; jr < RB; jr += RPT) {
+            unsigned char* xr[RPT];
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < RPT; ++q) xr[q] = s_x + (wid + (jr + q) * NW) * row_bytes;
+            float xf[RPT][XP][8];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
 #pragma unroll
                 for (int u = 0; u < XP; ++u) {
                     const half8v x = *(const half8v*)(xr[q] + (min(lane + 64 * u, 64 * np - 1) << 4));
 #pragma unroll
                     for (int e = 0; e < 8; ++e) xf[q][u][e] = (float)x[e];
                 }
-            float mean[2], rstd[2];
+            float mean[RPT], rstd[RPT];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < RPT; ++q) {
                 float sum = 0.f;
 #pragma unroll
                 for (int u = 0; u < XP; ++u) {
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemvSmallParams p, i
                 mean[q] = wave_sum_pre_mfma(sum) / fK;
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < RPT; ++q) {
                 float sq = 0.f;
 #pragma unroll
                 for (int u = 0; u < XP; ++u) {
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemvSmallParams p, i
                 const int cu = min(lane + 64 * u, 64 * np - 1) << 4;
                 const half8v gm = *(const half8v*)(s_g + cu), bt = *(const half8v*)(s_g + np * 1024 + cu);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < RPT; ++q) {
                     half8v y;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = (h16)((xf[q][u][e] - mean[q]) * rstd[q] * (float)gm[e] + (float)bt[e]);
