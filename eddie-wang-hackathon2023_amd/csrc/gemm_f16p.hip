@@ -61,7 +61,10 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     using namespace f16p;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     constexpr int WAIT = 4 * STAGES - 10;            // DMA pieces of this wave that may still be in flight when stage s + 1 must have landed
-    constexpr int N_STORES = 32;                     // store instructions of one wave's epilogue (8 pieces x 4)
+    // store instructions of one wave's epilogue, the number the first stage wait of the next tile may leave in flight ON TOP of the DMA
+    // pieces: 16 stores of 16 bytes in the SIMPLE form (4 row blocks x 4 block pairs), 32 of 8 bytes in the general one.  It must not
+    // exceed what the epilogue really issues: a larger count would let the wait pass with DMA pieces of the stage still in flight.
+    constexpr int N_STORES = SIMPLE ? 16 : 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;           // 4 (M) x 2 (N) waves, each 64 rows x 128 channels
