@@ -224,3 +224,44 @@ def test_gemm_rows_is_stable_next_to_a_memory_stream(lib):
         torch.cuda.current_stream().synchronize()
         assert torch.equal(outs[1], ref), it
     torch.cuda.synchronize()
+
+
+def test_persistent_gemm_is_stable_next_to_a_memory_stream(lib):
+    """The persistent GEMM's tile boundary (csrc/gemm_f16p.hip): the first stage wait of a tile is a COUNTED wait that leaves
+    the previous tile's epilogue stores in flight; a wrong count, or a missing one of the barriers around the epilogue, would let
+    a wave read a stage before its DMA has landed -- rarely, and only under memory load.  Several tiles per workgroup, 60 launches
+    next to a device-wide copy stream, plain / column-scaled / residual epilogues, every output compared with the first one."""
+    r = rng(777)
+    M, K = 33000, 1280                                          # 129 row panels x 5 .. 15 channel tiles > 256 workgroups
+    A = dev((r.standard_normal((M, K)) * 0.5).astype(np.float16))
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    big2 = torch.empty_like(big)
+    side = torch.cuda.Stream()
+    for N, resid, act in [(1280, True, 0), (3840, False, 0), (1280, False, 1)]:
+        Wf = dev((r.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16))
+        bias = dev((r.standard_normal(N) * 0.1).astype(np.float16))
+        res = dev((r.standard_normal((M, N)) * 0.5).astype(np.float16)) if resid else None
+        outs = [torch.zeros((M, N), dtype=torch.float16, device="cuda") for _ in range(2)]
+
+        def run(out):
+            native.check(lib.wm_gemm(A.data_ptr(), K, M, K, Wf.data_ptr(), N, 0, None, bias.data_ptr(), res.data_ptr() if resid else None, N, act,
+                                     out.data_ptr(), N, None, 0, stream()))
+        run(outs[0])
+        torch.cuda.synchronize()
+        ref = outs[0].clone()
+        want = (A[:64].float() @ Wf.float().T + bias.float()).half().float()
+        if act:
+            want = torch.nn.functional.gelu(want).half().float()
+        if resid:
+            want = (want + res[:64].float()).half().float()
+        assert float((ref[:64].float() - want).abs().max()) < 2e-2
+        for it in range(60):
+            if it % 6 == 0:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        big2.copy_(big, non_blocking=True)
+            outs[1].zero_()
+            run(outs[1])
+            torch.cuda.current_stream().synchronize()
+            assert torch.equal(outs[1], ref), (N, it)
+        torch.cuda.synchronize()
