@@ -57,7 +57,10 @@ int wm_device_count(int* out);
 int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** out);
 void wm_engine_destroy(wm_engine* e);
 int wm_engine_info(const wm_engine* e, int32_t* kind, uint32_t* flags, wm_dims* dims);
-/* bytes of device memory holding this engine's weights */
+/* bytes of device memory holding this engine's weights.  Weight-only engines keep int8 (or int4 codes, one per byte for the
+ * row-major matrices of the encoder / cross-K/V engines) + fp16 scales at rest; the encoder / cross-K/V engines expand one matrix
+ * at a time to fp16(fp16(q) * scale) into the caller's workspace right before its GEMM (the workspace sizes below include that
+ * scratch block): the reference dequantises in registers (fpA_intB_gemm_template.h:47-140), same values.                    */
 size_t wm_engine_weight_bytes(const wm_engine* e);
 
 /* ---- encoder engine: W/encoding.py:48-76 -> WhisperEncoder.forward (whisper/model.py:149-172) ---
