@@ -353,3 +353,14 @@ def test_gemm_rows_generated_code_keeps_the_request_order():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_rows_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert r.stdout.count("ok ") == 24
+
+
+def test_graft_entry_build_runs():
+    """`__graft_entry__.build()` is the driver's build check: make (a no-op when the library is current), load, ABI version, imports."""
+    import importlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
