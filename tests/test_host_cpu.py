@@ -364,3 +364,17 @@ def test_graft_entry_build_runs():
         sys.path.insert(0, root)
     entry = importlib.import_module("__graft_entry__")
     entry.build()
+
+
+def test_persistent_gemm_generated_code_matches_its_store_count():
+    """csrc/gemm_f16p.hip lets a tile's first stage wait leave the previous epilogue's stores in flight by COUNT (16 in the SIMPLE
+    kernels, 32 in the general ones); scripts/check_gemm_isa.py holds the generated code to the counts (hipcc -S, no GPU)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_gemm_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert r.stdout.count("ok ") == 6
