@@ -248,12 +248,222 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     }
 }
 
+// The same attention with FOUR waves per (b, h) -- the form small groups take (launch_attn_self).  With one wave per head a
+// token step at 64-128 cached tokens is three to five dependent memory round trips plus ~3 us of arithmetic in that single wave
+// (64 dequantised products per key and lane, one fused multiply-add per cached V row), and at a few rows per group nothing else
+// runs on the chip meanwhile (profiles/r3ab_b1_kernel_stats.csv: 8.7 us per launch at B = 1, the longest link of the small-batch
+// chain).  Here the key range is dealt over four waves in blocks -- keys in blocks of 64 (a key row per lane), V rows by wave-wide
+// 16-byte loads that cover whole rows (16 int8 rows or 8 fp16 rows = 1 KiB per instruction; the one-wave form reads one BYTE per
+// lane and row) -- and every wave requests its first K block and its first four V blocks before anything else: up to 256 cached
+// tokens (128 with an fp16 cache) the cache is read in ONE round trip that overlaps the q / k / v sums.  The waves meet in LDS:
+// maximum, sum, and the partial P.V sums (added in a fixed order: wave, row inside a block, block).  Same rounding points as the
+// one-wave form (scores, probabilities and the dequantised cache values are rounded to fp16, sums are fp32); the fp32 additions
+// of the softmax sum and of P.V happen in a different order, so the two forms agree to fp32 rounding, not bit for bit.
+constexpr int SELF_WAVES = 4;
+template <bool I8>
+__global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfParams p) {
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int MAXT = 512;
+    constexpr int ES = I8 ? 1 : 2;                // bytes per cache element
+    constexpr int ROW_B = 64 * ES;                // bytes per cached row
+    constexpr int DIMS = 16 / ES;                 // head dims per 16-byte chunk: 16 | 8
+    constexpr int NCH = 64 / DIMS;                // chunks per row: 4 | 8
+    constexpr int VROWS = 64 / NCH;               // rows per wave-wide V load: 16 | 8
+    constexpr int KCH = ROW_B / 16;               // 16-byte chunks of a key row: 4 | 8
+    constexpr int VPRE = 4;                       // V loads per wave requested up front
+    constexpr int NT = 64 * SELF_WAVES;
+    __shared__ float s_p[MAXT];
+    __shared__ h16 s_qall[MAX_L][64], s_knew[MAX_L][64], s_vnew[MAX_L][64];
+    __shared__ float s_o[NT][DIMS + 1];
+    __shared__ float s_red[2][SELF_WAVES];
+
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int b = blockIdx.y;
+    if (p.live) {                                 // rows still decoding (workgroup-uniform)
+        if (b >= p.live[0]) return;
+        b = p.live[1 + b];
+    }
+    const int T = p.t_dev ? *p.t_dev : p.T;
+    const int C = p.H * 64;
+    const unsigned char* pastK = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(0 * p.H + h) * p.past_cap * 64) * ES;
+    const unsigned char* pastV = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(1 * p.H + h) * p.past_cap * 64) * ES;
+    // rows past the end re-read the last cached row (no branch around a load); their values are never used
+    const int vr = lane / NCH, vc = lane % NCH;   // V loads: row inside the block, 16-byte chunk of the row
+    uint4 kpre[KCH], vpre[VPRE];
+    if (T > 0) {                                  // workgroup-uniform
+        const int kr = min(64 * wid + lane, T - 1);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) kpre[c] = ((const uint4*)(pastK + (size_t)kr * ROW_B))[c];
+#pragma unroll
+        for (int n = 0; n < VPRE; ++n) {
+            const int row = min((wid + SELF_WAVES * n) * VROWS + vr, T - 1);
+            vpre[n] = *(const uint4*)(pastV + (size_t)row * ROW_B + vc * 16);
+        }
+    }
+    const float t_dq = p.kv_scale;
+    const float inv_t = 1.0f / p.kv_scale;
+    const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.B * p.L * p.ldp;
+
+    // ---- this call's q, k, v for the head (wave 0; lane = head dim): slabs summed, bias, fp16; cache append -------------------
+    if (wid == 0) {
+        for (int i = 0; i < p.L; ++i) {
+            const int m = b * p.L + i;
+            float q = 0.f, k = 0.f, v = 0.f;
+            const float* row = p.part + (size_t)m * p.ldp + h * 64 + lane;
+            int s = 0;
+            for (; s + 4 <= p.ksplit; s += 4) {    // the one-wave form's order of additions
+                const float* r0 = row + (size_t)s * sstride;
+                const float* r1 = r0 + sstride; const float* r2 = r1 + sstride; const float* r3 = r2 + sstride;
+                const float q0 = r0[0], q1 = r1[0], q2 = r2[0], q3 = r3[0];
+                const float k0 = r0[C], k1 = r1[C], k2 = r2[C], k3 = r3[C];
+                const float v0 = r0[2 * C], v1 = r1[2 * C], v2 = r2[2 * C], v3 = r3[2 * C];
+                q += (q0 + q1) + (q2 + q3); k += (k0 + k1) + (k2 + k3); v += (v0 + v1) + (v2 + v3);
+            }
+            for (; s < p.ksplit; ++s) {
+                const float* r0 = row + (size_t)s * sstride;
+                q += r0[0]; k += r0[C]; v += r0[2 * C];
+            }
+            q = r16(q + (p.bias ? (float)p.bias[h * 64 + lane] : 0.f));
+            k = r16(k + (p.bias ? (float)p.bias[C + h * 64 + lane] : 0.f));
+            v = r16(v + (p.bias ? (float)p.bias[2 * C + h * 64 + lane] : 0.f));
+            if (p.amax) {     // calibration hook (see attn_self_kernel)
+                const float a = wave_max_nomfma(fmaxf(fabsf(q), fmaxf(fabsf(k), fabsf(v))));
+                if (lane == 0) atomicMax((unsigned int*)p.amax, __float_as_uint(a));
+            }
+            s_knew[i][lane] = (h16)k;
+            s_vnew[i][lane] = (h16)v;
+            const size_t off_k = (size_t)b * p.present_bstride + ((size_t)(0 * p.H + h) * p.present_cap + T + i) * 64 + lane;
+            const size_t off_v = (size_t)b * p.present_bstride + ((size_t)(1 * p.H + h) * p.present_cap + T + i) * 64 + lane;
+            if (I8) {
+                ((int8_t*)p.present)[off_k] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(k * inv_t)));
+                ((int8_t*)p.present)[off_v] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(v * inv_t)));
+            } else {
+                ((h16*)p.present)[off_k] = (h16)k;
+                ((h16*)p.present)[off_v] = (h16)v;
+            }
+            s_qall[i][lane] = (h16)r16(q * ATTN_SCALE);
+        }
+    }
+    // copy-forward when present is a different buffer than past (the reference's concat semantics, attention.py:296-306)
+    const bool inplace = (p.past == p.present) && (p.past_cap == p.present_cap) && (p.past_bstride == p.present_bstride);
+    if (!inplace && T > 0) {
+        for (int kv = 0; kv < 2; ++kv) {
+            const unsigned char* src = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(kv * p.H + h) * p.past_cap * 64) * ES;
+            unsigned char* dst = (unsigned char*)p.present + ((size_t)b * p.present_bstride + (size_t)(kv * p.H + h) * p.present_cap * 64) * ES;
+            const int n16 = T * 64 * ES / 16;
+            for (int c = tid; c < n16; c += NT) ((uint4*)dst)[c] = ((const uint4*)src)[c];
+        }
+    }
+    __syncthreads();
+
+    for (int i = 0; i < p.L; ++i) {
+        const h16* s_q = s_qall[i];
+        const int nk = T + i + 1;                 // causal: past + new tokens 0..i
+        // ---- scores: key blocks of 64 dealt over the waves, a key per lane ------------------------------------------------
+        float mx = -INFINITY;
+        for (int kb = wid; kb * 64 < nk; kb += SELF_WAVES) {
+            const int j = kb * 64 + lane;
+            float sc = -INFINITY;
+            if (j < nk) {
+                float acc = 0.f;
+                if (j < T) {
+                    const uint4* kr = (const uint4*)(pastK + (size_t)j * ROW_B);
+#pragma unroll
+                    for (int c = 0; c < KCH; ++c) {
+                        const uint4 w = kb == wid ? kpre[c] : kr[c];
+                        if (I8) {
+                            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int8_t q8 = (int8_t)((ws[e >> 2] >> (8 * (e & 3))) & 0xff);
+                                const float kd = r16(r16((float)q8 * t_dq) * ATTN_SCALE);
+                                acc += (float)s_q[c * 16 + e] * kd;
+                            }
+                        } else {
+                            const half8v wh = __builtin_bit_cast(half8v, w);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc += (float)s_q[c * 8 + e] * r16((float)wh[e] * ATTN_SCALE);
+                        }
+                    }
+                } else {
+                    const h16* kn = s_knew[j - T];
+#pragma unroll 8
+                    for (int e = 0; e < 64; ++e) acc += (float)s_q[e] * r16((float)kn[e] * ATTN_SCALE);
+                }
+                sc = r16(acc);
+                s_p[j] = sc;
+            }
+            mx = fmaxf(mx, sc);
+        }
+        mx = wave_max_nomfma(mx);
+        if (lane == 0) s_red[0][wid] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+        // ---- softmax: thread t owns keys t and t + 256 ---------------------------------------------------------------------
+        const float e0 = tid < nk ? __expf(s_p[tid] - mx) : 0.f;
+        const float e1 = tid + NT < nk ? __expf(s_p[tid + NT] - mx) : 0.f;
+        const float wsum = wave_sum_nomfma(e0 + e1);
+        if (lane == 0) s_red[1][wid] = wsum;
+        __syncthreads();
+        const float inv = 1.0f / ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
+        if (tid < nk) s_p[tid] = r16(e0 * inv);
+        if (tid + NT < nk) s_p[tid + NT] = r16(e1 * inv);
+        __syncthreads();
+        // ---- P.V over the cached rows: blocks of VROWS rows dealt over the waves; a lane holds DIMS dims of one row per block --
+        float o[DIMS];
+#pragma unroll
+        for (int d = 0; d < DIMS; ++d) o[d] = 0.f;
+        auto add_block = [&](int vb, const uint4& w) {
+            const int row = vb * VROWS + vr;
+            const float pj = row < T ? s_p[row] : 0.f;
+            if (I8) {
+                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const int8_t q8 = (int8_t)((ws[d >> 2] >> (8 * (d & 3))) & 0xff);
+                    o[d] += pj * r16((float)q8 * t_dq);
+                }
+            } else {
+                const half8v wh = __builtin_bit_cast(half8v, w);
+#pragma unroll
+                for (int d = 0; d < 8; ++d) o[d] += pj * (float)wh[d];
+            }
+        };
+#pragma unroll
+        for (int n = 0; n < VPRE; ++n) {
+            const int vb = wid + SELF_WAVES * n;
+            if (vb * VROWS < T) add_block(vb, vpre[n]);           // (wave-uniform)
+        }
+        for (int vb = wid + SELF_WAVES * VPRE; vb * VROWS < T; vb += SELF_WAVES) {
+            const int row = min(vb * VROWS + vr, T - 1);
+            add_block(vb, *(const uint4*)(pastV + (size_t)row * ROW_B + vc * 16));
+        }
+#pragma unroll
+        for (int d = 0; d < DIMS; ++d) s_o[tid][d] = o[d];
+        __syncthreads();
+        if (wid == 0) {                           // lane = head dim: chunk lane / DIMS of every (wave, row-in-block) partial sum
+            const int ch = lane / DIMS, d = lane % DIMS;
+            float acc = 0.f;
+            for (int w = 0; w < SELF_WAVES; ++w)
+#pragma unroll
+                for (int r = 0; r < VROWS; ++r) acc += s_o[w * 64 + r * NCH + ch][d];
+            for (int j = T; j < nk; ++j) acc += s_p[j] * (float)s_vnew[j - T][lane];
+            p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)acc;
+        }
+        __syncthreads();
+    }
+}
+
 int launch_attn_self(const AttnSelfParams& p, hipStream_t stream) {
     WM_REQUIRE(p.L >= 1 && p.L <= MAX_L, "attn_self: L=%d out of range [1,%d]", p.L, MAX_L);
     WM_REQUIRE(p.T + p.L <= 512, "attn_self: T+L=%d exceeds 512", p.T + p.L);
     WM_REQUIRE(p.T + p.L <= p.present_cap, "attn_self: present capacity %d < T+L=%d", p.present_cap, p.T + p.L);
     WM_REQUIRE(!p.int8_kv || p.kv_scale > 0.f, "attn_self: int8 KV needs a positive scale");
-    if (p.int8_kv)
+    WM_REQUIRE(p.waves == 0 || p.waves == 1 || p.waves == SELF_WAVES, "attn_self: waves=%d (0, 1 or %d)", p.waves, SELF_WAVES);
+    if (p.waves == SELF_WAVES) {
+        if (p.int8_kv) hipLaunchKernelGGL(attn_self_wg_kernel<true>, dim3(p.H, p.B), dim3(64 * SELF_WAVES), 0, stream, p);
+        else hipLaunchKernelGGL(attn_self_wg_kernel<false>, dim3(p.H, p.B), dim3(64 * SELF_WAVES), 0, stream, p);
+    } else if (p.int8_kv)
         hipLaunchKernelGGL(attn_self_kernel<true>, dim3(p.H, p.B), dim3(64), 0, stream, p);
     else
         hipLaunchKernelGGL(attn_self_kernel<false>, dim3(p.H, p.B), dim3(64), 0, stream, p);

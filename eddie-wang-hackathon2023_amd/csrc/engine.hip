@@ -599,6 +599,20 @@ int rows_path_min_rows() {
     return r;
 }
 
+// Waves per (b, h) of the decode self-attention: 0 = by size (the small-batch side of the switch above runs the four-wave
+// workgroup form, attn_decode.hip), 1 / 4 = forced (WM_SELF_WAVES, wm_set_self_attn_waves).
+std::atomic<int> g_self_waves{-1};
+int self_attn_waves(int rows) {
+    int w = g_self_waves.load(std::memory_order_relaxed);
+    if (w < 0) {
+        const char* v = getenv("WM_SELF_WAVES");
+        w = v ? atoi(v) : 0;
+        if (w != 1 && w != 4) w = 0;
+        g_self_waves.store(w, std::memory_order_relaxed);
+    }
+    return w ? w : (rows <= small_path_max_rows() ? 4 : 1);
+}
+
 struct GroupStep {
     const wm_engine* e; const wm_decoder_io* io; DecWs w;
     int B, L, T, C, H, M;
@@ -694,6 +708,7 @@ struct GroupStep {
         p.amax = io->qkv_amax ? io->qkv_amax + i : nullptr;
         p.t_dev = io->n_past_dev;
         p.live = io->live_rows;
+        p.waves = self_attn_waves(M);
         if (launch_attn_self(p, s)) return 2;
         mark(i, 2, s);
         if (fused()) {
@@ -1012,6 +1027,13 @@ int wm_gemm_rows(const wm_gemv_io* io, wm_stream_t stream) {
     return launch_gemm_rows(p, (hipStream_t)stream);
 }
 
+int wm_set_self_attn_waves(int waves) {
+    self_attn_waves(1);                          // (reads the environment once)
+    const int prev = g_self_waves.load(std::memory_order_relaxed);
+    g_self_waves.store(waves == 1 || waves == 4 ? waves : 0, std::memory_order_relaxed);
+    return prev;
+}
+
 int wm_set_small_batch_rows(int rows) {
     const int prev = small_path_max_rows();
     g_small_rows.store(rows < 0 ? 0 : (rows > GEMV_SMALL_MAX_M ? GEMV_SMALL_MAX_M : rows), std::memory_order_relaxed);
@@ -1069,6 +1091,7 @@ int wm_attn_decode_self(const float* qkv, int B, int L, int T, int H, const void
     if (T > 0 && past) { p.past = past; p.past_cap = past_cap; p.past_bstride = (long)2 * H * past_cap * 64; }
     else { p.past = present; p.past_cap = present_cap; p.past_bstride = p.present_bstride; }
     p.int8_kv = int8_kv; p.kv_scale = kv_scale; p.out = (h16*)out; p.ldo = H * 64;
+    p.waves = self_attn_waves(B * L);
     return launch_attn_self(p, (hipStream_t)stream);
 }
 

@@ -37,7 +37,7 @@ __device__ __forceinline__ AM am_merge(AM a, AM b) {
 }
 
 template <typename T, typename F>
-__device__ __forceinline__ T block_reduce(T v, F merge, T* scratch) {
+__device__ __forceinline__ T wave_reduce(T v, F merge) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         T other;
@@ -48,6 +48,11 @@ __device__ __forceinline__ T block_reduce(T v, F merge, T* scratch) {
         other = __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
         v = merge(v, other);
     }
+    return v;
+}
+template <typename T, typename F>
+__device__ __forceinline__ T block_reduce(T v, F merge, T* scratch) {
+    v = wave_reduce(v, merge);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) scratch[wid] = v;
@@ -61,9 +66,9 @@ __device__ __forceinline__ T block_reduce(T v, F merge, T* scratch) {
 constexpr int GREEDY_THREADS = 1024;
 
 __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) {
-    __shared__ MS s_ms[GREEDY_THREADS / 64];
-    __shared__ AM s_am[GREEDY_THREADS / 64];
-    __shared__ int s_info[4];
+    __shared__ MS s_ms[2][GREEDY_THREADS / 64];
+    __shared__ AM s_am[2][GREEDY_THREADS / 64];
+    __shared__ int s_info[4], s_hist[GREEDY_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int cur_len = p.t_dev ? *p.t_dev + 1 : p.cur_len;     // device step counter holds n_past = cur_len - 1
     h16* lg = p.logits + (size_t)b * p.ld_row;
@@ -78,22 +83,34 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
         for (int i = tid; i < p.n_suppress; i += GREEDY_THREADS) lg[p.suppress[i]] = ninf;
         if (first) for (int i = tid; i < p.n_blank; i += GREEDY_THREADS) lg[p.blank[i]] = ninf;
     }
-    // ---- token-history facts (thread 0): last / penultimate sampled token, last timestamp ----------
-    if (tid == 0) {
-        int last_ts = 0, pen_ts = 0, ts_last = -1;
-        if (p.apply_rules) {
-            const int n = cur_len - p.sample_begin;
-            last_ts = (n >= 1 && toks[cur_len - 1] >= tb) ? 1 : 0;
-            pen_ts = (n < 2 || toks[cur_len - 2] >= tb) ? 1 : 0;
-            for (int j = cur_len - 1; j >= p.sample_begin; --j)
-                if (toks[j] >= tb) { ts_last = toks[j]; break; }
-            if (ts_last >= 0 && !(last_ts && !pen_ts)) ts_last += 1;
+    // ---- token-history facts: last / penultimate sampled token, last timestamp.  Every thread looks at one sampled token
+    // (a backwards scan by one thread was a chain of dependent loads: up to one L2 round trip per sampled token) ------------
+    const int n_sampled = cur_len - p.sample_begin;
+    int my_rel = -1, my_tok = -1;                  // this thread's latest timestamp among the sampled tokens it looked at
+    if (p.apply_rules) {
+        for (int j = tid; j < n_sampled; j += GREEDY_THREADS) {
+            const int t = toks[p.sample_begin + j];
+            if (t >= tb) { my_rel = j; my_tok = t; }
+            if (j == n_sampled - 1) s_info[0] = t >= tb;
+            if (j == n_sampled - 2) s_info[1] = t >= tb;
         }
-        s_info[0] = last_ts; s_info[1] = pen_ts; s_info[2] = ts_last;
+    }
+    {
+        int r = my_rel;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) r = max(r, __shfl_xor(r, o));
+        if ((tid & 63) == 0) s_hist[tid >> 6] = r;
     }
     __syncthreads();                       // also orders the -inf stores above before the scan
-    const bool last_ts = s_info[0], pen_ts = s_info[1];
-    const int ts_last = s_info[2];
+    int rel_last = -1;
+#pragma unroll
+    for (int w = 0; w < GREEDY_THREADS / 64; ++w) rel_last = max(rel_last, s_hist[w]);
+    if (rel_last >= 0 && my_rel == rel_last) s_info[2] = my_tok;          // exactly one thread holds that position
+    __syncthreads();
+    const bool last_ts = p.apply_rules && n_sampled >= 1 && s_info[0];
+    const bool pen_ts = p.apply_rules && (n_sampled < 2 || s_info[1]);
+    int ts_last = rel_last >= 0 ? s_info[2] : -1;
+    if (ts_last >= 0 && !(last_ts && !pen_ts)) ts_last += 1;
 
     // allowed = [lo_txt, hi_txt) U [lo_ts, hi_ts): every rule of ApplyTimestampRules is a range
     int lo_txt = 0, hi_txt = p.apply_rules ? tb : p.V, lo_ts = p.apply_rules ? tb : p.V, hi_ts = p.V;
@@ -109,6 +126,23 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
         if (n < hi_txt) { if (n >= lo_txt) { txt = ms_add(txt, x); if (x > atxt.v) atxt = AM{x, n}; } }
         else if (n >= lo_ts && n < hi_ts) { tsm = ms_add(tsm, x); if (x > ats.v) ats = AM{x, n}; }
     };
+    // eight logits that all belong to one class: one maximum, at most one rescale of the running sum, eight exponentials --
+    // instead of eight dependent (compare, branch, exponential) updates
+    auto visit8 = [&](MS& ms, AM& am, int n0, const float (&f)[8]) {
+        const float m8 = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
+        if (m8 == -INFINITY) return;
+        if (m8 > ms.m) { ms.s *= __expf(ms.m - m8); ms.m = m8; }         // (first finite value: 0 * exp(-inf) = 0)
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = __expf(f[i] - ms.m);
+        ms.s += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+        if (m8 > am.v) {
+            int first_e = 7;
+#pragma unroll
+            for (int i = 6; i >= 0; --i) if (f[i] == m8) first_e = i;
+            am = AM{m8, n0 + first_e};
+        }
+    };
     // rows are only 2-byte aligned (odd vocabulary): scalar head up to a 16-byte boundary, 8-wide body
     const int head = min(p.V, (int)(((16 - ((size_t)lg & 15)) & 15) >> 1));
     for (int n = tid; n < head; n += GREEDY_THREADS) visit(n, (float)lg[n]);
@@ -116,15 +150,32 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
     for (int c = tid; c < nvec; c += GREEDY_THREADS) {
         const int n0 = head + c * 8;
         const half8v v = *(const half8v*)(lg + n0);
+        float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) visit(n0 + e, (float)v[e]);
+        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        if (n0 >= lo_txt && n0 + 8 <= hi_txt) visit8(txt, atxt, n0, f);
+        else if (n0 >= hi_txt && n0 >= lo_ts && n0 + 8 <= hi_ts) visit8(tsm, ats, n0, f);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) visit(n0 + e, f[e]);
+        }
     }
     for (int n = head + nvec * 8 + tid; n < p.V; n += GREEDY_THREADS) visit(n, (float)lg[n]);
 
-    txt = block_reduce(txt, ms_merge, s_ms);
-    tsm = block_reduce(tsm, ms_merge, s_ms);
-    atxt = block_reduce(atxt, am_merge, s_am);
-    ats = block_reduce(ats, am_merge, s_am);
+    // the four results meet in one exchange: wave-level merges, one LDS round, wave 0 merges the sixteen partial results
+    // (thread 0 alone uses them)
+    txt = wave_reduce(txt, ms_merge); tsm = wave_reduce(tsm, ms_merge);
+    atxt = wave_reduce(atxt, am_merge); ats = wave_reduce(ats, am_merge);
+    if ((tid & 63) == 0) { s_ms[0][tid >> 6] = txt; s_ms[1][tid >> 6] = tsm; s_am[0][tid >> 6] = atxt; s_am[1][tid >> 6] = ats; }
+    __syncthreads();
+    if (tid >= 64) return;
+    {
+        constexpr int NW = GREEDY_THREADS / 64;
+        txt = tid < NW ? s_ms[0][tid] : MS{-INFINITY, 0.f}; tsm = tid < NW ? s_ms[1][tid] : MS{-INFINITY, 0.f};
+        atxt = tid < NW ? s_am[0][tid] : AM{-INFINITY, 0x7fffffff}; ats = tid < NW ? s_am[1][tid] : AM{-INFINITY, 0x7fffffff};
+        txt = wave_reduce(txt, ms_merge); tsm = wave_reduce(tsm, ms_merge);
+        atxt = wave_reduce(atxt, am_merge); ats = wave_reduce(ats, am_merge);
+    }
 
     if (tid == 0) {
         bool ts_only = false;

@@ -130,6 +130,7 @@ struct AttnSelfParams {
     const int32_t* t_dev;                    // optional device copy of T (overrides T; hipGraph replay)
     h16* out; int ldo;                       // [M][C]
     const int32_t* live;                     // optional [1 + B]: count, then the rows to process (others are skipped)
+    int waves;                               // waves per (b, h): 0 / 1 the one-wave kernel, 4 the workgroup form (small groups)
 };
 int launch_attn_self(const AttnSelfParams& p, hipStream_t stream);
 

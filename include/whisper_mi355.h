@@ -45,7 +45,7 @@ typedef struct wm_dims {
 
 /* ABI version of this header: 2 (round 3: wm_gemm takes a workspace before the stream; wm_decoder_io / wm_greedy_io carry
  * the per-row `done` flags).  Callers built against another version must refuse to run (native.py does). */
-#define WM_ABI_VERSION 3
+#define WM_ABI_VERSION 4
 int wm_version(void);
 const char* wm_last_error(void);
 int wm_device_count(int* out);
@@ -240,6 +240,12 @@ int wm_gemm_rows(const wm_gemv_io* io, wm_stream_t stream);
  * Linear, as rounds 1-2 did.  Returns the previous value.  On either side of the switch a row's result does not depend on the
  * batch it is in; across it the two forms agree to fp32 summation order.  Captured graphs keep the path they were captured with. */
 int wm_set_rows_path(int min_rows);
+/* Waves per (utterance, head) of the decode self-attention (wm_attn_decode_self and the decoder step): 0 (default, or
+ * WM_SELF_WAVES) = by size -- calls on the small-batch side of wm_set_small_batch_rows' switch run four waves per head (key
+ * range dealt over the waves, the cache read in one round trip), larger ones one wave per head; 1 or 4 = that form for every
+ * size.  Returns the previous value.  The two forms round at the same points and add the softmax sum and P.V in different fp32
+ * orders; the cache they append is identical.  Captured graphs keep the form they were captured with.                       */
+int wm_set_self_attn_waves(int waves);
 /* fp16 LayerNorm rows, fp32 statistics, eps 1e-5 (layernormKernels.cu:62-188). */
 int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta,
                  void* out, int ldo, wm_stream_t stream);

@@ -455,10 +455,12 @@ def test_attn_decode_cross_int8(lib, B, L, H, Tk, nsplit):
 
 
 # --------------------------------------------------------------------------------- decode self-attention
+@pytest.mark.parametrize("waves", [1, 4])       # one wave per (utterance, head) | the four-wave workgroup form of small groups
 @pytest.mark.parametrize("int8_kv", [0, 1])
 @pytest.mark.parametrize("B,L,T,H,inplace", [(2, 3, 0, 2, True), (2, 1, 5, 2, True), (1, 1, 130, 3, False),
-                                             (3, 1, 447, 2, True), (2, 3, 7, 1, False)])
-def test_attn_decode_self(lib, B, L, T, H, inplace, int8_kv):
+                                             (3, 1, 447, 2, True), (2, 3, 7, 1, False), (2, 1, 64, 2, True),
+                                             (1, 4, 257, 2, True), (2, 2, 300, 1, False)])
+def test_attn_decode_self(lib, B, L, T, H, inplace, int8_kv, waves):
     r = rng(B + L + T + H + int8_kv)
     C_ = H * 64
     cap = 448 if inplace else T + L
@@ -492,9 +494,13 @@ def test_attn_decode_self(lib, B, L, T, H, inplace, int8_kv):
         past, past_cap = (past_store.cuda().contiguous() if T > 0 else None), T
     out = torch.zeros((B * L, C_), dtype=torch.float16, device="cuda")
     qd = dev(qkv)
-    native.check(lib.wm_attn_decode_self(qd.data_ptr(), B, L, T, H, past.data_ptr() if past is not None else None,
-                                         past_cap, present.data_ptr(), cap, int8_kv, t_scale, out.data_ptr(), stream()))
-    torch.cuda.synchronize()
+    prev = lib.wm_set_self_attn_waves(waves)
+    try:
+        native.check(lib.wm_attn_decode_self(qd.data_ptr(), B, L, T, H, past.data_ptr() if past is not None else None,
+                                             past_cap, present.data_ptr(), cap, int8_kv, t_scale, out.data_ptr(), stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib.wm_set_self_attn_waves(prev)
     got = out.float().cpu().numpy()
     # reference accepts 5e-3 with int8 KV (test_gpt_attention.py:684-693)
     assert np.abs(got - ref).max() <= 1.5e-3, np.abs(got - ref).max()

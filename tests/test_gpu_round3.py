@@ -435,3 +435,41 @@ def test_two_gpus_scale_like_one(tmp_path):
     two = _bench_line(["--gpus", "2", "--batch", "192"], cache)
     assert two["n_gpus"] == 2 and two["scaling"] == "weak"
     assert two["value"] / 2 > 0.95 * one["value"], (one["value"], two["value"])
+
+
+# ------------------------------------------------------------------------- round 3, third session: small-batch chain
+@pytest.mark.parametrize("batch", [1, 6])
+def test_self_attention_wave_forms_agree_in_the_engine(tmpdir_module, lib, batch):
+    """The one-wave and the four-wave form of the decode self-attention inside the engine: the appended cache codes are
+    identical, the logits agree to the fp32 summation order (a few fp16 ulps at most on the micro model)."""
+    dims = Dims(**synthetic.DIMS["micro"])
+    eng = build_engine(tmpdir_module, "micro", 7, True, True, [0.05, 0.06])
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    mel = synthetic_mel(batch, 2 * dims.n_audio_ctx, dims.n_mels, 11).cuda()
+    cross = dec.xa2cross_key_value(enc.get_audio_features(mel))
+    cap, H, V = dims.n_text_ctx, dims.n_text_head, dims.n_vocab
+    sess, pos = dec.decoder_session, dec.positional_embedding
+    n_steps = min(cap - 4, 12)
+    toks = torch.randint(0, V, (batch, 3 + n_steps), generator=torch.Generator().manual_seed(3)).to(torch.int32).cuda()
+
+    def run(waves):
+        prev = lib.wm_set_self_attn_waves(waves)
+        try:
+            kv = [torch.zeros((batch, 2, H, cap, 64), dtype=torch.int8, device="cuda") for _ in range(dims.n_text_layer)]
+            lg0 = torch.zeros((batch, 3, V), dtype=torch.float16, device="cuda")
+            sess.decoder_step(toks[:, :3].contiguous(), pos[0:3], cross, None, cap, kv, cap, lg0, 0, stream())
+            out = [lg0[:, -1]]
+            for t in range(n_steps):
+                lg = torch.zeros((batch, 1, V), dtype=torch.float16, device="cuda")
+                sess.decoder_step(toks[:, 3 + t:4 + t].contiguous(), pos[3 + t:4 + t], cross, kv, cap, kv, cap, lg, 3 + t, stream())
+                out.append(lg[:, 0])
+            torch.cuda.synchronize()
+            return torch.stack(out, 1).float(), kv
+        finally:
+            lib.wm_set_self_attn_waves(prev)
+    l1, kv1 = run(1)
+    l4, kv4 = run(4)
+    assert float((l1 - l4).abs().max()) <= LOGIT_TOL_INT8_KV
+    same = sum(int((a == b).sum()) for a, b in zip(kv1, kv4)); total = sum(a.numel() for a in kv1)
+    assert same >= 0.99 * total           # (the codes of layer > 0 inherit the attention's last-bit differences through the residual stream)
+    assert torch.equal(kv1[0], kv4[0])    # layer 0's k / v are functions of the token and its position alone
