@@ -41,6 +41,7 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import native  # noqa: E402,F401  (first: sets the HIP runtime's graph-replay default before anything initialises the runtime)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -567,6 +568,7 @@ def main():
             "second_figure": ragged,
             # arithmetic-order / scheduling knobs read from the environment, echoed when set (defaults otherwise)
             "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WM_")} or None,
+            "hip_runtime_knobs": {k: os.environ[k] for k in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "GPU_MAX_HW_QUEUES", "AMD_OPT_FLUSH") if k in os.environ},
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, T)

@@ -11,6 +11,15 @@ import ctypes as C
 import os
 from typing import Optional, Sequence
 
+# Decode steps are replayed as captured hipGraphs of ~300 dependent short kernels.  ROCm 7's default replays a graph from
+# pre-built AQL packets (DEBUG_CLR_GRAPH_PACKET_CAPTURE=1); with the nodes enqueued one by one through the ordinary dispatch
+# path instead, every kernel of the chain costs ~0.4 us less on the GPU side: token step B = 1 1.685 -> 1.570 ms, B = 8
+# 2.262 -> 2.126, B = 32 3.504 -> 3.423, B = 576 unchanged (23.2 ms, 15.5-15.6 k tokens/s either way) --
+# profiles/r3ah_bench_*.json, sweep of the other launch-path knobs in profiles/r3ag_launch_knobs.txt.  The flag is read when
+# the HIP runtime initialises (first HIP call of the process), so it is set here, at import, unless the caller chose a value:
+# import this package before the first torch.cuda call, or export the variable.  Same kernels, same results.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WM_LIBRARY_PATH") or os.path.join(_HERE, "libwhisper_mi355.so")
 

@@ -13,6 +13,8 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import native  # noqa: E402,F401  (sets the package's HIP-runtime defaults before any test initialises the runtime: the suite runs what ships)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
