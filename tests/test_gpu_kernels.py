@@ -329,6 +329,25 @@ def test_attn_decode_cross_rows_do_not_depend_on_the_launch(lib):
     assert len({tuple(row) for row in big[:4].float().cpu().numpy().round(3).tolist()}) > 1
 
 
+def test_attn_decode_cross_split_rows_do_not_depend_on_the_launch(lib):
+    """Key range cut into 8 splits of 188 keys, merged by the merge kernel: 1 or 2 utterances (160 / 320 items, one workgroup
+    each) against 8 utterances in the persistent launch (1280 items): same bits per row."""
+    r = rng(321)
+    H, Tk, ns = 20, 1500, 8
+    q = r.standard_normal((8, H * 64)).astype(np.float32)
+    kv = torch.from_numpy(r.standard_normal((8, 2, H, Tk, 64)).astype(np.float16)).cuda()
+    qd = dev(q)
+    def run(B):
+        out = torch.zeros((B, H * 64), dtype=torch.float16, device="cuda")
+        ws = torch.zeros(B * H * ns * 66, dtype=torch.float32, device="cuda")
+        native.check(lib.wm_attn_decode_cross(qd.data_ptr(), B, 1, H, Tk, kv.data_ptr(), out.data_ptr(), ns, ws.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        return out
+    big = run(8)
+    assert torch.equal(run(2), big[:2]) and torch.equal(run(1), big[:1])
+    assert bool((big != 0).any())
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 1024, 4096), (64, 1536, 4096)])
 def test_weight_only_matmul_reference_spec(lib, M, N, K):
     """The reference's own known-answer test (test_weight_only_quant_matmul.py:94-119): uniform
@@ -406,7 +425,9 @@ def test_attn_encoder(lib, B, T, H):
 
 # -------------------------------------------------------------------------------- decode cross-attention
 @pytest.mark.parametrize("B,L,H,Tk,nsplit", [(2, 1, 2, 100, 1), (2, 3, 2, 100, 1), (1, 1, 20, 1500, 1),
-                                             (3, 1, 2, 1500, 4), (2, 3, 3, 333, 3), (1, 2, 1, 8, 1)])
+                                             (3, 1, 2, 1500, 4), (2, 3, 3, 333, 3), (1, 2, 1, 8, 1),
+                                             # single-token items of one or two blocks of rows (<= 256 keys per split)
+                                             (1, 1, 20, 1500, 8), (2, 1, 2, 250, 1), (1, 1, 3, 129, 1), (4, 1, 2, 1500, 7), (2, 1, 2, 257, 1)])
 def test_attn_decode_cross(lib, B, L, H, Tk, nsplit):
     r = rng(B + L + H + Tk)
     C_ = H * 64
