@@ -560,7 +560,10 @@ __global__ void stamp_kernel(long long* tl, int cap, long long tag, long long wh
     if (i < cap) { tl[1 + 3 * i] = tag; tl[2 + 3 * i] = what; tl[3 + 3 * i] = wall_clock64(); }
 }
 
-constexpr int SMALL_PATH_DEFAULT_ROWS = 8;      // measured: 8 rows 2.43 vs 2.56 ms per token, 2 x 8 rows 2.79 vs 2.92; 2 x 16 rows 3.70 vs 3.52 (the other way)
+// Round 2 put the switch at 8 rows (8 rows 2.43 vs 2.56 ms per token, 2 x 8 rows 2.79 vs 2.92; 2 x 16 rows 3.70 vs 3.52 the other way).  Re-measured
+// at the end of round 3 (four-wave self-attention on this side of the switch, graphs replayed node by node; profiles/r3an_small_path_switch.txt):
+// 12 rows 2.38 vs 2.60 ms on the split-K chain, 2 x 12 rows 3.00 vs 3.13, 16 rows 2.68 vs 2.79, 2 x 16 rows 3.43 either way -> 16 rows (one MFMA row tile).
+constexpr int SMALL_PATH_DEFAULT_ROWS = 16;
 // Small batches (M = B * L <= SMALL_PATH_DEFAULT_ROWS rows) take the fused path of gemv_small.hip: every Linear is ONE launch
 // that also applies the LayerNorm of its input rows and its own epilogue (bias / GELU / residual) -- 8 launches per layer
 // instead of 12, no fp32 slabs, no row kernels.  WM_SMALL_PATH=<rows> moves the switch (0: the big-batch kernels for every size).

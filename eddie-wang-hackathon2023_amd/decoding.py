@@ -674,7 +674,7 @@ class WhisperDecoding:
         if self.micro_batches is None:
             n_micro = 3 if n_batch >= 128 else 2 if n_batch >= 16 else 1
         else:
-            n_micro = self.micro_batches if n_batch >= 8 * self.micro_batches else 1
+            n_micro = self.micro_batches if n_batch >= 4 * self.micro_batches else 1
         return n_micro, [(g * n_batch // n_micro, (g + 1) * n_batch // n_micro) for g in range(n_micro)]
 
     def balanced_order(self, n_batch: int) -> List[int]:

@@ -369,7 +369,7 @@ def test_main_loop_fast_equals_reference_loop_and_oracle(tmpdir_module):
 @pytest.fixture
 def one_decode_path():
     """Pins the decoder to the big-batch kernels for every batch size (wm_set_small_batch_rows(0)), for tests that compare
-    a batch with its rows taken alone bit for bit: the fused small-batch path (<= 8 rows by default) adds up its K slices
+    a batch with its rows taken alone bit for bit: the fused small-batch path (<= 16 rows by default) adds up its K slices
     in another order, so across the switch rows agree to fp32 summation order, not bit for bit."""
     lib = native.load_library()
     prev = lib.wm_set_small_batch_rows(0)
