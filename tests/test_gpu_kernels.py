@@ -572,6 +572,64 @@ def test_greedy_step_matches_reference_rules(lib, golden_dir):
         assert bool(int(n_done[0])) == bool(fixr[f"c{c}_done"]), f"case {c}"
 
 
+def test_greedy_step_long_histories_match_oracle_rules(lib, golden_dir):
+    """The greedy kernel looks at the sampled tokens with one thread per token (last / penultimate token, latest timestamp):
+    histories that span several waves and several passes of the workgroup, timestamps at every kind of position, several rows
+    per launch -- against the oracle's restatement of the rules (pinned to the reference's classes by decoding_rules.npz)."""
+    fixr = np.load(os.path.join(golden_dir, "decoding_rules.npz"))
+    ids = DR.MULTILINGUAL
+    V, tb = ids.n_vocab, ids.timestamp_begin
+    sup = sorted(set(fixr["suppress"].tolist() + [ids.no_timestamps]))
+    rules = DR.RuleSet(ids, 3, sup, fixr["blank"].tolist(), 50)
+    sup_d, blank_d = dev(np.array(sup, dtype=np.int32)), dev(fixr["blank"].astype(np.int32))
+    r = rng(2026)
+    ld = 1500                                              # room for histories longer than one pass of 1024 threads
+    for n in (1, 2, 63, 64, 65, 129, 300, 1100):
+        rows = []
+        for kind in range(6):
+            hist = r.integers(0, 50000, n)
+            if kind >= 1:                                  # a non-decreasing run of timestamps somewhere
+                pos = sorted(r.choice(n, size=min(n, 1 + kind), replace=False).tolist())
+                t = int(r.integers(0, 700))
+                for q in pos:
+                    t += int(r.integers(0, 40)); hist[q] = tb + t
+            if kind == 2: hist[-1] = tb + 1200             # ends on a timestamp
+            if kind == 3 and n >= 2: hist[-1] = hist[-2] = tb + 1300          # ends on a pair
+            if kind == 4: hist[0] = tb + 7; hist[1:] = r.integers(0, 50000, n - 1)   # the only timestamp is the oldest token
+            if kind == 5 and n > 70: hist[63] = tb + 900; hist[64:] = r.integers(0, 50000, n - 64)   # last lane of the first wave
+            rows.append(np.concatenate([[ids.sot, ids.lang0, ids.transcribe], hist]).astype(np.int64))
+        B, cur = len(rows), 3 + n
+        toks = np.stack(rows)
+        logits = (r.standard_normal((B, V)) * 2.0).astype(np.float32)
+        for b in range(B):                                 # clear winners in both classes: no near-ties of the rules
+            logits[b, int(r.integers(0, 50000))] += 12.0
+            logits[b, tb + int(r.integers(0, 1501))] += 9.0 if b % 2 else 14.0
+        logits = logits.astype(np.float16).astype(np.float32)
+        dom = []
+        filtered = DR.apply_filters(logits, toks, rules, dominance_out=dom)
+        want_sum = np.zeros(B, dtype=np.float32)
+        want_toks, _ = DR.greedy_update(toks, filtered, want_sum, ids.eot)
+        tok_buf = torch.zeros((B, ld), dtype=torch.int32, device="cuda")
+        tok_buf[:, :cur] = torch.from_numpy(toks).int().cuda()
+        lg = dev(logits.astype(np.float16))
+        s = torch.zeros(B, dtype=torch.float32, device="cuda")
+        n_done = torch.zeros(1, dtype=torch.int32, device="cuda")
+        io = native.WmGreedyIO()
+        io.logits, io.row_stride, io.batch, io.n_vocab = lg.data_ptr(), V, B, V
+        io.tokens, io.tokens_ld, io.cur_len = tok_buf.data_ptr(), ld, cur
+        io.sum_logprobs, io.suppress, io.n_suppress = s.data_ptr(), sup_d.data_ptr(), len(sup)
+        io.blank, io.n_blank = blank_d.data_ptr(), len(fixr["blank"])
+        io.sample_begin, io.eot, io.timestamp_begin = 3, ids.eot, tb
+        io.max_initial_timestamp_index, io.apply_rules, io.n_done = 50, 1, n_done.data_ptr()
+        native.check(lib.wm_greedy_step(C.byref(io), stream()))
+        torch.cuda.synchronize()
+        got = tok_buf[:, cur].cpu().numpy()
+        for b in range(B):
+            assert abs(dom[b]) > 0.05, (n, b, dom[b])      # the case is not a near-tie of the timestamp-dominance rule
+            assert int(got[b]) == int(want_toks[b, -1]), (n, b, int(got[b]), int(want_toks[b, -1]))
+            assert abs(float(s[b]) - float(want_sum[b])) < 2e-4, (n, b)
+
+
 @pytest.mark.gpu
 def test_log_mel_device(lib, golden_dir):
     """wm_log_mel (device STFT + mel) against the reference's log_mel_spectrogram output (tests/golden/mel.npz)
