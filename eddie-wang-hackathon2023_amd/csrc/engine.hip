@@ -491,6 +491,9 @@ int prof_slot(Profiler& pr, int layer, hipStream_t s) {
 struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total; };
 
 int cross_nsplit(int B, int H) {
+    static const int forced = [] { const char* v = getenv("WM_CROSS_NSPLIT"); return v ? atoi(v) : 0; }();      // lab knob (A/B runs)
+    if (forced == -1) return B * H >= 512 ? 1 : 8;            // two classes only
+    if (forced > 0) return forced > 8 ? 8 : forced;
     // fill >= ~2 workgroups per CU with (b, h, split) triples
     int n = (512 + B * H - 1) / (B * H);
     if (n < 1) n = 1;
