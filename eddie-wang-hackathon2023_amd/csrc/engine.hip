@@ -491,15 +491,20 @@ int prof_slot(Profiler& pr, int layer, hipStream_t s) {
 struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total; };
 
 int cross_nsplit(int B, int H) {
-    static const int forced = [] { const char* v = getenv("WM_CROSS_NSPLIT"); return v ? atoi(v) : 0; }();      // lab knob (A/B runs)
-    if (forced == -1) return B * H >= 512 ? 1 : 8;            // two classes only
+    // Pieces the key range of the decode cross-attention is cut into (one workgroup per (utterance, head, piece), partial
+    // softmaxes merged by attn_cross_combine_kernel).  TWO classes only, by the number of (utterance, head) pairs of the group:
+    // fewer than 160 pairs (8 utterances of large-v2) -> 4 pieces, otherwise the exact single pass without a merge launch.
+    // Within a class a row's result does not depend on the batch it is in.  Rounds 1-3 used ceil(512 / pairs) <= 8 pieces
+    // ("two workgroups per CU"): 8 different counts below 26 utterances, i.e. 8 different roundings of the merged softmax,
+    // and no faster -- forced counts, token step in ms (profiles/r3au_cross_nsplit_forced.txt): 1 utterance 1.74 /
+    // 1.65 / 1.58 / 1.58 with 1 / 2 / 4 / 8 pieces, 4 utterances 2.00 / 1.92 / 1.89 / 1.88, 6: 2.09 / 2.04 / 2.01 / 2.06,
+    // 8: 2.15 / 2.16 / 2.13 (4), 12: 2.33 / 2.37 / 2.38 (1 / 2 / 3), 2 x 12: 2.86 / 2.91 / 3.01, 2 x 16: 3.41 / 3.44 / 3.47.
+    // WM_CROSS_NSPLIT=n forces a count (A/B runs), -1 = 8 pieces below 512 pairs, -2 = the old rule.
+    static const int forced = [] { const char* v = getenv("WM_CROSS_NSPLIT"); return v ? atoi(v) : 0; }();
+    if (forced == -1) return B * H >= 512 ? 1 : 8;
+    if (forced == -2) { int n = (512 + B * H - 1) / (B * H); return n < 1 ? 1 : (n > 8 ? 8 : n); }
     if (forced > 0) return forced > 8 ? 8 : forced;
-    // fill >= ~2 workgroups per CU with (b, h, split) triples
-    int n = (512 + B * H - 1) / (B * H);
-    if (n < 1) n = 1;
-    if (n > 8) n = 8;       // B = 1: 8 splits + combine 10.2 us, 16 splits 11.3, 4 splits 10.5 (scripts/bench_cross_small.py); one
-                            // 16-wave workgroup per head over the whole key range, without a combine launch: 12.2
-    return n;
+    return B * H < 160 ? 4 : 1;
 }
 
 DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {

@@ -224,9 +224,10 @@ typedef struct wm_gemv_io {
 int wm_gemv_fused(const wm_gemv_io* io, wm_stream_t stream);
 /* Decoder calls with batch * n_new <= rows activation rows take the fused small-batch path (wm_gemv_fused per Linear);
  * default 16 (or WM_SMALL_PATH; 8 until the end of round 3), 0 = never, at most 32.  Returns the previous value.  A row's result does not depend on
- * the batch it is in on either side of the switch (one exception on both sides: groups of fewer than 512 (utterance, head)
- * pairs split the cross-attention's key range into a number of pieces that follows the group size, and across different
- * piece counts the merged softmax agrees to fp32 summation order); across it the two paths agree to fp32 summation order (a last-bit
+ * the batch it is in on either side of the switch (one more boundary on both sides: groups of fewer than 160 (utterance, head)
+ * pairs -- 8 utterances of large-v2 -- cut the cross-attention's key range into 4 pieces and merge the partial softmaxes,
+ * larger ones run the exact single pass; across that boundary a row's context agrees to fp32 summation order); across the
+ * switch the two paths agree to fp32 summation order (a last-bit
  * difference of fp16 values in rare cases).  Captured graphs keep the path they were captured with.                    */
 int wm_set_small_batch_rows(int rows);
 /* The same Linear (same wm_gemv_io, modes 0-2, optional LayerNorm prologue) for ANY number of rows m: the rows are split over

@@ -1,0 +1,18 @@
+#!/bin/bash
+# forced key-range split counts at 1-6 utterances
+out=gpurun_out/r3av; mkdir -p $out
+common="--steps 2 --warmup 1 --no-cpu-baseline --no-measure-traffic --encoder-cus 0 --length-dist forced"
+for cfg in "b1|1 2" "b2|1" "b3|1 2 4 8" "b4|1 2 4 8" "b5|1 2 4" "b6|1 2 4 8" "b12|1 2 3" "b24|1 2 3"; do
+  IFS='|' read bname splits <<< "$cfg"; b=${bname#b}
+  for n in $splits; do
+    name=${bname}_n$n
+    WM_CROSS_NSPLIT=$n timeout 600 python bench.py $common --batch $b > $out/bench_$name.json 2> $out/bench_$name.err
+    python - <<PY
+import json
+try:
+    d=json.loads(open("$out/bench_$name.json").read().strip().splitlines()[-1]); r=d.get("roofline") or {}
+    print("$name", d["value"], "tok/s; decode step", r.get("decode_step_ms"), "loop", r.get("decode_loop_ms"))
+except Exception as e: print("$name failed", e)
+PY
+  done
+done

@@ -416,6 +416,30 @@ def test_small_batch_path_agrees_with_big_batch_path(tmpdir_module):
     assert all(torch.equal(a[1:2], b) for a, b in zip(small, solo))
 
 
+def test_rows_do_not_depend_on_the_batch_within_a_cross_attention_class(tmpdir_module, one_decode_path):
+    """The decode cross-attention cuts its key range into 4 pieces below 160 (utterance, head) pairs per group and runs the
+    exact single pass from there on -- two classes, not a count that follows the batch size.  tiny shape (6 heads): batches
+    of 2 / 9 / 26 utterances (12 / 54 / 156 pairs) give the same rows bit for bit, so do 27 / 32 (162 / 192); across the
+    boundary the rows agree to the logit tolerance.  (One GEMM path for every size: `one_decode_path`.)"""
+    dims = Dims(**synthetic.DIMS["tiny"])
+    eng = build_engine(tmpdir_module, "tiny", 5)
+    enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(32, 2 * dims.n_audio_ctx, dims.n_mels, 3).cuda())
+
+    def run(b):
+        cross = dec.xa2cross_key_value(xa[:b])
+        lg0, kv = dec.decode(torch.tensor([[50258, 50259, 50359]] * b).cuda(), cross)
+        lg1, _ = dec.decode(torch.tensor([[50363]] * b).cuda(), cross, kv)
+        return lg0[:, -1].clone(), lg1[:, -1].clone()
+    small = {b: run(b) for b in (2, 9, 26)}
+    big = {b: run(b) for b in (27, 32)}
+    for i in range(2):
+        assert torch.equal(small[9][i][:2], small[2][i]) and torch.equal(small[26][i][:9], small[9][i])
+        assert torch.equal(big[32][i][:27], big[27][i])
+        assert float((small[26][i].float() - big[27][i][:26].float()).abs().max()) < LOGIT_TOL
+    assert len({tuple(r) for r in small[26][1].float().cpu().numpy().round(2).tolist()}) > 1      # rows differ: not vacuous
+
+
 def test_batch_independence(tmpdir_module, one_decode_path):
     """Utterances are independent units (the data-parallel sharding relies on it): a batch of 3
     gives the rows it gives one by one."""
