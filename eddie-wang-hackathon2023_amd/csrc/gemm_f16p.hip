@@ -218,6 +218,39 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         st_skip = blockIdx.x == 9 && t == 1 && ks >= 10 && ks < 30;       // (all eight waves of the stamped workgroup)
 #endif
         const unsigned char* st = smem + (cons % STAGES) * STAGE;
+#ifdef WM_GEMM_WHOLE_STAGE
+        // ---- one load interval (all twelve fragments of the stage, four DMA pieces, the stage wait) | barrier | 32 MFMAs | barrier:
+        // two barriers per stage instead of four (lab: the barrier hand-over costs the matrix pipe ~100 cycles each time)
+        half8v bx2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bx2[j] = *(const half8v*)(st + b_off + (4 + j) * 1024);
+        issue_half(1);                               // completes stage cons + STAGES - 2
+        issue_half(0);                               // opens stage cons + STAGES - 1
+        if (issued >= total_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT + N_STORES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT) : "memory");
+        after_epilogue = false;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx[j], af[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx2[j], af[i], acc[i][4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+#else
         // ---- first half of the channels: fragments, DMA requests | barrier | 16 MFMAs | barrier ------------------------
 #if defined(WM_GEMM_STAMPS) && defined(WM_GEMM_STAMP_SKIP)
         if (((WM_GEMM_STAMP_SKIP) & 2) && st_skip) { } else
@@ -278,6 +311,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         WM_ST(6);
         __builtin_amdgcn_s_barrier();
         WM_ST(7);
+#endif
         ++cons;
         if (++ks < nk) continue;
 
