@@ -147,7 +147,7 @@ def cpu_baseline(args, decode_steps: int, time_cap_s: float = 150.0):
     t_step = t_loop / max(n_meas, 1)
     total = t_enc + t_ckv + t_lang + t_pre + (decode_steps - 1) * t_step
     return {
-        "value": round(decode_steps / total, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+        "value": round(decode_steps / total, 3), "unit": "tokens/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
         "rtf": round(total / 30.0, 3),
         "sample": (f"oracle, fp16-input mode, batch 1, {args.model} at full depth ({dims.n_audio_layer}+{dims.n_text_layer} layers): "
                    f"encoder {t_enc:.2f}s, cross-K/V {t_ckv:.2f}s, language-ID pass {t_lang:.2f}s, prefill {t_pre:.2f}s, "
@@ -203,6 +203,27 @@ def measure_traffic(group: int, kv_bytes: int, timeout_s: float = 240.0) -> dict
         return {}
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def rocprof_reference(group: int) -> dict:
+    """Average duration of the dominant kernel over every launch of the committed rocprofv3 --kernel-trace --stats run of the
+    driver's command (newest profiles/*_bench_kernel_stats.csv), for the reader to set beside the HIP-event sample."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), key=os.path.getmtime)
+    for f in reversed(files):
+        try:
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    name = row.get("Name") or row.get("KernelName") or ""
+                    if "attn_cross_kernel<1, false, 0>" in name or "attn_cross_kernelILi1ELb0ELi0" in name:
+                        avg_ns = float(row.get("AverageNs") or row.get("Average") or 0)
+                        if avg_ns > 0:
+                            return {"rocprof_avg_launch_ms": round(avg_ns * 1e-6, 5), "rocprof_calls": int(float(row.get("Calls", 0))),
+                                    "rocprof_source": os.path.relpath(f, ROOT)}
+        except Exception:       # noqa: BLE001
+            continue
+    return {}
 
 
 def librispeech_like_lengths(n: int, t_max: int, seed: int = 2620) -> np.ndarray:
@@ -373,24 +394,39 @@ def main():
 
     loop_events = []            # (start, end) of every decode loop: torch events on the current stream, which main_loop
     last = {}                   # joins with its group streams before it returns
+    stage_events = []           # per step: the stage boundaries (see step())
+    enc.time_prefetch = True    # events around every prefetched encoder pass and around collect()'s wait (encoding.py)
 
     # One step = encoder + cross-K/V + language pass + prefill + decode loop of one batch.  Consecutive steps are software-
     # pipelined the way a transcription job over many batches is (run.py): while the HBM-bound decode loop of batch n runs,
     # the MFMA-bound encoder of batch n + 1 runs beside it on a budget of CUs (WhisperEncoding.prefetch).  Every step's
     # encoder runs inside the region that is timed: the first one in the open, the last decode loop with nothing beside it.
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
     def step(more_to_come: bool):
-        xa = enc.collect() if last.get("prefetched") else enc.get_audio_features_async(mel)
+        # stage boundaries as events on the current stream (main_loop and detect_language join their group streams into it
+        # before they return): s0 | encoder in the open, or the wait for the prefetched one | s1 | cross-K/V projection +
+        # language pass | s2 ... e0 | prefill + decode loop | e1 | gather | s3
+        s0 = mark()
+        was_prefetched = bool(last.get("prefetched"))
+        xa = enc.collect() if was_prefetched else enc.get_audio_features_async(mel)
+        s1 = mark()
         dec.detect_language(xa)
+        s2 = mark()
         last["prefetched"] = bool(args.encoder_cus > 0 and more_to_come)
         if last["prefetched"]:
             enc.prefetch(mel, args.encoder_cus)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0 = mark()
         tokens, sum_lp, _ = dec.main_loop(xa, ignore_eot=True)
-        e1.record()
+        e1 = mark()
         loop_events.append((e0, e1, last["prefetched"]))
         last["xa"] = xa
-        return dp.gather_results(tokens, sum_lp, n_total, width, dec.tokenizer.eot)
+        res = dp.gather_results(tokens, sum_lp, n_total, width, dec.tokenizer.eot)
+        stage_events.append((s0, s1, s2, e0, e1, mark(), was_prefetched))
+        return res
 
     for k in range(args.warmup):
         out = step(k + 1 < args.warmup)
@@ -401,13 +437,37 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     loop_events.clear()
+    stage_events.clear()
+    enc.prefetch_events = []
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = step(k + 1 < args.steps)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = dp.max_over_ranks(my_elapsed, dev)
+    per_rank_ms = dp.all_ranks(my_elapsed / args.steps * 1e3, dev)       # every rank's own ms per step: imbalance shows at a glance
+
+    # ---- where a step's time goes (GPU events of the timed steps; the review's "make the line tell the truth about the schedule") ----
+    def _mean(xs):
+        return round(float(np.mean(xs)), 2) if len(xs) else None
+    pre = list(getattr(enc, "prefetch_events", []))
+    pipeline = {
+        "encoder_in_the_open_ms": _mean([a[0].elapsed_time(a[1]) for a in stage_events if not a[6]]),
+        "encoder_prefetch_ms": _mean([t0e.elapsed_time(t1e) for t0e, t1e, _, _ in pre]),
+        "collect_wait_ms": _mean([a[0].elapsed_time(a[1]) for a in stage_events if a[6]]),
+        "cross_kv_and_language_ms": _mean([a[1].elapsed_time(a[2]) for a in stage_events]),
+        "prefill_and_decode_loop_ms": _mean([a[3].elapsed_time(a[4]) for a in stage_events]),
+        "gather_ms": _mean([a[4].elapsed_time(a[5]) for a in stage_events]),
+        "other_ms": _mean([a[2].elapsed_time(a[3]) for a in stage_events]),
+        "sum_per_step_ms": round(sum(a[0].elapsed_time(a[5]) for a in stage_events) / max(len(stage_events), 1), 2),
+        "note": "means over the timed steps, GPU events on the stream that drives a step: the first step's encoder runs in the open, "
+                "the others beside the previous step's decode loop (encoder_prefetch_ms = that pass on its own stream, start to end; "
+                "collect_wait_ms = what the next step still waits for it after the loop has ended); sum_per_step_ms adds the stages of "
+                "a step (encoder in the open or the wait, cross-K/V projection + language pass, prefill + decode loop, gather) and "
+                "is to be read against ms_per_step (host clock over all steps)",
+    }
 
     # ---- untimed probes after the headline region -------------------------------------------------------------------
     # (a) the encoder alone on the whole chip (MFMA roofline of the other big stage)
@@ -456,6 +516,29 @@ def main():
             dist.barrier()
         r_elapsed = dp.max_over_ranks(time.perf_counter() - t_r, dev)
         loop_ms = [a.elapsed_time(b) for a, b in loops]
+        # the same five batches PIPELINED as the headline's steps are (summarize.py --overlap_encoder): the encoder of batch n + 1 on
+        # --encoder-cus CUs beside the decode loop of batch n
+        rp_elapsed = None
+        if args.encoder_cus > 0:
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t_p = time.perf_counter()
+            xa_p = enc.get_audio_features_async(mel)
+            for i, limits in enumerate(batches):
+                dec.detect_language(xa_p)
+                if i + 1 < len(batches):
+                    enc.prefetch(mel, args.encoder_cus)
+                dec.main_loop(xa_p, row_limit=torch.as_tensor(limits, dtype=torch.int32))
+                if i + 1 < len(batches):
+                    xa_p = enc.collect()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            rp_elapsed = dp.max_over_ranks(time.perf_counter() - t_p, dev)
+        # audio seconds behind the token counts (the inverse of librispeech_like_lengths: 3.6 tokens/s + 2 timestamps)
+        audio_s = float(np.maximum(all_limits - 2, 1).sum() / 3.6) * world
+        best = min(r_elapsed, rp_elapsed) if rp_elapsed else r_elapsed
         kvb = 1 if args.config == "int8x" else 2
         row_bytes = dims["n_text_layer"] * dims["n_text_head"] * 2 * dims["n_audio_ctx"] * 64 * kvb       # cross K/V of one utterance, one token
         live_bytes = [float(l.sum() + B) * row_bytes for l in batches]     # a row is streamed once per token it samples (+ the step that ends it)
@@ -466,6 +549,13 @@ def main():
                                            "per_batch_max": [int(l.max()) for l in batches]},
                   "tokens_match_the_limits": bool((got == batches[0]).all()),
                   "ms_per_batch": round(r_elapsed * 1e3 / n_jobs, 1), "decode_loop_ms": [round(x, 1) for x in loop_ms],
+                  "ms_per_batch_pipelined": round(rp_elapsed * 1e3 / n_jobs, 1) if rp_elapsed else None,
+                  "useful_tokens_per_s_pipelined": round(float(all_limits.sum()) * world / rp_elapsed, 1) if rp_elapsed else None,
+                  "audio_seconds": round(audio_s, 1), "rtf": round(best / audio_s, 6),
+                  "test_clean_estimate_s": round(best * 2620.0 / (n_jobs * B * world), 2),
+                  "test_clean_note": "LibriSpeech test-clean is 2 620 utterances; the reference publishes 1 333 s for it on one A10 at batch 1 "
+                                     "(BASELINE.md: TRT-LLM fp16, plugin flags; other hardware, fp16, real weights) -- this is the time of the "
+                                     f"faster of the two schedules above scaled from {n_jobs * B * world} synthetic clips to 2 620 (context, not a same-node comparison)",
                   "decode_loop_vs_live_row_bytes": round(sum(loop_ms) * 1e-3 / (sum(live_bytes) / 5.66e12), 3),
                   "decode_loop_vs_live_row_bytes_per_batch": [round(m * 1e-3 / (b / 5.66e12), 3) for m, b in zip(loop_ms, live_bytes)],
                   "note": "whole path per batch as in the headline (encoder + cross-K/V + language pass + prefill + decode loop), one stage after "
@@ -505,10 +595,14 @@ def main():
                             for k, v in pmc_traffic(group, kv_bytes).items()}),
                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 5),
                         "samples": int(cnt.value), "utterances_per_launch": group,
+                        **rocprof_reference(group),
                         "note": "HIP events around the eager (language-ID pass) launches of the kernel inside the timed "
                                 "steps, the utterance groups taking turns for that pass so that the kernel has the HBM to "
-                                "itself as it does under rocprofv3 (profiles/*_kernel_stats.csv: same average); the captured "
-                                f"decode graphs replay the same kernel and grid, there {n_micro} groups share the HBM.  The launch is "
+                                "itself; rocprof_avg_launch_ms is the average over EVERY launch of the kernel (language pass, prefill "
+                                "and all token steps) in the committed rocprofv3 --kernel-trace --stats run of the same command, "
+                                "which serialises the queues: the two samples differ by a few percent (the token steps' launches "
+                                "start behind a chain of short kernels, the sampled ones behind another K/V launch); the captured "
+                                f"decode graphs replay the same kernel and grid, there {n_micro} groups share the HBM (in_situ_*).  The launch is "
                                 "persistent (<= 2 workgroups per CU, every workgroup the same number of items) and software-"
                                 "pipelined: with 8 of a CU's 32 wave slots it leaves room for the other groups' short kernels"}
             # ---- the same kernel IN SITU: graph-replayed launches, the groups sharing the HBM (device-side stamps around
@@ -520,9 +614,22 @@ def main():
             if decode_loop_ms is not None:
                 step_ms = decode_loop_ms / T
                 cross_bytes = B * dims["n_text_layer"] * H * 2 * Tk * 64 * kv_bytes          # B x 245.76 MB at large-v2
+                # ALL of SURVEY 8d's bytes of one token step: the decoder's Linear weights and the logits matrix as resident (every
+                # utterance group streams them once per step), the cross K/V of every utterance, the self-attention cache at the
+                # loop's mean length (prefill + T / 2 tokens; one byte per element with the int8 cache, two without)
+                wo_cfg, i8kv_cfg = CONFIGS[args.config]
+                Ct, Lt, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
+                lin_bytes = Lt * 14 * Ct * Ct * (0.5 if wo_cfg == "int4" else 1 if wo_cfg else 2)      # per layer: qkv 3 + out 1, cross q 1 + out 1, mlp 8 (x C^2; the cross k / v projections live in their own engine): 734.0 MB int8 at large-v2
+                logit_bytes = V * Ct * 2
+                self_bytes = B * Lt * 2 * Ct * (dec.initial_token_length + T / 2.0) * (1 if i8kv_cfg else 2)
+                all_bytes = n_micro * (lin_bytes + logit_bytes) + cross_bytes + self_bytes
                 roofline.update({"decode_loop_ms": round(decode_loop_ms, 2), "decode_step_ms": round(step_ms, 3),
-                                 "decode_step_frac": round(cross_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "decode_step_note": "cross-K/V bytes of one token step for the whole batch / (decode loop time / tokens) / 8 TB/s"
+                                 "decode_step_frac": round(all_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "decode_step_bytes": {"linear_weights": int(lin_bytes), "logits_matrix": int(logit_bytes), "utterance_groups": n_micro,
+                                                       "cross_kv": int(cross_bytes), "self_kv_mean": int(self_bytes), "total": int(all_bytes)},
+                                 "decode_step_frac_cross_kv_only": round(cross_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "decode_step_note": "SURVEY 8d bytes of one token step -- (Linear weights + logits matrix) x utterance groups + cross K/V of the "
+                                                     "whole batch + self-attention cache at the loop's mean length -- / (decode loop time / tokens) / 8 TB/s"
                                                      + ("; decode loops with nothing beside them (the last step's)" if shared else "")})
                 if decode_loop_shared_ms is not None:
                     roofline.update({"decode_loop_beside_encoder_ms": round(decode_loop_shared_ms, 2),
@@ -546,7 +653,9 @@ def main():
                       f"Whisper {args.model} " + ("int8 weight-only + int8 KV" if args.config == "int8" else args.config)
                       + "; rtf reported beside it",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 2),
+            "ms_per_step_per_rank": {"min": round(min(per_rank_ms), 2), "max": round(max(per_rank_ms), 2), "all": [round(x, 2) for x in per_rank_ms]},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "rtf": round((ms_per_step * 1e-3) / (B * 30.0), 6),
             "utterances_per_s": round(n_total / (ms_per_step * 1e-3), 2),
@@ -564,10 +673,13 @@ def main():
             # (README.md:178-180: 9.3-11.3 GB at batch 1 on an A10)
             "hbm_bytes_resident": {"engine_weights": int(weight_bytes), "buffers": int(torch_bytes),
                                    "device_in_use": int(total_b - free_b), "batch_per_gpu": B},
+            "pipeline": pipeline,
             "roofline": roofline,
             "second_figure": ragged,
             # arithmetic-order / scheduling knobs read from the environment, echoed when set (defaults otherwise)
             "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WM_")} or None,
+            # what the package did to the HIP runtime's environment (and whether in time), the lab knobs the LIBRARY honoured (WM_LAB=1 only)
+            "runtime": native.runtime_report(),
             "hip_runtime_knobs": {k: os.environ[k] for k in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "GPU_MAX_HW_QUEUES", "AMD_OPT_FLUSH") if k in os.environ},
         }
         if not args.no_cpu_baseline and world == 1:

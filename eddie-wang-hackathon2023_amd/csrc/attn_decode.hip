@@ -851,7 +851,7 @@ __global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams 
 
 // lab (WM_CROSS_UNR=2): the single-token fp16 kernel with 2 loads per block instead of 4: 78 registers (80 allocated) instead of 92 (96)
 static bool cross_unr2() {
-    static const bool v = [] { const char* e = getenv("WM_CROSS_UNR"); return e && atoi(e) == 2; }();
+    static const bool v = lab_env_int("WM_CROSS_UNR", 4) == 2;
     return v;
 }
 
@@ -865,7 +865,7 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
     // one workgroup per item.  The kernel alone is as fast either way (6.3-6.7 TB/s), but with 8 of a CU's 32 wave slots
     // it leaves room for the OTHER utterance group's short kernels to be dispatched while it streams: 13.2 instead of
     // 13.9 ms per decode step at B = 256 (WM_CROSS_PERSIST_WGS overrides the workgroup count, 0 = one per item).
-    static const int persist_env = [] { const char* v = getenv("WM_CROSS_PERSIST_WGS"); return v ? atoi(v) : -1; }();
+    static const int persist_env = lab_env_int("WM_CROSS_PERSIST_WGS", -1);
     // CU count of the device this launch goes to, cached per device (a process may drive several GPUs from several threads)
     static std::atomic<int> n_cu_dev[64];
     int dev = 0;

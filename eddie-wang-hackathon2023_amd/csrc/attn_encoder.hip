@@ -203,6 +203,8 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
                 }
             l_run[qb] = __fmaf_rn(l_run[qb], alpha[qb], ps);     // this lane's keys only; the four lanes of a query meet at the end
         }
+        // (Round 4 tried the test per block of 16 queries -- a block's maxima move half as often as the wave's 64 -- : four ballots
+        // and branches per tile instead of one, 1.5 % SLOWER at B = 128 / 256, profiles/r4a_attn_rescale_per_block_ab.log.)
         if (any_moved) {                            // skip the accumulator round trip while no query's maximum moved (alpha == 1 exactly)
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
@@ -271,7 +273,7 @@ int launch_attn_encoder(const AttnEncParams& p, hipStream_t stream) {
     // the faster variant at every batch size for T = 1500 (B = 1: 60 vs 67 us, B = 128: 21 vs 36 us per clip-layer).
     // The choice depends on T only, never on the batch: the two instantiations agree to one fp16 ulp, not bit for bit,
     // and the result of a clip must not depend on how many clips share the launch (tests: batch independence).
-    static const int lab_wgs = [] { const char* v = getenv("WM_ATTN_MAX_WGS"); return v ? atoi(v) : 0; }();        // probes only (scripts/kv_beside_probe.py)
+    static const int lab_wgs = lab_env_int("WM_ATTN_MAX_WGS", 0);        // probes only (scripts/kv_beside_probe.py; honoured under WM_LAB=1)
     const int max_wgs = p.max_wgs > 0 ? p.max_wgs : lab_wgs;
     const int heads8 = 8 * ((p.H * p.B + 7) / 8);            // items: see the kernel (8 heads x nx query tiles per group)
     if (p.T > 128 && max_wgs > 0 && max_wgs < ((p.T + 255) / 256) * p.H * p.B) {

@@ -46,6 +46,15 @@ int post_launch_check(hipStream_t s, const char* what);
         if (_r) return _r;                                                                  \
     } while (0)
 
+// ---- lab knobs ---------------------------------------------------------------------------------
+// Environment variables that change a schedule or the order of fp32 sums exist for A/B runs only (scripts/).  The
+// library honours them ONLY when WM_LAB=1 is in the environment too, says so once per knob on stderr and lists them through
+// wm_lab_knobs() (bench.py echoes that list in its line); without WM_LAB=1 a knob that is set is ignored, with one warning.
+// Call sites cache the value in a function-local static: a knob is read once per process.  (WM_SYNC_CHECK, a debugging aid that
+// changes no result, does not need WM_LAB.)
+int lab_env_int(const char* name, int dflt);
+const char* lab_env_str(const char* name);          // nullptr unless set and WM_LAB=1
+
 // ---- device helpers ------------------------------------------------------------------
 // Wave-wide reductions as an xor butterfly from 32 down to 1, entirely inside the ALU: v_permlane32_swap / v_permlane16_swap
 // (gfx950) for the two cross-row steps, DPP row rotations and quad permutations for the rest.  __shfl_xor compiles to
@@ -161,7 +170,10 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + f
 // The same arithmetic on two values at a time: the multiplies and fused multiply-adds become packed fp32 instructions
 // (v_pk_mul_f32 / v_pk_fma_f32: two values per issue), rcp and exp2 stay one per value.  Every operation is the scalar
 // function's, in its order, so the results are bit-identical (scripts/lab/gemm_lab3.hip compares a GEMM that uses this
-// form with one that uses the scalar form, element by element).
+// form with one that uses the scalar form, element by element).  Round 4 re-measured the scalar form in the persistent GEMM's
+// GELU epilogue (no SLP re-packing: 1 793 plain + 256 transcendental instructions per wave and tile against 896 packed + 256,
+// and 74 instead of 335 hazard s_nops): 892-893 against 895-900 TFLOP/s on mlp1 -- the packed form stays
+// (profiles/r4a_gemm_gelu_scalar_ab.log).
 __device__ __forceinline__ float2v gelu_erf2(float2v x) {
     const float2v xs = x * 0.70710678118654752f;
     const float2v ax = {fabsf(xs[0]), fabsf(xs[1])};

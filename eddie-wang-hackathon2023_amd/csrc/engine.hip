@@ -43,6 +43,34 @@ int post_launch_check(hipStream_t s, const char* what) {
     return 0;
 }
 
+// ---- lab knobs (common.h) ------------------------------------------------------------------------
+namespace {
+std::mutex g_lab_mu;
+std::string g_lab_honoured;                 // "NAME=value;..." of every knob honoured so far
+std::map<std::string, int> g_lab_seen;      // 1: honoured and logged, 2: ignored and warned
+}  // namespace
+const char* lab_env_str(const char* name) {
+    const char* v = getenv(name);
+    if (!v) return nullptr;
+    const char* lab = getenv("WM_LAB");
+    const bool on = lab && lab[0] == '1';
+    std::lock_guard<std::mutex> lk(g_lab_mu);
+    int& seen = g_lab_seen[name];
+    if (on && seen != 1) {
+        fprintf(stderr, "whisper_mi355: lab knob %s=%s honoured (WM_LAB=1): results or timings may differ from the product's\n", name, v);
+        g_lab_honoured += std::string(name) + "=" + v + ";";
+        seen = 1;
+    } else if (!on && seen == 0) {
+        fprintf(stderr, "whisper_mi355: %s=%s is set but WM_LAB is not 1: ignored (lab knobs are for A/B runs only)\n", name, v);
+        seen = 2;
+    }
+    return on ? v : nullptr;
+}
+int lab_env_int(const char* name, int dflt) {
+    const char* v = lab_env_str(name);
+    return v ? atoi(v) : dflt;
+}
+
 // ---- blob format (written by weight.py: write_engine_blob) ---------------------------------------
 #pragma pack(push, 1)
 struct BlobHeader {
@@ -500,7 +528,7 @@ int cross_nsplit(int B, int H) {
     // 1.65 / 1.58 / 1.58 with 1 / 2 / 4 / 8 pieces, 4 utterances 2.00 / 1.92 / 1.89 / 1.88, 6: 2.09 / 2.04 / 2.01 / 2.06,
     // 8: 2.15 / 2.16 / 2.13 (4), 12: 2.33 / 2.37 / 2.38 (1 / 2 / 3), 2 x 12: 2.86 / 2.91 / 3.01, 2 x 16: 3.41 / 3.44 / 3.47.
     // WM_CROSS_NSPLIT=n forces a count (A/B runs), -1 = 8 pieces below 512 pairs, -2 = the old rule.
-    static const int forced = [] { const char* v = getenv("WM_CROSS_NSPLIT"); return v ? atoi(v) : 0; }();
+    static const int forced = lab_env_int("WM_CROSS_NSPLIT", 0);
     if (forced == -1) return B * H >= 512 ? 1 : 8;
     if (forced == -2) { int n = (512 + B * H - 1) / (B * H); return n < 1 ? 1 : (n > 8 ? 8 : n); }
     if (forced > 0) return forced > 8 ? 8 : forced;
@@ -582,8 +610,7 @@ std::atomic<int> g_small_rows{-1};        // -1: not yet read from the environme
 int small_path_max_rows() {               // WM_SMALL_PATH=<rows> / wm_set_small_batch_rows: the fused path serves M <= rows (0: never)
     int r = g_small_rows.load(std::memory_order_relaxed);
     if (r < 0) {
-        const char* v = getenv("WM_SMALL_PATH");
-        r = v ? atoi(v) : SMALL_PATH_DEFAULT_ROWS;
+        r = lab_env_int("WM_SMALL_PATH", SMALL_PATH_DEFAULT_ROWS);
         r = r < 0 ? 0 : (r > GEMV_SMALL_MAX_M ? GEMV_SMALL_MAX_M : r);
         g_small_rows.store(r, std::memory_order_relaxed);
     }
@@ -601,9 +628,7 @@ std::atomic<int> g_rows_min{-1};          // -1: not yet read from the environme
 int rows_path_min_rows() {
     int r = g_rows_min.load(std::memory_order_relaxed);
     if (r < 0) {
-        const char* on = getenv("WM_ROWS_PATH");
-        const char* v = getenv("WM_ROWS_MIN");
-        r = (on && atoi(on) == 0) ? 0 : (v ? atoi(v) : 40);
+        r = lab_env_int("WM_ROWS_PATH", 1) == 0 ? 0 : lab_env_int("WM_ROWS_MIN", 40);
         if (r < 0) r = 0;
         g_rows_min.store(r, std::memory_order_relaxed);
     }
@@ -616,8 +641,7 @@ std::atomic<int> g_self_waves{-1};
 int self_attn_waves(int rows) {
     int w = g_self_waves.load(std::memory_order_relaxed);
     if (w < 0) {
-        const char* v = getenv("WM_SELF_WAVES");
-        w = v ? atoi(v) : 0;
+        w = lab_env_int("WM_SELF_WAVES", 0);
         if (w != 1 && w != 4) w = 0;
         g_self_waves.store(w, std::memory_order_relaxed);
     }
@@ -649,7 +673,7 @@ struct GroupStep {
     // diagnostic (WM_TIMELINE_FINE=1 with wm_debug_timeline): a stamp behind EVERY kernel of the chain, code 1000 + 32 * layer + position
     // (scripts/chain_probe.py turns them into in-situ durations per chain position); the K/V launch keeps its own pair of stamps
     void mark(int layer, int pos, hipStream_t s) {
-        static const bool fine = [] { const char* v = getenv("WM_TIMELINE_FINE"); return v && v[0] == '1'; }();
+        static const bool fine = lab_env_int("WM_TIMELINE_FINE", 0) == 1;
         if (fine && prof->timeline)
             hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, prof->timeline, prof->timeline_cap, (long long)(uintptr_t)io->logits, (long long)(1000 + 32 * layer + pos));
     }
@@ -1036,6 +1060,18 @@ int wm_gemm_rows(const wm_gemv_io* io, wm_stream_t stream) {
     p.out32 = io->out32; p.ld32 = io->ld32; p.out16 = (h16*)io->out16; p.ld16 = io->ld16; p.n_valid = io->n_valid;
     p.x = (h16*)io->x; p.ldx = io->ldx;
     return launch_gemm_rows(p, (hipStream_t)stream);
+}
+
+int wm_lab_knobs(char* buf, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_lab_mu);
+    if (buf && cap > 0) { strncpy(buf, g_lab_honoured.c_str(), cap - 1); buf[cap - 1] = 0; }
+    return (int)g_lab_honoured.size();
+}
+
+int wm_set_gemm_small_tiles(int tiles) {
+    const int prev = get_gemm_small_tiles();
+    set_gemm_small_tiles(tiles);
+    return prev;
 }
 
 int wm_set_self_attn_waves(int waves) {

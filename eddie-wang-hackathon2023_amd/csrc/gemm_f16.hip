@@ -22,20 +22,36 @@
 // ds_read_b128 fragment read (16 rows x one chunk) hit 64 distinct banks.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace wm {
 
 namespace f16gemm {
-constexpr int BM = 256, BK = 64, STAGES = 2, NWAVE = 8;
+constexpr int BK = 64;
 }  // namespace f16gemm
 
-// BN = 256 (N % 256 == 0: every large-v2 shape) or 128.  8 waves as 4 (M) x 2 (N); a wave owns
+// BN = 256 (N % 256 == 0: every large-v2 shape) or 128.  NWAVE = 8 waves as 4 (M) x 2 (N), a 256-row tile; a wave owns
 // 64 x BN/2 outputs = 4 x TN MFMA blocks.
-template <int BN, int ACT>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU (compile-time: keeps the epilogue small)
-__global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
+// NWAVE = 4 (round 4, BN = 128 only): 2 x 2 waves on a 128 x 128 tile, 64 KB of LDS, two workgroups per CU -- the form for
+// FEW ROWS (one to a few clips: M = 1500 .. ~12 000).  There the 256 x 256 tiles of the persistent kernel are too few for the
+// chip (M = 1500, N = 1280: 30 tiles for 256 CUs, each running the whole K alone; the batch-1 encoder spent 10.5 ms at 216
+// TFLOP/s).  An output element is the same chain of MFMA 16x16x32 steps over K in every tile shape, and the epilogue is this
+// kernel's own: results are bit-identical to the 256 x 256 forms (tests: test_gemm_small_tiles_bit_identical), so a clip's
+// encoder output still does not depend on how many clips share the launch.
+// What did NOT help at one tile per CU (M = 1500, N = 1280: 120 tiles; profiles/r4b_*): a 4-deep ring with counted waits, and eight
+// waves on the 128 x 128 tile -- out / mlp2 stayed at 19.8 / 58 us to the microsecond in all three forms.  A lone tile is bound
+// by what ONE CU can take in from beyond its XCD's L2 (~45 GB/s: 120 workgroups x 2.6 MB of A and W panels at K = 5120 = 58 us),
+// not by how the workgroup is organised; smaller tiles use more CUs and read proportionally more, and a K split would change the
+// order of the fp32 sums (a clip's output must not depend on its batch).
+template <int NWAVE, int BN, int ACT>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU (compile-time: keeps the epilogue small)
+__global__ __launch_bounds__(NWAVE * 64, 2) void gemm_f16_kernel(GemmBigParams p) {
     using namespace f16gemm;
+    constexpr int TM = 4, ROWS_W = 16 * TM;                   // a wave owns 64 rows x BN / 2 channels; two-stage ring
+    constexpr int BM = NWAVE / 2 * ROWS_W;
+    static_assert((BM + BN) / 8 % NWAVE == 0, "DMA pieces must divide evenly over the waves");
     constexpr int A_STAGE = BM * BK * 2, B_STAGE = BN * BK * 2, STAGE = A_STAGE + B_STAGE;
     constexpr int LOADS = (BM + BN) / 8 / NWAVE;          // wave-wide 1 KiB DMA loads per wave per K-tile
     constexpr int TN = BN / 2 / 16;
@@ -82,9 +98,9 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
     };
 
     // acc[i][j] = D block of W_j . A_i^T: rows = 4 output channels (4g + r), col = token row (lane & 15)
-    float4v acc[4][TN];
+    float4v acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
@@ -92,10 +108,10 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
     issue(0, 0);
     // the second-dispatched half of the workgroup loses every issue arbitration against its SIMD partner; a static
     // priority for it evens the two out (+3-4 % on the K loop, scripts/lab/gemm_lab.hip)
-    if (wid >= 4) __builtin_amdgcn_s_setprio(1);
+    if (NWAVE == 8 && wid >= 4) __builtin_amdgcn_s_setprio(1);
 
     const int swz = (lane & 15) >> 1, g = lane >> 4;
-    const int a_off = (wr * 64 + (lane & 15)) * 128;
+    const int a_off = (wr * ROWS_W + (lane & 15)) * 128;
     const int b_off = A_STAGE + (wc * (BN / 2) + (lane & 15)) * 128;
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -107,13 +123,13 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int pos = ((4 * s + g) ^ swz) * 16;
-            half8v af[4], bf[TN];
+            half8v af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 16 * 128 + pos);
+            for (int i = 0; i < TM; ++i) af[i] = *(const half8v*)(st + a_off + i * 16 * 128 + pos);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *(const half8v*)(st + b_off + j * 16 * 128 + pos);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
@@ -139,8 +155,8 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
     // instructions and 1 100 branches -- more than the instruction cache -- and cost more than the K loop)
     const int colw = col0 + wc * WN_COLS + g * 4;                   // this lane's first column
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + wr * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < TM; ++i) {
+        const int row = row0 + wr * ROWS_W + i * 16 + (lane & 15);
         const int rowc = row < p.M ? row : p.M - 1;
         half4v r4[TN];
         if (p.residual) {                                           // all of this row's residual loads first
@@ -207,34 +223,49 @@ __global__ __launch_bounds__(512) void gemm_f16_kernel(GemmBigParams p) {
     }
 }
 
+// 256 x 256 tiles a launch must have before the persistent kernel takes it; below, 128 x 128 tiles on two workgroups per CU.
+// Measured on MI355X (scripts/bench_gemm_small.py, profiles/r4a_*): see DESIGN.md section 4.  wm_set_gemm_small_tiles() moves it
+// (tests pin either side; <= 0 restores the default).
+static std::atomic<int> g_small_tiles{GEMM_SMALL_TILES_DEFAULT};
+void set_gemm_small_tiles(int tiles) { g_small_tiles.store(tiles > 0 ? tiles : (tiles == 0 ? 0 : GEMM_SMALL_TILES_DEFAULT), std::memory_order_relaxed); }
+int get_gemm_small_tiles() { return g_small_tiles.load(std::memory_order_relaxed); }
+
 int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream) {
     using namespace f16gemm;
     // every large-v2 shape (N a multiple of 256) takes the persistent kernel of gemm_f16p.hip: same arithmetic, bit for bit
-    // (scripts/lab/gemm_lab3.hip compares the two element by element); WM_GEMM_ROUND1=1 keeps this file's kernel (A/B runs)
-    static const bool round1 = [] { const char* v = getenv("WM_GEMM_ROUND1"); return v && v[0] == '1'; }();
-    if (!round1 && gemm_f16p_supports(p)) return launch_gemm_f16p(p, stream);
+    // (scripts/lab/gemm_lab3.hip compares the two element by element) -- unless the launch has too few 256 x 256 tiles to
+    // fill the chip (a few clips): then this file's 128 x 128 form.  A launch on a budget of CUs (max_wgs) is persistent.
+    const bool few = p.max_wgs <= 0 && p.N % 128 == 0 &&
+                     (long)((p.M + 255) / 256) * ((p.N + 255) / 256) < (long)g_small_tiles.load(std::memory_order_relaxed);
+    if (!few && gemm_f16p_supports(p)) return launch_gemm_f16p(p, stream);
     WM_REQUIRE(p.N % 128 == 0, "gemm_f16: N=%d must be a multiple of 128", p.N);
     WM_REQUIRE(p.K % BK == 0, "gemm_f16: K=%d must be a multiple of %d", p.K, BK);
     WM_REQUIRE(p.lda % 8 == 0, "gemm_f16: lda=%d must be a multiple of 8 (16-byte loads)", p.lda);
     WM_REQUIRE(p.ldc % 8 == 0 && p.ldr % 8 == 0, "gemm_f16: ldc/ldr must be multiples of 8 (16-byte epilogue accesses)");
     WM_REQUIRE(p.M > 0, "gemm_f16: empty M");
-    const bool wide = (p.N % 256 == 0);
-    const int bn = wide ? 256 : 128;
-    const int grid = ((p.M + BM - 1) / BM) * (p.N / bn);
-    const size_t lds = (size_t)STAGES * (BM + bn) * BK * 2;         // the K-tile ring
     WM_REQUIRE(p.act >= 0 && p.act <= 2, "gemm_f16: act=%d", p.act);
+    const int form = few ? 2 : (p.N % 256 == 0 ? 0 : 1);           // 0: 256 x 256, 1: 256 x 128, 2: 128 x 128 (4 waves, two workgroups per CU)
+    const int bm = form == 2 ? 128 : 256, bn = form == 0 ? 256 : 128;
+    const int grid = ((p.M + bm - 1) / bm) * (p.N / bn);
+    static std::atomic<unsigned long long> attr_set{0};             // per device: the dynamic-LDS attribute is a per-device property
+    int dev = 0;
+    WM_CHECK_HIP(hipGetDevice(&dev));
+    const int slot = dev & 63;
     using Kern = void (*)(GemmBigParams);
-    static const Kern kerns[2][3] = {{gemm_f16_kernel<256, 0>, gemm_f16_kernel<256, 1>, gemm_f16_kernel<256, 2>},
-                                     {gemm_f16_kernel<128, 0>, gemm_f16_kernel<128, 1>, gemm_f16_kernel<128, 2>}};
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (int a = 0; a < 3; ++a) {
-            WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[0][a], hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * (BM + 256) * BK * 2));
-            WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[1][a], hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * (BM + 128) * BK * 2));
-        }
-        attr_set = true;
+    static const Kern kerns[3][3] = {{gemm_f16_kernel<8, 256, 0>, gemm_f16_kernel<8, 256, 1>, gemm_f16_kernel<8, 256, 2>},
+                                     {gemm_f16_kernel<8, 128, 0>, gemm_f16_kernel<8, 128, 1>, gemm_f16_kernel<8, 128, 2>},
+                                     {gemm_f16_kernel<4, 128, 0>, gemm_f16_kernel<4, 128, 1>, gemm_f16_kernel<4, 128, 2>}};
+    static const int rows_of[3] = {256, 256, 128}, cols_of[3] = {256, 128, 128};
+    const unsigned long long bit = 1ull << slot;
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        for (int f = 0; f < 3; ++f)
+            for (int a = 0; a < 3; ++a)
+                WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[f][a], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 2 * (rows_of[f] + cols_of[f]) * BK * 2));
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kerns[wide ? 0 : 1][p.act], dim3(grid), dim3(512), lds, stream, p);
+    const size_t lds = (size_t)2 * (bm + bn) * BK * 2;              // the two-stage K-tile ring
+    hipLaunchKernelGGL(kerns[form][p.act], dim3(grid), dim3(form == 2 ? 256 : 512), lds, stream, p);
     WM_LAUNCH_CHECK(stream, "gemm_f16");
     return 0;
 }

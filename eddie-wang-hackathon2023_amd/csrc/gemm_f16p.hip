@@ -47,21 +47,6 @@
 
 namespace wm {
 
-// Diagnostic build only (-DWM_GEMM_STAMPS=<point mask>, scripts/gemm_interval_stamps.py): core-clock stamps (s_memtime) of one
-// workgroup's waves 0 and 4 at the interval boundaries of 16 consecutive K stages of its second tile, kept in LDS (a global store
-// inside the K loop would enter the counted vmcnt waits) and copied out at the end.  Nothing of this exists in the product build.
-#ifdef WM_GEMM_STAMPS
-__device__ unsigned long long* g_gemm_stamps = nullptr;            // [2 waves][16 stages][10 points]
-extern "C" int wm_debug_gemm_stamps(unsigned long long* buf) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
-}
-#define WM_ST(pt) do { if (((WM_GEMM_STAMPS) >> (pt)) & 1) { if (st_on) { \
-        const unsigned long long st_t = __builtin_amdgcn_s_memtime(); \
-        if (lane == 0) st_lds[(ks - 12) * 10 + (pt)] = st_t; } } } while (0)
-#else
-#define WM_ST(pt) do {} while (0)
-#endif
-
 namespace f16p {
 constexpr int BM = 256, BN = 256, BK = 32, NWAVE = 8;
 constexpr int A_PART = BM * BK * 2, STAGE = (BM + BN) * BK * 2;      // 16 KB + 16 KB
@@ -145,25 +130,13 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         }
     };
     int load_ks = 0, load_tile = 0, issued = 0;      // stage whose pieces are requested next (issued = its stream number)
-#ifdef WM_GEMM_STAMPS
-    bool st_skip = false;                            // WM_GEMM_STAMP_SKIP & 1: no DMA requests, & 2: no fragment reads in the stamped stages (timing only: the data are stale)
-#endif
     auto issue_half = [&](int half) {                // this wave's A piece and W piece number `half` of stream stage `issued`
         if (issued >= total_stages) return;
         unsigned char* slot = smem + (issued % STAGES) * STAGE + (wid + NWAVE * half) * 1024;
-#if defined(WM_GEMM_STAMPS) && defined(WM_GEMM_STAMP_SKIP)
-        if (((WM_GEMM_STAMP_SKIP) & 1) && st_skip) { } else
-#endif
-        {
-        if (p.nt_flags & 1)        // (wave-uniform) A panels as non-temporal requests: lab knob WM_GEMM_NT, see launch_gemm_f16p
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
-                                             (__attribute__((address_space(3))) void*)slot, 16, 0, 2);
-        else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
-                                             (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
+                                         (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_lane[half]),
                                          (__attribute__((address_space(3))) void*)(slot + A_PART), 16, 0, 0);
-        }
         if (half == 1) {
             a_base += BK * 2; w_base += BK * 2;
             ++issued;
@@ -207,65 +180,16 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
             for (int j = 0; j < 8; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-#ifdef WM_GEMM_STAMPS
-    unsigned long long* st_lds = (unsigned long long*)(smem + STAGES * STAGE + MAX_N * 2) + (wid >> 2) * 160;
-    const bool st_wg = blockIdx.x == 9 && (wid == 0 || wid == 4) && g_gemm_stamps != nullptr;
-    if (st_wg && lane < 2) for (int q = lane; q < 160; q += 2) st_lds[q] = 0ull;
-#endif
     for (;;) {
-#ifdef WM_GEMM_STAMPS
-        const bool st_on = st_wg && t == 1 && ks >= 12 && ks < 28;
-        st_skip = blockIdx.x == 9 && t == 1 && ks >= 10 && ks < 30;       // (all eight waves of the stamped workgroup)
-#endif
         const unsigned char* st = smem + (cons % STAGES) * STAGE;
-#ifdef WM_GEMM_WHOLE_STAGE
-        // ---- one load interval (all twelve fragments of the stage, four DMA pieces, the stage wait) | barrier | 32 MFMAs | barrier:
-        // two barriers per stage instead of four (lab: the barrier hand-over costs the matrix pipe ~100 cycles each time)
-        half8v bx2[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + j * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bx2[j] = *(const half8v*)(st + b_off + (4 + j) * 1024);
-        issue_half(1);                               // completes stage cons + STAGES - 2
-        issue_half(0);                               // opens stage cons + STAGES - 1
-        if (issued >= total_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT + N_STORES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT) : "memory");
-        after_epilogue = false;
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx[j], af[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx2[j], af[i], acc[i][4 + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-#else
         // ---- first half of the channels: fragments, DMA requests | barrier | 16 MFMAs | barrier ------------------------
-#if defined(WM_GEMM_STAMPS) && defined(WM_GEMM_STAMP_SKIP)
-        if (((WM_GEMM_STAMP_SKIP) & 2) && st_skip) { } else
-#endif
-        {
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + j * 1024);
-        }
         issue_half(1);                               // completes stage cons + STAGES - 2
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        WM_ST(0);
-        WM_ST(8);                                    // (a second stamp: the first one's wait has absorbed the fragment reads' wait)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -274,32 +198,21 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        WM_ST(1);
         __builtin_amdgcn_s_barrier();
-        WM_ST(2);
         // ---- second half ------------------------------------------------------------------------------------------------
-#if defined(WM_GEMM_STAMPS) && defined(WM_GEMM_STAMP_SKIP)
-        if (((WM_GEMM_STAMP_SKIP) & 2) && st_skip) { } else
-#endif
-        {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + (4 + j) * 1024);
-        }
         issue_half(0);                               // opens stage cons + STAGES - 1
         // Stage cons + 1 is read by waves 0-3 two barriers from here (one for waves 4-7): this wave's pieces of it must have
         // landed before the next barrier.  Its last pieces were requested STAGES - 3 stages ago; WAIT younger requests may stay
         // in flight -- plus, on the first stage after an epilogue, the epilogue's stores, which sit behind those pieces in the
         // queue and must not be waited for here (they drain while the next stage is multiplied).
-        WM_ST(3);
         if (issued >= total_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT + N_STORES) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT) : "memory");
         after_epilogue = false;
         __builtin_amdgcn_sched_barrier(0);
-        WM_ST(4);
         __builtin_amdgcn_s_barrier();
-        WM_ST(5);
-        WM_ST(9);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -308,10 +221,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                 acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bx[j], af[i], acc[i][4 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        WM_ST(6);
         __builtin_amdgcn_s_barrier();
-        WM_ST(7);
-#endif
         ++cons;
         if (++ks < nk) continue;
 
@@ -398,15 +308,9 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                     if constexpr (SIMPLE) {
                         if (row < p.M) {
                             h16* crow = p.C + (size_t)row * p.ldc + colp;
-                            if (p.nt_flags & 4) {          // (wave-uniform) lab knob: non-temporal stores of C
 #pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    __builtin_nontemporal_store(half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]}, (half4v*)(crow + j * 16));
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    *(half4v*)(crow + j * 16) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
-                            }
+                            for (int j = 0; j < 4; ++j)
+                                *(half4v*)(crow + j * 16) = half4v{(h16)v[j][0], (h16)v[j][1], (h16)v[j][2], (h16)v[j][3]};
                         }
                     } else if (row < p.M) {
                         if (p.out_mode == 0) {
@@ -556,9 +460,6 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         zero_acc();
         if (wid >= 4) __builtin_amdgcn_s_barrier();  // one barrier behind waves 0-3 again
     }
-#ifdef WM_GEMM_STAMPS
-    if (st_wg && lane == 0) for (int q = 0; q < 160; ++q) g_gemm_stamps[(wid >> 2) * 160 + q] = st_lds[q];
-#endif
 }
 
 bool gemm_f16p_supports(const GemmBigParams& p) {
@@ -582,11 +483,7 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     using Kern = void (*)(GemmBigParams);
     static const Kern kerns[6] = {gemm_f16p_kernel<STAGES, 0>, gemm_f16p_kernel<STAGES, 1>, gemm_f16p_kernel<STAGES, 2>,
                                   gemm_f16p_kernel<STAGES, 0, true>, gemm_f16p_kernel<STAGES, 1, true>, gemm_f16p_kernel<STAGES, 2, true>};
-#ifdef WM_GEMM_STAMPS
-    constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE + MAX_N * 2 + 4096;
-#else
     constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE + MAX_N * 2;
-#endif
     if (n_cu == 0) {
         int v = 0;
         WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
@@ -599,7 +496,7 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     const int n_tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     int grid = (n_cu / 8) * 8;
     if (grid < 8) grid = 8;
-    static const int lab_wgs = [] { const char* v = getenv("WM_GEMM_MAX_WGS"); return v ? atoi(v) : 0; }();      // probes only (scripts/kv_beside_probe.py)
+    static const int lab_wgs = lab_env_int("WM_GEMM_MAX_WGS", 0);      // probes only (scripts/kv_beside_probe.py; honoured under WM_LAB=1)
     const int max_wgs = p.max_wgs > 0 ? p.max_wgs : lab_wgs;
     if (max_wgs > 0 && max_wgs < grid) grid = max_wgs >= 8 ? (max_wgs / 8) * 8 : 8;
     const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
@@ -607,11 +504,9 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f && !(p.residual && p.colscale_n > 0) &&
                         (p.act == 0 || (!p.residual && p.colscale_n <= 0)) &&
                         p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));      // 16-byte epilogue accesses
-    static const int lab_rows = [] { const char* v = getenv("WM_GEMM_TILE_ROWS"); return v ? atoi(v) : 0; }();    // A/B runs: 1 = the plain row-major tile order
-    static const int lab_nt = [] { const char* v = getenv("WM_GEMM_NT"); return v ? atoi(v) : 0; }();             // A/B runs: 1 = A panels nt, 4 = C stores nt, 5 = both
+    static const int lab_rows = lab_env_int("WM_GEMM_TILE_ROWS", 0);    // A/B runs (WM_LAB=1): 1 = the plain row-major tile order
     GemmBigParams q = p;
     if (q.tile_rows <= 0) q.tile_rows = lab_rows;
-    q.nt_flags = lab_nt;
     hipLaunchKernelGGL(kerns[p.act + (simple ? 3 : 0)], dim3(grid), dim3(512), LDS_BYTES, stream, q);
     WM_LAUNCH_CHECK(stream, "gemm_f16p");
     return 0;

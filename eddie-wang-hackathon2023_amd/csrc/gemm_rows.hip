@@ -307,8 +307,8 @@ int launch_gemm_rows(const GemvSmallParams& p, hipStream_t stream) {
     WM_REQUIRE(p.mode != 2 || p.ldx >= n_full, "gemm_rows: ldx=%d < 16 * n_blocks = %d", p.ldx, n_full);
     // rows per workgroup: 32 (two MFMA row tiles) from 17 rows on; 8 waves (128 channels) per workgroup from 2560 channels on:
     // choices by the shapes only, and none of them touches a row's arithmetic
-    static const int lab_mt = [] { const char* v = getenv("WM_ROWS_MT"); return v ? atoi(v) : 0; }();      // A/B runs: 1 | 2
-    static const int lab_nw = [] { const char* v = getenv("WM_ROWS_NW"); return v ? atoi(v) : 0; }();      // A/B runs: 4 | 8
+    static const int lab_mt = lab_env_int("WM_ROWS_MT", 0);      // A/B runs (WM_LAB=1): 1 | 2
+    static const int lab_nw = lab_env_int("WM_ROWS_NW", 0);      // A/B runs (WM_LAB=1): 4 | 8
     const int MT = lab_mt == 1 ? 1 : (p.M > 16 ? 2 : 1);
     const int NW = lab_nw == 4 || lab_nw == 8 ? lab_nw : (p.n_blocks >= 160 ? 8 : 4);
     const int n_ms = (p.M + 16 * MT - 1) / (16 * MT), n_cg = (p.n_blocks + NW - 1) / NW;

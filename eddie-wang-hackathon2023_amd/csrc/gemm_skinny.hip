@@ -220,7 +220,7 @@ int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
     // 12 % of what the cross-attention kernel streams -- and next to that kernel the chain of short kernels is
     // throughput-bound, not latency-bound.  4 slices: 26.0 instead of 26.9 ms per decode step at B = 576 (8 are 5 % faster
     // for a kernel running alone, scripts/bench_skinny.py).  WM_KSPLIT_CAP overrides (experiments).
-    static const int cap_env = [] { const char* v = getenv("WM_KSPLIT_CAP"); return v ? atoi(v) : 4; }();
+    static const int cap_env = lab_env_int("WM_KSPLIT_CAP", 4);
     s = min(s, cap_env);
     return max(1, s);
 }
@@ -232,13 +232,13 @@ int skinny_default_ksplit(int M, int K, int n_blocks, int w8) {
 // no longer overlap the other groups' streams.  4-wave workgroups (one wave per SIMD) fit.  The arithmetic does not depend
 // on the choice (same K slices, same order).  WM_SKINNY_NW=4|8 overrides.
 static int skinny_nw() {
-    static const int nw = [] { const char* v = getenv("WM_SKINNY_NW"); const int x = v ? atoi(v) : 8; return x == 4 ? 4 : 8; }();
+    static const int nw = lab_env_int("WM_SKINNY_NW", 8) == 4 ? 4 : 8;
     return nw;
 }
 
 // Row tiles per workgroup above 64 rows in slab mode (WM_SKINNY_MT=4|6|8|12|16 overrides; 16 = rounds 1-2: no row split)
 static int skinny_split_mt() {
-    static const int mt = [] { const char* v = getenv("WM_SKINNY_MT"); const int x = v ? atoi(v) : 4; return (x == 4 || x == 6 || x == 8 || x == 12 || x == 16) ? x : 4; }();
+    static const int mt = [] { const int x = lab_env_int("WM_SKINNY_MT", 4); return (x == 4 || x == 6 || x == 8 || x == 12 || x == 16) ? x : 4; }();
     return mt;
 }
 

@@ -23,10 +23,14 @@ struct GemmBigParams {
     // > 0: at most this many (persistent, one per CU) workgroups -- the launch then leaves the other CUs to whatever runs
     // beside it (wm_encoder_forward_shared); the tiles and their arithmetic are the same, only who computes them changes
     int max_wgs;
-    int nt_flags;                            // lab (WM_GEMM_NT): 1 = A panels by non-temporal DMA, 4 = non-temporal stores of plain row-major C
+    int nt_flags;                            // unused by the product kernels (the lab patch scripts/lab/gemm_f16p_stamps_whole_stage_nt.patch reads it: 1 = A panels by non-temporal DMA, 4 = non-temporal stores of C)
     int tile_rows;                           // persistent kernel: row panels per step of the tile order (0: chosen from K; 1: plain row-major)
 };
-int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // dispatch: gemm_f16p.hip when it supports the shape, else gemm_f16.hip's kernel
+int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // dispatch: gemm_f16p.hip when it supports the shape and the launch has enough tiles, else gemm_f16.hip's kernels
+// launches with fewer 256 x 256 tiles than this run 128 x 128 tiles, two workgroups per CU (gemm_f16.hip; bit-identical results)
+constexpr int GEMM_SMALL_TILES_DEFAULT = 192;
+void set_gemm_small_tiles(int tiles);     // 0: never the small form; < 0: the default
+int get_gemm_small_tiles();
 int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream);     // persistent 256x256 tiles, continuous LDS-DMA stream, alternating wave groups
 bool gemm_f16p_supports(const GemmBigParams& p);
 int launch_dequant_w8(const int8_t* q, const h16* scale, h16* out, int N, int K, hipStream_t stream);

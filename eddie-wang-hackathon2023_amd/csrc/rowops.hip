@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void layernorm_stream_kernel(const h16* x, int
 
 int launch_layernorm(const h16* x, int ldx, int M, int N, const h16* g, const h16* b, h16* out, int ldo,
                      hipStream_t stream) {
-    const char* form = getenv("WM_LN_FORM");       // "workgroup": row_finish_kernel's form for every width (A/B runs, the bit-identity test)
+    const char* form = lab_env_str("WM_LN_FORM");  // "workgroup": row_finish_kernel's form for every width (WM_LAB=1: A/B runs, the bit-identity test)
     if (N % 4 == 0 && N <= LNS_G * 256 && ldx % 4 == 0 && ldo % 4 == 0 && M > 0 && !(form && form[0] == 'w')) {      // by row width only: a row's result never depends on M
         const int rows_per_wg = 4 * LNS_ROWS;
         hipLaunchKernelGGL(layernorm_stream_kernel, dim3((M + rows_per_wg - 1) / rows_per_wg), dim3(256), 0, stream, x, ldx, M, N, g, b, out, ldo);

@@ -79,3 +79,13 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def all_ranks(value: float, device) -> List[float]:
+    """`value` of every rank, in rank order, on every rank (one small all-gather; [value] without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x[0]) for x in out]

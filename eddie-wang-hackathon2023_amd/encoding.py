@@ -107,11 +107,17 @@ class WhisperEncoding:
         side.wait_stream(torch.cuda.current_stream())          # mel may still be in flight on the caller's stream
         device = mel.device
 
+        timed = bool(getattr(self, "time_prefetch", False))        # bench.py: events around the prefetched pass and around collect()'s wait
+
         def work():
             try:
                 torch.cuda.set_device(device)
                 with torch.cuda.stream(side):
+                    if timed:
+                        box["t0"] = torch.cuda.Event(enable_timing=True); box["t0"].record()
                     box["xa"] = self.get_audio_features_async(mel, cu_budget=cu_budget)
+                    if timed:
+                        box["t1"] = torch.cuda.Event(enable_timing=True); box["t1"].record()
             except BaseException as exc:                       # re-raised by collect()
                 box["error"] = exc
 
@@ -127,6 +133,12 @@ class WhisperEncoding:
         if "error" in box:
             raise box["error"]
         cur = torch.cuda.current_stream()
+        if "t0" in box:                          # (encoder start, encoder end, before the wait, after the wait): read after a synchronize
+            w0 = torch.cuda.Event(enable_timing=True); w0.record()
         cur.wait_stream(self._prefetch_stream)
+        if "t0" in box:
+            w1 = torch.cuda.Event(enable_timing=True); w1.record()
+            self.prefetch_events = getattr(self, "prefetch_events", [])
+            self.prefetch_events.append((box["t0"], box["t1"], w0, w1))
         box["xa"].record_stream(cur)             # allocated on the side stream, used on this one
         return box["xa"]

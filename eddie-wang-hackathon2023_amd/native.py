@@ -18,7 +18,53 @@ from typing import Optional, Sequence
 # profiles/r3ah_bench_*.json, sweep of the other launch-path knobs in profiles/r3ag_launch_knobs.txt.  The flag is read when
 # the HIP runtime initialises (first HIP call of the process), so it is set here, at import, unless the caller chose a value:
 # import this package before the first torch.cuda call, or export the variable.  Same kernels, same results.
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+#
+# DEBUG_CLR_GRAPH_PACKET_CAPTURE is a debug switch of the HIP runtime, not a documented interface: it is process-wide (every HIP
+# user of the process replays its graphs node by node), it takes effect only if it is in the environment before the process's
+# first HIP call, and a ROCm update may drop it.  So: a value chosen by the caller wins; WM_GRAPH_NODE_REPLAY=0 keeps this
+# package from touching the variable at all; the package records what it did and whether it was in time (RUNTIME_KNOBS,
+# runtime_report() -- bench.py and summarize.py print it) and warns when the runtime was already initialised; and
+# tests/test_gpu_round4.py::test_graph_node_replay_still_pays fails when the switch stops making the batch-1 step faster.
+import sys
+import warnings
+
+
+def _hip_already_initialised() -> bool:
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:       # noqa: BLE001
+        return False
+
+
+def _configure_runtime() -> dict:
+    name = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+    late = _hip_already_initialised()
+    if name in os.environ:
+        return {"name": name, "value": os.environ[name], "set_by": "caller", "in_time": None}      # the caller's business, and timing
+    if os.environ.get("WM_GRAPH_NODE_REPLAY", "1") == "0":
+        return {"name": name, "value": None, "set_by": "nobody (WM_GRAPH_NODE_REPLAY=0)", "in_time": None}
+    os.environ[name] = "0"
+    if late:
+        warnings.warn("whisper_mi355: the HIP runtime was initialised before this package was imported, so "
+                      f"{name}=0 (node-by-node graph replay, 6-10 % of the small-batch token step) is NOT in effect: "
+                      "import the package before the first torch.cuda call, or export the variable yourself", RuntimeWarning, stacklevel=3)
+    return {"name": name, "value": "0", "set_by": "package", "in_time": not late}
+
+
+RUNTIME_KNOBS = _configure_runtime()
+
+
+def runtime_report() -> dict:
+    """What this package did to the HIP runtime's environment, whether it was in time, and the lab knobs the library honoured."""
+    rep = dict(RUNTIME_KNOBS)
+    rep["effective_env"] = os.environ.get(RUNTIME_KNOBS["name"])
+    if _lib is not None:
+        buf = C.create_string_buffer(4096)
+        _lib.wm_lab_knobs(buf, 4096)
+        rep["lab_knobs_honoured"] = buf.value.decode() or None
+    return rep
+
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WM_LIBRARY_PATH") or os.path.join(_HERE, "libwhisper_mi355.so")
@@ -31,12 +77,12 @@ EXPORTS = (
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
     "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
-    "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_gemv_fused", "wm_gemm_rows", "wm_set_rows_path", "wm_set_small_batch_rows", "wm_set_self_attn_waves", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
+    "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_gemv_fused", "wm_gemm_rows", "wm_set_rows_path", "wm_set_small_batch_rows", "wm_set_self_attn_waves", "wm_set_gemm_small_tiles", "wm_lab_knobs", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
     "wm_step_finish",
 )
 
 
-ABI_VERSION = 4          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
+ABI_VERSION = 5          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
 
 
 class WmError(RuntimeError):
@@ -152,6 +198,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_gemm_rows.argtypes = [C.POINTER(WmGemvIO), vp]
     lib.wm_set_rows_path.argtypes = [i32]
     lib.wm_set_self_attn_waves.argtypes = [i32]
+    lib.wm_set_gemm_small_tiles.argtypes = [i32]
+    lib.wm_lab_knobs.argtypes = [C.c_char_p, sz]
     lib.wm_gemm_skinny.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.wm_gemm_skinny_default_ksplit.argtypes = [i32, i32, i32, i32]
     lib.wm_layernorm.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp]

@@ -43,9 +43,16 @@ typedef struct wm_dims {
     int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
 } wm_dims;
 
-/* ABI version of this header: 2 (round 3: wm_gemm takes a workspace before the stream; wm_decoder_io / wm_greedy_io carry
- * the per-row `done` flags).  Callers built against another version must refuse to run (native.py does). */
-#define WM_ABI_VERSION 4
+/* ABI version of this header.  Callers built against another version must refuse to run (native.py does).
+ *   2  wm_gemm takes a workspace before the stream; wm_decoder_io / wm_greedy_io carry the per-row `done` flags
+ *   3  weight-only engines keep int8 at rest: wm_cross_kv takes (workspace, workspace_bytes) and REJECTS fewer than
+ *      wm_cross_kv_workspace_bytes() bytes for every engine kind (256 B for fp16 engines; the fp16 expansion of one layer's
+ *      matrix for weight-only ones) -- a caller that passed NULL / 0 to an fp16 engine before now gets rc 1;
+ *      wm_gemm_rows, wm_set_rows_path
+ *   4  wm_set_self_attn_waves
+ *   5  (round 4) wm_set_gemm_small_tiles, wm_lab_knobs; environment knobs are honoured only under WM_LAB=1;
+ *      wm_greedy_io gains the sampling fields (temperature, seed) and `without_timestamps` moves into the device rules   */
+#define WM_ABI_VERSION 5
 int wm_version(void);
 const char* wm_last_error(void);
 int wm_device_count(int* out);
@@ -249,6 +256,17 @@ int wm_set_rows_path(int min_rows);
  * size.  Returns the previous value.  The two forms round at the same points and add the softmax sum and P.V in different fp32
  * orders; the cache they append is identical.  Captured graphs keep the form they were captured with.                       */
 int wm_set_self_attn_waves(int waves);
+/* The MFMA-bound GEMMs (encoder layers, convolutions, cross-K/V projection; wm_gemm, wm_conv1d_gelu) pick their tile by the
+ * size of the launch: with fewer than `tiles` 256 x 256 output tiles (default 192: one to four clips of large-v2, by shape) the launch
+ * runs 128 x 128 tiles, two workgroups per CU, else the persistent 256 x 256 kernel.  0 = never the small form, < 0 = the
+ * default.  Returns the previous value.  Both forms add an output element's products in the same order and share the
+ * epilogue arithmetic: the results are bit-identical, a clip's encoder output does not depend on the batch it is in.     */
+int wm_set_gemm_small_tiles(int tiles);
+/* Lab knobs (environment variables such as WM_CROSS_NSPLIT, WM_ROWS_MIN, WM_KSPLIT_CAP: DESIGN.md, scripts/README.md) change a
+ * schedule or the order of fp32 sums for A/B runs.  They are honoured ONLY when WM_LAB=1 is set as well; every knob honoured by
+ * this process is logged once on stderr and listed here as "NAME=value;..." (returns the length of the full list; buf may be
+ * NULL).  Without WM_LAB=1 a set knob is ignored with one warning on stderr.                                                */
+int wm_lab_knobs(char* buf, size_t cap);
 /* fp16 LayerNorm rows, fp32 statistics, eps 1e-5 (layernormKernels.cu:62-188). */
 int wm_layernorm(const void* x, int ldx, int M, int N, const void* gamma, const void* beta,
                  void* out, int ldo, wm_stream_t stream);

@@ -390,6 +390,7 @@ def test_layernorm_streaming_form_is_bit_identical(lib, M, N, monkeypatch):
     x = dev((r.standard_normal((M, N)) * 3 + 1).astype(np.float16))
     g, b = dev(r.uniform(0.5, 1.5, N).astype(np.float16)), dev(r.uniform(-0.5, 0.5, N).astype(np.float16))
     outs = []
+    monkeypatch.setenv("WM_LAB", "1")                         # lab knobs are honoured only under WM_LAB=1
     for form in ("", "workgroup"):
         monkeypatch.setenv("WM_LN_FORM", form)
         out = torch.full((M + 1, N), 7.0, dtype=torch.float16, device="cuda")
