@@ -74,11 +74,15 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
     h16* lg = p.logits + (size_t)b * p.ld_row;
     int32_t* toks = p.tokens + (size_t)b * p.ld_tok;
     const int tb = p.timestamp_begin;
-    const bool first = p.apply_rules && (cur_len == p.sample_begin);
+    // apply_rules: 0 plain arg-max; 1 SuppressBlank + SuppressTokens + ApplyTimestampRules (the default decoding options);
+    // 2 the two suppress filters WITHOUT the timestamp rules -- DecodingOptions.without_timestamps, where the reference builds no
+    // ApplyTimestampRules filter (W/decoding.py:337-346) and samples from the whole (suppressed) vocabulary
+    const bool lists = p.apply_rules != 0, ts_rules = p.apply_rules == 1;
+    const bool first = lists && (cur_len == p.sample_begin);
 
     // ---- SuppressTokens (+ no_timestamps) and SuppressBlank: written into the logits row, exactly
     // like the reference's in-place filters (decoding.py:202-217); the scan below then sees -inf ----
-    if (p.apply_rules) {
+    if (lists) {
         const h16 ninf = (h16)(-INFINITY);
         for (int i = tid; i < p.n_suppress; i += GREEDY_THREADS) lg[p.suppress[i]] = ninf;
         if (first) for (int i = tid; i < p.n_blank; i += GREEDY_THREADS) lg[p.blank[i]] = ninf;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
     // (a backwards scan by one thread was a chain of dependent loads: up to one L2 round trip per sampled token) ------------
     const int n_sampled = cur_len - p.sample_begin;
     int my_rel = -1, my_tok = -1;                  // this thread's latest timestamp among the sampled tokens it looked at
-    if (p.apply_rules) {
+    if (ts_rules) {
         for (int j = tid; j < n_sampled; j += GREEDY_THREADS) {
             const int t = toks[p.sample_begin + j];
             if (t >= tb) { my_rel = j; my_tok = t; }
@@ -107,14 +111,14 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
     for (int w = 0; w < GREEDY_THREADS / 64; ++w) rel_last = max(rel_last, s_hist[w]);
     if (rel_last >= 0 && my_rel == rel_last) s_info[2] = my_tok;          // exactly one thread holds that position
     __syncthreads();
-    const bool last_ts = p.apply_rules && n_sampled >= 1 && s_info[0];
-    const bool pen_ts = p.apply_rules && (n_sampled < 2 || s_info[1]);
+    const bool last_ts = ts_rules && n_sampled >= 1 && s_info[0];
+    const bool pen_ts = ts_rules && (n_sampled < 2 || s_info[1]);
     int ts_last = rel_last >= 0 ? s_info[2] : -1;
     if (ts_last >= 0 && !(last_ts && !pen_ts)) ts_last += 1;
 
     // allowed = [lo_txt, hi_txt) U [lo_ts, hi_ts): every rule of ApplyTimestampRules is a range
-    int lo_txt = 0, hi_txt = p.apply_rules ? tb : p.V, lo_ts = p.apply_rules ? tb : p.V, hi_ts = p.V;
-    if (p.apply_rules) {
+    int lo_txt = 0, hi_txt = ts_rules ? tb : p.V, lo_ts = ts_rules ? tb : p.V, hi_ts = p.V;
+    if (ts_rules) {
         if (first) { hi_txt = 0; if (p.max_initial_ts >= 0) hi_ts = min(hi_ts, tb + p.max_initial_ts + 1); }
         if (last_ts) { if (pen_ts) lo_ts = p.V; else lo_txt = max(lo_txt, p.eot); }
         if (ts_last >= 0) lo_ts = max(lo_ts, ts_last);
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
 
     if (tid == 0) {
         bool ts_only = false;
-        if (p.apply_rules) {
+        if (ts_rules) {
             const float lse_ts = (tsm.m == -INFINITY) ? -INFINITY : tsm.m + __logf(tsm.s);
             ts_only = lse_ts > txt.m;      // logsumexp(ts logprobs) > max(text logprobs)
         }

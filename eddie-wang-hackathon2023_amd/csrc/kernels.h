@@ -161,7 +161,7 @@ struct GreedyParams {
     const int32_t* suppress; int n_suppress; // token ids suppressed on every step (SuppressTokens + no_timestamps)
     const int32_t* blank; int n_blank;       // SuppressBlank list (incl. eot)
     int sample_begin; int eot; int timestamp_begin; int max_initial_ts;   // -1 = no limit
-    int apply_rules;                         // 0 = plain argmax (tests / models without special ids)
+    int apply_rules;                         // 0 = plain argmax (tests / models without special ids), 1 = all rules, 2 = suppress lists only (without_timestamps)
     int32_t* n_done;                         // [1] number of rows whose last token is eot after this step
     const int32_t* t_dev;                    // optional device step counter: cur_len = *t_dev + 1
     int32_t* done;                           // optional [B]: 1 once the row's newest token is eot

@@ -728,7 +728,9 @@ class WhisperDecoding:
         io.blank, io.n_blank = st['blank'].data_ptr(), st['n_blank']
         io.sample_begin, io.eot, io.timestamp_begin = self.sample_begin, tk.eot, tk.timestamp_begin
         io.max_initial_timestamp_index = -1 if self.max_initial_timestamp_index is None else self.max_initial_timestamp_index
-        io.apply_rules = 1          # main_loop routes without_timestamps to the reference loop
+        # 1: SuppressBlank + SuppressTokens + ApplyTimestampRules; 2: without_timestamps -- the reference then builds no timestamp
+        # filter (W/decoding.py:337-346) and samples from the whole suppressed vocabulary
+        io.apply_rules = 2 if self.options.without_timestamps else 1
         io.n_done = st['n_done'].data_ptr()
         io.n_past_dev = n_past_dev.data_ptr() if n_past_dev is not None else None
         io.done = st['done'][lo:hi].data_ptr()
@@ -747,7 +749,7 @@ class WhisperDecoding:
         HBM-bound part of a step) the other group runs its latency-bound weight-streaming chain.
         Rows that have emitted EOT drop out of the attention kernels and a group whose rows are all
         finished is no longer stepped (`skip_finished_rows`): the loop's cost follows the live rows."""
-        if self.options.temperature != 0 or self.n_group != 1 or self.options.without_timestamps:
+        if self.options.temperature != 0 or self.n_group != 1:
             return self.main_loop_reference(audio_features)
         dev = audio_features.device
         tokens0 = self._initial_token_rows(audio_features.shape[0], dev)

@@ -2,10 +2,12 @@
 reference (W/run.py:21-63): prints "transcribe time <s>" and the text.
 
 Audio front-end: the reference shells out to ffmpeg and computes the log-mel on the GPU with
-torch.stft (W/whisper_utils.py:17-146).  ffmpeg is not on these boxes; `--input_file` therefore
-accepts a `.npy` log-mel `[80, 3000]`, a 16 kHz mono `.wav` (PCM16, decoded with the standard
-library; mel via whisper_utils.log_mel_spectrogram) or the keyword `synthetic`.  Row (f1) of
-SURVEY.md section 8 (device-side STFT + FLAC/m4a reader) is next-scope.
+torch.stft (W/whisper_utils.py:17-146).  ffmpeg is not on these boxes; `--input_file` accepts a
+`.flac` (decoded on the device: wm_flac_decode, csrc/flac_decode.hip -- LibriSpeech's format), a
+16 kHz mono `.wav` (PCM16, standard library), a `.npy` log-mel `[80, 3000]` or the keyword
+`synthetic`; the log-mel itself is the HIP front end (wm_log_mel, csrc/frontend.hip: STFT + mel +
+log on the device), held to the reference's golden mel in
+tests/test_gpu_model.py.  m4a / resampling (ffmpeg's job in the reference) stay out of scope.
 """
 from __future__ import annotations
 

@@ -67,9 +67,17 @@ def discover(dataset_dir) -> List[Tuple[Path, str]]:
     return pairs
 
 
+# bytes per second of audio by container, for clips whose header does not give a duration: FLAC of 16 kHz mono speech
+# compresses to roughly half of PCM16 (LibriSpeech: ~ 15-18 kB/s), wav is PCM16, a log-mel .npy holds 80 x 100 fp32 per second
+_BYTES_PER_SECOND = {".flac": 16000.0, ".wav": 32000.0, ".npy": 32000.0}
+_warned_fallback = [False]
+
+
 def clip_seconds(audio_file) -> float:
-    """Duration of a clip without decoding it: FLAC STREAMINFO (the fields wm_flac_info returns, read from the first 42
-    bytes), the wav header, the .npy header; file size as a last resort (monotone in the duration for one codec, which is all the ordering needs)."""
+    """Duration of a clip in SECONDS without decoding it: FLAC STREAMINFO (the fields wm_flac_info returns, read from the first
+    42 bytes), the wav header, the .npy header (frames at the front end's 100 per second).  A header that gives no duration
+    (a FLAC with total_samples = 0, a container this reader does not know) falls back to file size / a bytes-per-second estimate
+    for the suffix -- still seconds, so such clips sort among the others instead of behind every one of them -- and says so once."""
     path = Path(audio_file)
     try:
         if path.suffix == ".flac":
@@ -86,10 +94,16 @@ def clip_seconds(audio_file) -> float:
             with wave.open(str(path), "rb") as w:
                 return w.getnframes() / float(w.getframerate())
         elif path.suffix == ".npy":
-            return np.load(path, mmap_mode="r").shape[-1] / 16000.0
-    except Exception:       # noqa: BLE001 -- ordering is an optimisation; any unreadable header falls back to the size
+            arr = np.load(path, mmap_mode="r")
+            # a log-mel [n_mels, frames] (100 frames per second, W/whisper_utils.py:99-146) or raw 16 kHz samples
+            return arr.shape[-1] / (100.0 if arr.ndim >= 2 else 16000.0)
+    except Exception:       # noqa: BLE001 -- ordering is an optimisation; any unreadable header falls back to the size estimate
         pass
-    return float(path.stat().st_size)
+    if not _warned_fallback[0]:
+        _warned_fallback[0] = True
+        logging.getLogger(__name__).warning("summarize: no duration in the header of %s (and possibly others): ordering by size / %s bytes per second",
+                                            path, _BYTES_PER_SECOND.get(path.suffix, 16000.0))
+    return float(path.stat().st_size) / _BYTES_PER_SECOND.get(path.suffix, 16000.0)
 
 
 def plan_batches(pairs, batch_size: int, rank: int = 0, world: int = 1, deal=None):
@@ -240,6 +254,29 @@ def transcribe_dataset(pairs, evaluate, batch_size: int, device) -> Tuple[List[s
     return hyps, refs, elapsed
 
 
+def rank_share(pairs, batch_size: int, rank: int, world: int, deal=None, keep_order: bool = False) -> list:
+    """The (audio file, reference) pairs THIS rank transcribes, in the order it takes them (W/summarize.py:72-181 is one
+    process over the whole list).  Default: batches of similar-length clips dealt round-robin over the ranks (plan_batches) --
+    the last batch may be ragged and some ranks may get one batch fewer; `keep_order` (or batch size 1): a contiguous slice of the
+    directory order (dp.shard_bounds).  Every pair lands on exactly one rank; the WER does not depend on the order."""
+    import dp
+    if keep_order or batch_size <= 1:
+        lo, hi = dp.shard_bounds(len(pairs), rank, world)
+        return list(pairs[lo:hi])
+    return [pair for batch in plan_batches(pairs, batch_size, rank, world, deal) for pair in batch]
+
+
+def gather_transcripts(hyps: List[str], refs: List[str], seconds: float) -> Tuple[List[str], List[str], float]:
+    """Every rank's hypotheses and references on every rank (rank order; pairs stay aligned), and the slowest rank's seconds:
+    the job's only exchange besides the model weights each rank loads for itself.  Without a process group: the arguments."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return hyps, refs, seconds
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, (hyps, refs, seconds))
+    return [h for g in gathered for h in g[0]], [r for g in gathered for r in g[1]], max(g[2] for g in gathered)
+
+
 def main(args) -> Optional[dict]:
     logging.basicConfig(level=getattr(logging, args.log_level.upper(), logging.INFO))
     import torch.distributed as dist
@@ -250,11 +287,7 @@ def main(args) -> Optional[dict]:
     whisper_encoding = WhisperEncoding(engine_dir)
     whisper_decoding = WhisperDecoding(engine_dir, vocab_path=args.vocab)
     pairs = discover(args.dataset_dir)
-    if args.no_sort_by_duration or args.batch_size <= 1:
-        lo, hi = dp.shard_bounds(len(pairs), rank, world)
-        mine = pairs[lo:hi]
-    else:        # batches of similar-length clips, dealt over the ranks (plan_batches); the WER does not depend on the order
-        mine = [pair for batch in plan_batches(pairs, args.batch_size, rank, world, whisper_decoding.balanced_order) for pair in batch]
+    mine = rank_share(pairs, args.batch_size, rank, world, whisper_decoding.balanced_order, args.no_sort_by_duration)
     report = {}
     runs = []
     if args.test_torch:
@@ -268,12 +301,7 @@ def main(args) -> Optional[dict]:
                 mine, lambda mels: eval_engines_stream(whisper_encoding, whisper_decoding, mels), args.batch_size, device)
         else:
             hyps, refs, seconds = transcribe_dataset(mine, evaluate, args.batch_size, device)
-        if world > 1:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, (hyps, refs, seconds))
-            hyps = [h for g in gathered for h in g[0]]
-            refs = [r for g in gathered for r in g[1]]
-            seconds = max(g[2] for g in gathered)
+        hyps, refs, seconds = gather_transcripts(hyps, refs, seconds)
         if rank == 0:
             value = score(hyps, refs)
             logger.info(f"{name} (total latency: {seconds} sec)")

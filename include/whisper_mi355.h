@@ -164,7 +164,7 @@ typedef struct wm_greedy_io {
     const int32_t* suppress; int32_t n_suppress; /* token ids suppressed on every step */
     const int32_t* blank; int32_t n_blank; /* suppressed on the first sampled step only */
     int32_t sample_begin, eot, timestamp_begin, max_initial_timestamp_index /* -1: none */;
-    int32_t apply_rules; /* 0: plain arg-max */
+    int32_t apply_rules; /* 0: plain arg-max; 1: SuppressBlank + SuppressTokens + ApplyTimestampRules; 2: the two suppress filters only (without_timestamps, W/decoding.py:337-346) */
     int32_t* n_done;
     const int32_t* n_past_dev; /* optional device step counter: cur_len = *n_past_dev + 1 */
     int32_t* done;             /* optional int32 [batch]: set to 1 when the row's new token is EOT (never cleared here) */

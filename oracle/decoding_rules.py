@@ -71,6 +71,7 @@ class RuleSet:
     suppress_tokens: Sequence[int]          # sorted, incl. the specials added at :407-419
     blank_tokens: Sequence[int]             # tokenizer.encode(" ") + [eot]   (:209)
     max_initial_timestamp_index: Optional[int] = 50   # round(1.0 / 0.02)   (:343-348)
+    timestamps: bool = True                 # False = DecodingOptions.without_timestamps: no ApplyTimestampRules filter is built (:337-348)
 
 
 def log_softmax_f32(x: np.ndarray) -> np.ndarray:
@@ -93,6 +94,8 @@ def apply_filters(logits: np.ndarray, tokens: np.ndarray, rules: RuleSet, domina
         lg[:, list(rules.blank_tokens)] = NEG_INF
     # SuppressTokens (:212-217)
     lg[:, list(rules.suppress_tokens)] = NEG_INF
+    if not rules.timestamps:                # without_timestamps: the two suppress filters are the whole list (:332-348)
+        return lg
     # ApplyTimestampRules (:145-199)
     lg[:, ids.no_timestamps] = NEG_INF
     for k in range(B):

@@ -239,6 +239,34 @@ def gen_rules_fixture(dec):
     print("tokenizer.npz written")
 
 
+def gen_rules_nots_fixture(dec):
+    """DecodingOptions.without_timestamps (round 4): the reference then builds SuppressBlank and SuppressTokens but NO
+    ApplyTimestampRules (W/decoding.py:332-348), and <|notimestamps|> joins the start sequence (sample_begin = 4).  The cases of
+    DR.golden_rule_cases with that token inserted, through the reference's own two filter classes and GreedyDecoder.update."""
+    tk_ids = DR.MULTILINGUAL
+    base = np.load(os.path.join(OUT, "decoding_rules.npz"))
+    sup, blank = base["suppress"].tolist(), base["blank"].tolist()
+    ftok = _Tok(tk_ids, blank[:-1])
+    filters = [dec.SuppressBlank(ftok, 4), dec.SuppressTokens(sup)]
+    greedy = dec.GreedyDecoder(0.0, tk_ids.eot)
+    fix = {}
+    cases = DR.golden_rule_cases(tk_ids)
+    for c, (toks, logits) in enumerate(cases):
+        toks = np.concatenate([toks[:3], [tk_ids.no_timestamps], toks[3:]])
+        lt = torch.from_numpy(logits.copy())[None]
+        tt = torch.from_numpy(toks)[None]
+        for f in filters:
+            f.apply(lt, tt)
+        s = torch.zeros(1)
+        new_tokens, done = greedy.update(tt, lt.clone(), s)
+        fix[f"c{c}_next"] = int(new_tokens[0, -1])
+        fix[f"c{c}_sumlp"] = float(s[0])
+        fix[f"c{c}_done"] = bool(done)
+    fix["n_cases"] = len(cases)
+    np.savez_compressed(os.path.join(OUT, "decoding_rules_nots.npz"), **fix)
+    print("decoding_rules_nots.npz:", len(cases), "cases; next tokens", [fix[f"c{c}_next"] for c in range(len(cases))][:12])
+
+
 def gen_sampling_fixture(dec):
     """The sampling path of the decode loop, produced by the reference's own classes:
       (1) GreedyDecoder(temperature=0.7).update (W/decoding.py:274-300) on seeded CPU logits under torch.manual_seed,
@@ -344,6 +372,9 @@ if __name__ == "__main__":
     if "--only-tiny" in sys.argv:
         gen_tiny_en_shape_fixture(tm)
         sys.exit(0)
+    if "--only-rules-nots" in sys.argv:
+        gen_rules_nots_fixture(import_reference_decoding())
+        sys.exit(0)
     if "--only-sampling" in sys.argv:
         gen_sampling_fixture(import_reference_decoding())
         sys.exit(0)
@@ -353,4 +384,5 @@ if __name__ == "__main__":
     gen_mel_fixture()
     dec = import_reference_decoding()
     gen_rules_fixture(dec)
+    gen_rules_nots_fixture(dec)
     gen_sampling_fixture(dec)

@@ -107,3 +107,50 @@ def test_bench_launches_its_own_ranks(monkeypatch, capsys):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     assert bench.launch_ranks(argparse.Namespace(gpus=4)) == 2
     assert "shows 1 GPU" in capsys.readouterr().err
+
+
+def _summarize_worker(rank, world, port, tmp, ret):
+    """summarize.py's rank-sharded path without a GPU: the planning (rank_share), the per-rank loop (transcribe_dataset with a
+    stand-in evaluator and front end) and the gather of the transcripts; 11 clips in batches of 4 -> a ragged last batch and
+    one rank with a batch fewer."""
+    import types
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import summarize as S
+        from pathlib import Path
+        files = sorted(Path(tmp).glob("*.npy"))
+        pairs = [(f, f.stem.upper()) for f in files]
+        mine = S.rank_share(pairs, 4, rank, world)
+        sizes = []
+
+        def fake_eval(mel):                                     # "transcribes" a clip to its first sample (set per file below)
+            sizes.append(mel.shape[0])
+            return [types.SimpleNamespace(text=f"clip{int(v)}.") for v in mel[:, 0].tolist()]
+        S.load_audio = lambda path: np.load(path)               # noqa: E731 -- the stand-in front end: samples as stored
+        S.mel_batch = lambda audio, device: torch.tensor([[float(a[0])] for a in audio])      # noqa: E731
+        hyps, refs, seconds = S.transcribe_dataset(mine, fake_eval, 4, "cpu")
+        assert sizes == ([4, 3] if rank == 0 else [4]), (rank, sizes)       # batches 0 and 2 (ragged) on rank 0, batch 1 on rank 1
+        hyps, refs, seconds = S.gather_transcripts(hyps, refs, float(rank + 1))
+        assert seconds == float(world)
+        assert len(hyps) == len(refs) == 11
+        assert sorted(refs) == sorted(p[1] for p in pairs)                  # every clip exactly once
+        assert all(h == r for h, r in zip(hyps, refs))                      # hypotheses stay aligned with their references
+        assert dp.all_ranks(float(10 + rank), "cpu") == [10.0, 11.0]
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_summarize_rank_sharded_path_world2_gloo(tmp_path):
+    import numpy as np
+    for k, n in enumerate([16000, 4000, 52000, 9000, 30000, 2500, 41000, 12000, 7000, 60000, 21000]):
+        a = np.zeros(n, dtype=np.float32)
+        a[0] = k                                                # the "content" of clip k: its transcript is CLIPk
+        np.save(tmp_path / f"clip{k}.npy", a)
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_summarize_worker, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}

@@ -1,4 +1,7 @@
 """Round 4 GPU tests (through the C ABI, on a real MI355X)."""
+import ctypes as C
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -6,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import native  # noqa: E402
+from oracle import decoding_rules as DR  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -59,3 +63,70 @@ def test_gemm_tile_switch_default_and_setter(lib):
     prev = lib.wm_set_gemm_small_tiles(7)
     assert lib.wm_set_gemm_small_tiles(-1) == 7
     assert lib.wm_set_gemm_small_tiles(prev) == 192
+
+
+# ------------------------------------------------------------------------------------------ greedy step, without_timestamps
+def test_greedy_step_without_timestamps_matches_reference_rules(lib, golden_dir):
+    """apply_rules = 2: SuppressBlank + SuppressTokens and NO timestamp rules -- what the reference's filter list is under
+    DecodingOptions.without_timestamps (W/decoding.py:332-348).  Expected tokens / log-probs: the reference's own classes
+    (tests/golden/decoding_rules_nots.npz).  Round 4 moved this option from the host loop into the fused device loop."""
+    fixr = np.load(os.path.join(golden_dir, "decoding_rules.npz"))
+    fixn = np.load(os.path.join(golden_dir, "decoding_rules_nots.npz"))
+    ids = DR.MULTILINGUAL
+    V = ids.n_vocab
+    sup = sorted(set(fixr["suppress"].tolist()))             # no <|notimestamps|> in the list: that token belongs to the timestamp filter
+    sup_d = torch.tensor(sup, dtype=torch.int32, device="cuda")
+    blank_d = torch.tensor(fixr["blank"].astype(np.int32), device="cuda")
+    for c, (toks, logits) in enumerate(DR.golden_rule_cases()):
+        toks = np.concatenate([toks[:3], [ids.no_timestamps], toks[3:]])
+        cur = len(toks)
+        tok_buf = torch.zeros((1, 64), dtype=torch.int32, device="cuda")
+        tok_buf[0, :cur] = torch.from_numpy(toks).int().cuda()
+        lg = torch.from_numpy(logits.astype(np.float16)).cuda()
+        s = torch.zeros(1, dtype=torch.float32, device="cuda")
+        n_done = torch.zeros(1, dtype=torch.int32, device="cuda")
+        io = native.WmGreedyIO()
+        io.logits, io.row_stride, io.batch, io.n_vocab = lg.data_ptr(), V, 1, V
+        io.tokens, io.tokens_ld, io.cur_len = tok_buf.data_ptr(), 64, cur
+        io.sum_logprobs, io.suppress, io.n_suppress = s.data_ptr(), sup_d.data_ptr(), len(sup)
+        io.blank, io.n_blank = blank_d.data_ptr(), len(fixr["blank"])
+        io.sample_begin, io.eot, io.timestamp_begin = 4, ids.eot, ids.timestamp_begin
+        io.max_initial_timestamp_index, io.apply_rules, io.n_done = 50, 2, n_done.data_ptr()
+        native.check(lib.wm_greedy_step(C.byref(io), stream()))
+        torch.cuda.synchronize()
+        assert int(tok_buf[0, cur]) == int(fixn[f"c{c}_next"]), f"case {c}"
+        assert abs(float(s[0]) - float(fixn[f"c{c}_sumlp"])) < 2e-4, f"case {c}"
+        assert bool(int(n_done[0])) == bool(fixn[f"c{c}_done"]), f"case {c}"
+
+
+# ------------------------------------------------------------------------------------------ fused loop, without_timestamps
+def test_without_timestamps_runs_the_fused_loop_and_equals_the_reference_loop(tmp_path_factory):
+    """Round 3 sent DecodingOptions.without_timestamps to the literal by-name loop (host filters, a stream sync per token); the
+    option is a filter list (W/decoding.py:332-348), so the fused device loop now takes it.  Token ids equal the literal loop's
+    bit for bit and no timestamp rule shapes the output."""
+    import synthetic
+    from decoding import DecodingOptions, WhisperDecoding
+    from encoding import WhisperEncoding
+    from oracle.whisper_oracle import Dims, synthetic_mel
+    from test_gpu_model import build_engine
+    tmp = tmp_path_factory.mktemp("nots")
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmp, "micro-fullvocab", 3)
+    enc = WhisperEncoding(eng)
+    mel = synthetic_mel(5, 2 * dims.n_audio_ctx, dims.n_mels, 78).cuda()
+    xa = enc.get_audio_features(mel)
+    dec = WhisperDecoding(eng, options=DecodingOptions(without_timestamps=True, sample_len=10))
+    tk = dec.tokenizer
+    assert dec.sample_begin == 3                                # as in the reference, whose start sequence does not change with the option (W/decoding.py:316-317)
+    dec.detect_language(xa)
+    called = {"ref": 0}
+    literal = dec.main_loop_reference
+    dec.main_loop_reference = lambda *a, **k: (called.__setitem__("ref", called["ref"] + 1), literal(*a, **k))[1]
+    fast = dec.main_loop(xa)
+    assert called["ref"] == 0                                   # the fused loop itself, not a detour
+    ref = literal(xa)
+    n = min(fast[0].shape[1], ref[0].shape[1])
+    assert n > dec.sample_begin and torch.equal(fast[0][:, :n].cpu(), ref[0][:, :n].cpu())
+    assert torch.allclose(fast[1].cpu(), ref[1].cpu(), atol=2e-3)
+    # with the timestamp rules the first sampled token must be a timestamp; without them random weights choose text tokens too
+    assert bool((fast[0][:, 3] < tk.timestamp_begin).any())

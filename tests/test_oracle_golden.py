@@ -108,6 +108,28 @@ def test_decoding_rules_match_reference(golden_dir):
         assert done == bool(fixr[f"c{c}_done"])
 
 
+def test_decoding_rules_without_timestamps_match_reference(golden_dir):
+    """DecodingOptions.without_timestamps: the reference builds SuppressBlank + SuppressTokens and no ApplyTimestampRules
+    (W/decoding.py:332-348); tests/golden/decoding_rules_nots.npz holds what its two filter classes and GreedyDecoder.update give
+    on the rule cases with <|notimestamps|> in the start sequence (oracle/gen_golden.py: gen_rules_nots_fixture)."""
+    import dataclasses
+    fixr, fixn = np.load(os.path.join(golden_dir, "decoding_rules.npz")), np.load(os.path.join(golden_dir, "decoding_rules_nots.npz"))
+    rules = dataclasses.replace(_rules(fixr), sample_begin=4, timestamps=False)
+    cases = DR.golden_rule_cases()
+    assert len(cases) == int(fixn["n_cases"])
+    differ = 0
+    for c, (toks, logits) in enumerate(cases):
+        toks = np.concatenate([toks[:3], [rules.ids.no_timestamps], toks[3:]])
+        lg = DR.apply_filters(logits[None], toks[None], rules)
+        s = np.zeros(1, dtype=np.float32)
+        new_tokens, done = DR.greedy_update(toks[None], lg, s, rules.ids.eot)
+        assert int(new_tokens[0, -1]) == int(fixn[f"c{c}_next"]), c
+        assert abs(float(s[0]) - float(fixn[f"c{c}_sumlp"])) < 1e-4, c
+        assert done == bool(fixn[f"c{c}_done"])
+        differ += int(fixn[f"c{c}_next"]) != int(fixr[f"c{c}_next"])
+    assert differ >= 12                    # not the timestamp rules' answers: the mode is really exercised
+
+
 def test_special_ids():
     ids = DR.MULTILINGUAL
     assert (ids.eot, ids.sot, ids.lang0, ids.translate, ids.transcribe, ids.sot_lm, ids.sot_prev,

@@ -304,3 +304,24 @@ def test_clips_are_batched_by_duration_and_dealt_over_the_ranks(golden_dir, tmp_
     # every rank gets short AND long batches (a contiguous slice of the sorted list would not)
     means = [[np.mean([want[p[0].name] for p in b]) for b in r] for r in per_rank]
     assert min(means[0]) < 0.6 and max(means[0]) > 2.0 and min(means[1]) < 1.0 and max(means[1]) > 1.8
+
+
+def test_clip_without_a_duration_in_its_header_sorts_among_the_others(tmp_path):
+    """clip_seconds' fallback used to return BYTES on the seconds scale, so one odd header sent its clip behind
+    every 30 s clip.  A FLAC whose STREAMINFO says total_samples = 0 (allowed: "unknown") now gets size / 16 kB per second."""
+    import summarize as S
+    rng = np.random.Generator(np.random.Philox(5))
+    x = _smooth(rng, 48000, 1, 16)                                   # 3 s
+    blob = bytearray(encode_flac(x, 16, [dict(block=4096, kind="fixed2") for _ in range(0, 48000 - 4095, 4096)] + [dict(block=48000 % 4096, kind="fixed2")] if 48000 % 4096 else
+                                 [dict(block=4096, kind="fixed2") for _ in range(0, 48000, 4096)]))
+    assert abs(S.clip_seconds(_write(tmp_path, "known.flac", bytes(blob))) - 3.0) < 1e-9
+    blob[8 + 13] &= 0xF0                                            # total_samples (36 bits) := 0
+    blob[8 + 14:8 + 18] = bytes(4)
+    est = S.clip_seconds(_write(tmp_path, "unknown.flac", bytes(blob)))
+    assert 0.5 < est < 12.0                                          # seconds, not bytes (the file is ~ 50-100 kB)
+
+
+def _write(tmp_path, name, data):
+    path = tmp_path / name
+    path.write_bytes(data)
+    return path
