@@ -484,7 +484,16 @@ constexpr int CROSS_MAX_SPLIT = 16;                   // key-range splits the me
 // 64 B, a lane takes 16 dims (one 16-byte load), a wave-instruction covers 16 rows.  The values are exactly code * t (no
 // fp16 rounding of the dequantised tensor), so the scale factors out of both products: score = r16((q16 . code) * t *
 // d^-0.25) with v_dot2 on exact fp16 codes, out = r16(t * (p . code)) -- one VALU op per element instead of eight.
-template <int L, bool I8 = false, int UNR_ = 0>
+// SKIP (round 4; fp16 K/V, single pass): EXACT V-row skipping.  After the two-pass softmax a probability is an fp16 value, and
+// with real weights Whisper's cross-attention is sharply peaked: most keys' probabilities round to fp16 ZERO (exp(s - m) / sum <
+// 2^-25).  Such a key contributes exactly 0 to P.V (0 x finite = 0, adding 0 changes nothing), so its V row need not leave HBM.
+// The load instructions stay where they are -- the software pipeline above depends on an unconditional stream -- but a wave
+// instruction whose 8 rows ALL weigh zero (for every token of the call) fetches the item's first 8 V rows instead, which the
+// workgroup has just read (an L2 hit): the data is multiplied by 0 either way.  Bit-identical outputs by construction (tests:
+// test_cross_attention_v_skip_*); the first block of V rows is requested before the softmax and is never skipped.  With random
+// weights (diffuse attention) nothing underflows and nothing is skipped: the bench headline cannot show this, a peaked
+// synthetic fixture and FETCH_SIZE do (profiles/r4*_pmc_vskip*).
+template <int L, bool I8 = false, int UNR_ = 0, bool SKIP = false>
 __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     constexpr int DPL = I8 ? 16 : 8;                     // dims per lane
     constexpr int LPR = 64 / DPL;                        // lanes per row: 8 (fp16) / 4 (int8)
@@ -499,6 +508,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     __shared__ float s_sc[L][CROSS_MAX_KEYS];
     __shared__ float s_red[L][4][2];
     __shared__ float s_o[4][L][64];
+    __shared__ unsigned char s_live[SKIP ? CROSS_MAX_KEYS / 8 : 1];      // per group of 8 rows (one wave instruction): does any of them weigh anything?
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar loop control
     const int sub = lane % LPR, rowi = lane / LPR;        // 16-byte column, row inside a group of RPI rows
@@ -749,6 +759,18 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
             for (int j = tid; j < nkeys; j += 256) s_sc[i][j] = r16(s_sc[i][j] * inv);
         }
         __syncthreads();
+        if constexpr (SKIP) {
+            static_assert(!I8 && RPI == 8, "V-row skipping is built for the fp16 K/V layout (8 rows per wave instruction)");
+            for (int g = tid; g * RPI < nkeys; g += 256) {
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < L; ++i)
+#pragma unroll
+                    for (int r = 0; r < RPI; ++r) any |= (g * RPI + r < nkeys) && s_sc[i][min(g * RPI + r, nkeys - 1)] != 0.f;
+                s_live[g] = any;
+            }
+            __syncthreads();
+        }
     }
 
     // ---- pass 2: P.V --------------------------------------------------------------------------------
@@ -757,7 +779,24 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     for (int i = 0; i < L; ++i)
 #pragma unroll
         for (int e = 0; e < DPL; ++e) o[i][e] = 0.f;
-    auto fetch2 = [&](u32x4 (&dst)[UNR], int k) { issue(dst, V, k_begin, nkeys, first + k * STRIDE); };
+    auto fetch2 = [&](u32x4 (&dst)[UNR], int k) {
+        if constexpr (SKIP) {                                     // (the launcher instantiates SKIP for the single-pass form only)
+            const int r0 = first + k * STRIDE;
+            // the flags of the block's UNR instructions first (wave-uniform LDS reads), then the UNR requests back to back
+            bool live[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)     // the instruction's 8 rows r0 + 8 u .. + 7 (r0 is a multiple of 8); groups past the end weigh 0 anyway
+                live[u] = (r0 + u * RPI < nkeys) && s_live[min((r0 + u * RPI) / RPI, (nkeys - 1) / RPI)];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int rr = live[u] ? min(r0 + u * RPI + rowi, nkeys - 1) : min(rowi, nkeys - 1);
+                dst[u] = __builtin_nontemporal_load((const u32x4*)(V + ((size_t)(k_begin + rr) * 64 + sub * DPL) * ESZ));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            issue(dst, V, k_begin, nkeys, first + k * STRIDE);
+        }
+    };
     auto consume2 = [&](const u32x4 (&cur)[UNR], int k) {
         const int r0 = first + k * STRIDE;
 #pragma unroll
@@ -902,6 +941,16 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
             case 2: hipLaunchKernelGGL((attn_cross_kernel<2, true>), grid, dim3(256), 0, stream, p); break;
             case 3: hipLaunchKernelGGL((attn_cross_kernel<3, true>), grid, dim3(256), 0, stream, p); break;
             default: hipLaunchKernelGGL((attn_cross_kernel<4, true>), grid, dim3(256), 0, stream, p); break;
+        }
+    } else if (p.skip_zero_rows && p.nsplit == 1 && !cross_unr2()) {            // exact V-row skipping (fp16 K/V, single pass)
+        switch (p.L) {
+            case 1:
+                if (ev_start && ev_stop) hipExtLaunchKernelGGL((attn_cross_kernel<1, false, 0, true>), grid, dim3(256), 0, stream, ev_start, ev_stop, 0, p);
+                else hipLaunchKernelGGL((attn_cross_kernel<1, false, 0, true>), grid, dim3(256), 0, stream, p);
+                break;
+            case 2: hipLaunchKernelGGL((attn_cross_kernel<2, false, 0, true>), grid, dim3(256), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((attn_cross_kernel<3, false, 0, true>), grid, dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL((attn_cross_kernel<4, false, 0, true>), grid, dim3(256), 0, stream, p); break;
         }
     } else if (ev_start && ev_stop && p.L == 1) {
         // in-situ roofline sample (bench.py): the events take the dispatch's own begin / end timestamps, as a

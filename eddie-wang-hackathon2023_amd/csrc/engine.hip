@@ -606,6 +606,8 @@ constexpr int SMALL_PATH_DEFAULT_ROWS = 16;
 // (For more rows the same fusion was built into gemm_skinny.hip and measured: without a K split its 10-40 workgroups each
 // stage the whole activation block, 70 us per launch at M = 192 against 16 + 10 for the split GEMM + row kernel, and the
 // decode step at B = 576 went from 26.1 to 30.3 ms -- profiles/r2d_b576_fused_skinny_ks1_kernel_stats.csv.  Not kept.)
+// exact V-row skipping of the decode cross-attention (attn_decode.hip, SKIP): on unless switched off (wm_set_cross_v_skip)
+std::atomic<int> g_cross_v_skip{CROSS_V_SKIP_DEFAULT};
 std::atomic<int> g_small_rows{-1};        // -1: not yet read from the environment
 int small_path_max_rows() {               // WM_SMALL_PATH=<rows> / wm_set_small_batch_rows: the fused path serves M <= rows (0: never)
     int r = g_small_rows.load(std::memory_order_relaxed);
@@ -784,6 +786,7 @@ struct GroupStep {
         p.kv_q8_scale = e->i8cross() ? Lr.cross_scale : 0.f;
         p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
         p.live = io->live_rows;
+        p.skip_zero_rows = g_cross_v_skip.load(std::memory_order_relaxed);
         const int slot = (L == 1) ? prof_slot(*prof, i, s) : -1;
         if (launch_attn_cross(p, s, slot >= 0 ? prof->start[slot] : nullptr, slot >= 0 ? prof->stop[slot] : nullptr)) return 2;
         return 0;
@@ -1115,7 +1118,14 @@ int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void
     p.part = q; p.ksplit = 1; p.ldp = H * 64; p.bias = nullptr;
     p.B = B; p.L = L; p.H = H; p.Tk = Tk; p.kv = (const h16*)kv; p.kv_bstride = (long)2 * H * Tk * 64;
     p.out = (h16*)out; p.ldo = H * 64; p.nsplit = nsplit; p.ws = ws;
+    p.skip_zero_rows = g_cross_v_skip.load(std::memory_order_relaxed);
     return launch_attn_cross(p, (hipStream_t)stream);
+}
+
+int wm_set_cross_v_skip(int on) {
+    const int prev = g_cross_v_skip.load(std::memory_order_relaxed);
+    g_cross_v_skip.store(on < 0 ? CROSS_V_SKIP_DEFAULT : (on ? 1 : 0), std::memory_order_relaxed);
+    return prev;
 }
 
 int wm_attn_decode_cross_i8(const float* q, int B, int L, int H, int Tk, const void* kv_i8, float kv_scale, void* out, int nsplit,

@@ -149,7 +149,9 @@ struct AttnCrossParams {
     int nsplit;                              // key-range splits per (b,h)  (1 = single pass)
     float* ws;                               // [B*H*nsplit][L][66] partial (m, l, o[64]) when nsplit > 1
     const int32_t* live;                     // optional [1 + B]: count, then the rows to process (others are skipped)
+    int skip_zero_rows;                      // fp16 K/V, nsplit == 1: V rows whose probabilities all round to fp16 zero are not fetched (exact)
 };
+constexpr int CROSS_V_SKIP_DEFAULT = 1;      // measured: profiles/r4e_* (diffuse attention: no slower; peaked: FETCH_SIZE falls with the skipped rows)
 int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---------------------------------------------------------------- greedy.hip

@@ -262,6 +262,11 @@ int wm_set_self_attn_waves(int waves);
  * default.  Returns the previous value.  Both forms add an output element's products in the same order and share the
  * epilogue arithmetic: the results are bit-identical, a clip's encoder output does not depend on the batch it is in.     */
 int wm_set_gemm_small_tiles(int tiles);
+/* Exact V-row skipping in the decode cross-attention (fp16 K/V, single-pass form): a key whose softmax probability rounds to
+ * fp16 zero contributes exactly nothing to P.V, so the wave instructions whose 8 rows all weigh zero do not fetch them from
+ * HBM (they re-read 8 rows the workgroup has just used).  Outputs are bit-identical with it on or off for finite V.  1 = on
+ * (default), 0 = off, < 0 = the default.  Returns the previous value.  Captured graphs keep the form they were captured with. */
+int wm_set_cross_v_skip(int on);
 /* Lab knobs (environment variables such as WM_CROSS_NSPLIT, WM_ROWS_MIN, WM_KSPLIT_CAP: DESIGN.md, scripts/README.md) change a
  * schedule or the order of fp32 sums for A/B runs.  They are honoured ONLY when WM_LAB=1 is set as well; every knob honoured by
  * this process is logged once on stderr and listed here as "NAME=value;..." (returns the length of the full list; buf may be

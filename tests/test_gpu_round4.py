@@ -130,3 +130,53 @@ def test_without_timestamps_runs_the_fused_loop_and_equals_the_reference_loop(tm
     assert torch.allclose(fast[1].cpu(), ref[1].cpu(), atol=2e-3)
     # with the timestamp rules the first sampled token must be a timestamp; without them random weights choose text tokens too
     assert bool((fast[0][:, 3] < tk.timestamp_begin).any())
+
+
+# ------------------------------------------------------------------------------------------ cross-attention: exact V-row skipping
+def _peaked_kv(B, H, Tk, scale, seed):
+    """K rows scaled so that the softmax is sharply peaked (as Whisper's cross-attention is with real weights): with score
+    standard deviation ~ `scale`, every key more than 17.3 below the maximum has a probability that rounds to fp16 zero."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(B, H * 64, device="cuda", generator=g).half().float()
+    kv = torch.randn(B, 2, H, Tk, 64, device="cuda", generator=g)
+    kv[:, 0] *= scale                                        # score = q . k / 8 over 64 dims, q ~ N(0, 1), k ~ N(0, scale^2): std ~ scale
+    return q, kv.half()
+
+
+@pytest.mark.parametrize("B,L,Tk,scale", [(3, 1, 1500, 12.0), (2, 1, 1500, 1.0), (2, 3, 1500, 14.0), (2, 4, 77, 20.0), (1, 1, 8, 30.0),
+                                          (13, 1, 1500, 16.0)])
+def test_cross_attention_v_skip_is_bit_identical(lib, B, L, Tk, scale):
+    """A key whose probability rounds to fp16 zero contributes exactly 0 to P.V: not fetching its V row changes no bit.  Peaked
+    (most rows skipped) and diffuse (none) inputs, one to four tokens per call, ragged key counts; against the kernel with the
+    skipping off, and against the oracle's attention (W/torch_model.py:88-103) at the kernel test's tolerance."""
+    from oracle.whisper_oracle import Dims, OracleConfig, OracleModel
+    H = 20 if Tk == 1500 else 3
+    q1, kv = _peaked_kv(B, H, Tk, scale, 11 + B + L + Tk)
+    q = q1[:, None, :].repeat(1, L, 1)
+    if L > 1:
+        q = (q + 0.25 * torch.randn(q.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))).half().float()
+    q = q.reshape(B * L, H * 64).contiguous()
+    outs = []
+    prev = lib.wm_set_cross_v_skip(-1)
+    try:
+        for on in (0, 1):
+            lib.wm_set_cross_v_skip(on)
+            out = torch.zeros((B * L, H * 64), dtype=torch.float16, device="cuda")
+            native.check(lib.wm_attn_decode_cross(q.data_ptr(), B, L, H, Tk, kv.data_ptr(), out.data_ptr(), 1, None, stream()))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        lib.wm_set_cross_v_skip(prev)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    if B * L * Tk <= 3 * 1500 * 4:                           # the oracle on the CPU: small cases only
+        m = OracleModel(Dims(80, Tk, H * 64, H, 0, 8, 4, H * 64, H, 0), {}, OracleConfig(act="float16"))
+        kk = kv[:, 0].float().cpu().permute(0, 2, 1, 3).reshape(B, Tk, H * 64)
+        vv = kv[:, 1].float().cpu().permute(0, 2, 1, 3).reshape(B, Tk, H * 64)
+        ref = m._attend(q.cpu().reshape(B, L, H * 64), kk, vv, H).numpy().reshape(B * L, H * 64)
+        assert np.abs(outs[1].float().cpu().numpy() - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    if scale >= 12.0 and Tk == 1500:                         # the fixture really is peaked: most groups of 8 keys weigh nothing
+        sc = torch.einsum("bhd,bhtd->bht", q.reshape(B, L, H, 64)[:, 0].half().float() * 64 ** -0.25,
+                          (kv[:, 0].float() * 64 ** -0.25).half().float())
+        pr = torch.softmax(sc, dim=-1).half()
+        dead = (pr.reshape(B, H, -1)[..., : Tk // 8 * 8].reshape(B, H, -1, 8) == 0).all(dim=-1).float().mean()
+        assert float(dead) > (0.5 if L == 1 else 0.2)
