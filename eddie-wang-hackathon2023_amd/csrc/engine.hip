@@ -992,6 +992,9 @@ int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream) {
     p.max_initial_ts = io->max_initial_timestamp_index; p.apply_rules = io->apply_rules; p.n_done = io->n_done;
     p.t_dev = io->n_past_dev;
     p.done = io->done; p.row_limit = io->row_limit;
+    WM_REQUIRE(io->temperature >= 0.f, "wm_greedy_step: negative temperature");
+    p.temperature = io->temperature; p.seed_lo = (uint32_t)io->seed; p.seed_hi = (uint32_t)(io->seed >> 32);
+    p.seed_dev = io->seed_dev; p.row0 = io->row0;
     return launch_greedy(p, (hipStream_t)stream);
 }
 

@@ -12,6 +12,13 @@
 //   decide: timestamps win if logsumexp(timestamps) > max(text)  (:191-199; the common log Z
 //           cancels), then the next token, its log-probability under the final mask, EOT
 //           stickiness and the append.
+// temperature > 0 (round 4): the reference draws next ~ Categorical(logits / T) on the host (GreedyDecoder.update, :282-285) and
+// books log_softmax(logits)[next] at T = 1.  Here the draw is a Gumbel-max: next = argmax_n (x_n / T + g_n), g_n = -log(-log u_n),
+// which has exactly that distribution; u_n comes from a counter-based generator keyed on (seed, global row, position, token), so
+// a draw depends on nothing but its own coordinates (not on the batch, the utterance groups or the launch shape), the same
+// kernel serves every step of a replayed graph (the seed sits in device memory) and the host can recompute any draw
+// (tests/test_gpu_round4.py).  The draws cannot equal torch's generator's: the distribution, the masks and the log-probability
+// bookkeeping are what the tests hold to the reference.
 #include "common.h"
 #include "kernels.h"
 
@@ -65,9 +72,20 @@ __device__ __forceinline__ T block_reduce(T v, F merge, T* scratch) {
 
 constexpr int GREEDY_THREADS = 1024;
 
+// uniform in (0, 1) from (seed, row, position, token): three rounds of the murmur3 finaliser over the mixed-in coordinates
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float gumbel_noise(uint32_t key, int n) {
+    const uint32_t h = fmix32(fmix32(key ^ ((uint32_t)n * 0x27d4eb2fu)) + 0x9e3779b9u * (uint32_t)n);
+    const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);          // (0, 1), 24 bits
+    return -__logf(-__logf(u));
+}
+
 __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) {
     __shared__ MS s_ms[2][GREEDY_THREADS / 64];
-    __shared__ AM s_am[2][GREEDY_THREADS / 64];
+    __shared__ AM s_am[4][GREEDY_THREADS / 64];
     __shared__ int s_info[4], s_hist[GREEDY_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int cur_len = p.t_dev ? *p.t_dev + 1 : p.cur_len;     // device step counter holds n_past = cur_len - 1
@@ -126,9 +144,24 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
 
     MS txt{-INFINITY, 0.f}, tsm{-INFINITY, 0.f};
     AM atxt{-INFINITY, 0x7fffffff}, ats{-INFINITY, 0x7fffffff};
+    // sampling: arg-max of the perturbed logits per class (wave-uniform switch; the greedy path is untouched)
+    const bool sampling = p.temperature > 0.f;
+    const float inv_temp = sampling ? 1.0f / p.temperature : 0.f;
+    uint32_t rng_key = 0;
+    if (sampling) {
+        const uint32_t s_lo = p.seed_dev ? p.seed_dev[0] : p.seed_lo, s_hi = p.seed_dev ? p.seed_dev[1] : p.seed_hi;
+        rng_key = fmix32(fmix32(s_lo ^ ((uint32_t)(p.row0 + b) * 0x9e3779b1u)) ^ s_hi ^ ((uint32_t)cur_len * 0x85ebca77u));
+    }
+    AM ptxt{-INFINITY, 0x7fffffff}, pts{-INFINITY, 0x7fffffff};
+    auto perturb = [&](int n, float x) {                           // one token of an allowed class
+        if (x == -INFINITY) return;
+        const float y = x * inv_temp + gumbel_noise(rng_key, n);
+        if (n < hi_txt) { if (y > ptxt.v) ptxt = AM{y, n}; }
+        else if (y > pts.v) pts = AM{y, n};
+    };
     auto visit = [&](int n, float x) {
-        if (n < hi_txt) { if (n >= lo_txt) { txt = ms_add(txt, x); if (x > atxt.v) atxt = AM{x, n}; } }
-        else if (n >= lo_ts && n < hi_ts) { tsm = ms_add(tsm, x); if (x > ats.v) ats = AM{x, n}; }
+        if (n < hi_txt) { if (n >= lo_txt) { txt = ms_add(txt, x); if (x > atxt.v) atxt = AM{x, n}; if (sampling) perturb(n, x); } }
+        else if (n >= lo_ts && n < hi_ts) { tsm = ms_add(tsm, x); if (x > ats.v) ats = AM{x, n}; if (sampling) perturb(n, x); }
     };
     // eight logits that all belong to one class: one maximum, at most one rescale of the running sum, eight exponentials --
     // instead of eight dependent (compare, branch, exponential) updates
@@ -157,9 +190,19 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
-        if (n0 >= lo_txt && n0 + 8 <= hi_txt) visit8(txt, atxt, n0, f);
-        else if (n0 >= hi_txt && n0 >= lo_ts && n0 + 8 <= hi_ts) visit8(tsm, ats, n0, f);
-        else {
+        if (n0 >= lo_txt && n0 + 8 <= hi_txt) {
+            visit8(txt, atxt, n0, f);
+            if (sampling) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) perturb(n0 + e, f[e]);
+            }
+        } else if (n0 >= hi_txt && n0 >= lo_ts && n0 + 8 <= hi_ts) {
+            visit8(tsm, ats, n0, f);
+            if (sampling) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) perturb(n0 + e, f[e]);
+            }
+        } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) visit(n0 + e, f[e]);
         }
@@ -170,7 +213,11 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
     // (thread 0 alone uses them)
     txt = wave_reduce(txt, ms_merge); tsm = wave_reduce(tsm, ms_merge);
     atxt = wave_reduce(atxt, am_merge); ats = wave_reduce(ats, am_merge);
-    if ((tid & 63) == 0) { s_ms[0][tid >> 6] = txt; s_ms[1][tid >> 6] = tsm; s_am[0][tid >> 6] = atxt; s_am[1][tid >> 6] = ats; }
+    if (sampling) { ptxt = wave_reduce(ptxt, am_merge); pts = wave_reduce(pts, am_merge); }
+    if ((tid & 63) == 0) {
+        s_ms[0][tid >> 6] = txt; s_ms[1][tid >> 6] = tsm; s_am[0][tid >> 6] = atxt; s_am[1][tid >> 6] = ats;
+        if (sampling) { s_am[2][tid >> 6] = ptxt; s_am[3][tid >> 6] = pts; }
+    }
     __syncthreads();
     if (tid >= 64) return;
     {
@@ -179,6 +226,10 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
         atxt = tid < NW ? s_am[0][tid] : AM{-INFINITY, 0x7fffffff}; ats = tid < NW ? s_am[1][tid] : AM{-INFINITY, 0x7fffffff};
         txt = wave_reduce(txt, ms_merge); tsm = wave_reduce(tsm, ms_merge);
         atxt = wave_reduce(atxt, am_merge); ats = wave_reduce(ats, am_merge);
+        if (sampling) {
+            ptxt = tid < NW ? s_am[2][tid] : AM{-INFINITY, 0x7fffffff}; pts = tid < NW ? s_am[3][tid] : AM{-INFINITY, 0x7fffffff};
+            ptxt = wave_reduce(ptxt, am_merge); pts = wave_reduce(pts, am_merge);
+        }
     }
 
     if (tid == 0) {
@@ -188,6 +239,10 @@ __global__ __launch_bounds__(GREEDY_THREADS) void greedy_kernel(GreedyParams p) 
             ts_only = lse_ts > txt.m;      // logsumexp(ts logprobs) > max(text logprobs)
         }
         AM best = ts_only ? ats : am_merge(atxt, ats);
+        if (sampling) {                 // the draw among the allowed tokens; its log-probability is the UNperturbed logit's (T = 1)
+            best = ts_only ? pts : am_merge(ptxt, pts);
+            if (best.i != 0x7fffffff) best.v = (float)lg[best.i];
+        }
         MS z = ts_only ? tsm : ms_merge(txt, tsm);
         const float logz = z.m + logf(z.s);
         const float lp = best.v - logz;

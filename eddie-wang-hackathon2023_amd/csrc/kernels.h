@@ -168,6 +168,9 @@ struct GreedyParams {
     const int32_t* t_dev;                    // optional device step counter: cur_len = *t_dev + 1
     int32_t* done;                           // optional [B]: 1 once the row's newest token is eot
     const int32_t* row_limit;                // optional [B]: at most that many sampled tokens per row, then eot (no log-prob)
+    float temperature;                       // > 0: draw from softmax(logits / temperature) (Gumbel-max) instead of the arg-max
+    uint32_t seed_lo, seed_hi; const uint32_t* seed_dev;     // the generator's seed: immediate, or [2] words in device memory (graph replay)
+    int row0;                                // global index of row 0 (draws are keyed on the global row, not on the launch)
 };
 int launch_greedy(const GreedyParams& p, hipStream_t stream);
 int launch_step_advance(int32_t* counter, hipStream_t stream);

@@ -253,6 +253,7 @@ class WhisperDecoding:
         self.run_ahead = 3                # decode steps the host may be ahead of the GPU in the partitioned loop
         self._partition = None            # (light streams, heavy stream), created on first use
         self.use_graphs = True            # replay one captured decode step per token (hipGraph)
+        self.device_sampling = True       # temperature > 0 / best_of > 1 through the fused device loop (False: the literal host loop)
         # Per-row completion (W/decoding.py:817-819 stops its single utterance at EOT): rows that have emitted EOT drop out
         # of the attention kernels (their cross K/V -- 245.76 MB per token at large-v2 -- and KV cache are no longer read)
         # and a group whose rows have all finished is no longer stepped.  Results are unchanged: a finished row is kept at
@@ -612,6 +613,7 @@ class WhisperDecoding:
             sum_logprobs=torch.zeros(n_batch, dtype=torch.float32, device=device),
             n_done=torch.zeros(1, dtype=torch.int32, device=device),
             done=torch.zeros(n_batch, dtype=torch.int32, device=device),          # per row: 1 once it has emitted EOT
+            seed=torch.zeros(2, dtype=torch.int32, device=device),                # the sampling generator's seed (temperature > 0)
             live={},
             # per-row sample_len (stable address: the captured graphs read it); 2^30 = no limit
             row_limit=torch.full((n_batch,), 1 << 30, dtype=torch.int32, device=device),
@@ -735,6 +737,9 @@ class WhisperDecoding:
         io.n_past_dev = n_past_dev.data_ptr() if n_past_dev is not None else None
         io.done = st['done'][lo:hi].data_ptr()
         io.row_limit = st['row_limit'][lo:hi].data_ptr()
+        # temperature > 0: the draw happens in the same kernel (Gumbel-max, counter-based generator keyed on the global row: lo + b);
+        # the seed lives in device memory so that a replayed graph draws afresh in every main_loop call
+        io.temperature, io.row0, io.seed_dev = float(self.options.temperature), lo, st['seed'].data_ptr()
         native.check(native.load_library().wm_greedy_step(C.byref(io), stream), "wm_greedy_step")
 
     def main_loop(self, audio_features, ignore_eot: bool = False, row_limit=None):
@@ -750,13 +755,22 @@ class WhisperDecoding:
         Rows that have emitted EOT drop out of the attention kernels and a group whose rows are all
         finished is no longer stepped (`skip_finished_rows`): the loop's cost follows the live rows."""
         if self.options.temperature != 0 or self.n_group != 1:
-            return self.main_loop_reference(audio_features)
+            # Sampling options (W/decoding.py:274-300 temperature, :92-115 best_of + ranker).  Round 4: the device loop takes them --
+            # the draw is a Gumbel-max inside the greedy kernel, candidates are rows like any others.  `device_sampling = False`
+            # (or tensors that are not on the GPU) keeps the literal host loop: torch's generator, the draws the goldens hold.
+            if not self.device_sampling or not audio_features.is_cuda:
+                return self.main_loop_reference(audio_features)
+            if self.n_group > 1:      # candidates share their utterance's audio: the reference repeats the features too (:538-539 of this file)
+                audio_features = audio_features.repeat_interleave(self.n_group, dim=0)
         dev = audio_features.device
-        tokens0 = self._initial_token_rows(audio_features.shape[0], dev)
+        tokens0 = self._initial_token_rows(audio_features.shape[0] // self.n_group, dev)
         n_batch, L0 = tokens0.shape
+        assert n_batch == audio_features.shape[0]
         cfg = self.decoder_config
         V, cap = cfg['vocab_size'], cfg['num_text_ctx']
         st = self._fast_state(n_batch, dev)
+        if self.options.temperature != 0:     # a fresh seed per call from torch's generator: torch.manual_seed makes a run repeatable
+            st['seed'].copy_(torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32))
         cross = self._cross_persistent(audio_features, st)
         st['tokens'].zero_()
         st['tokens'][:, :L0] = tokens0.to(torch.int32)

@@ -147,6 +147,8 @@ class WmGreedyIO(C.Structure):
         ("n_past_dev", C.c_void_p),
         ("done", C.c_void_p),
         ("row_limit", C.c_void_p),
+        ("temperature", C.c_float), ("row0", C.c_int32),
+        ("seed", C.c_uint64), ("seed_dev", C.c_void_p),
     ]
 
 

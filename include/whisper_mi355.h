@@ -172,6 +172,12 @@ typedef struct wm_greedy_io {
                                   without adding to its log-probability -- a per-utterance `sample_len` (the reference has
                                   one for the whole loop, W/decoding.py:328, whose loop ends the same way: no EOT
                                   log-probability, finalize pads the EOT) */
+    /* ABI 5: sampling (GreedyDecoder.update at temperature > 0, W/decoding.py:282-285).  temperature > 0: the next token is
+     * drawn from softmax(filtered logits / temperature) by a Gumbel-max with a counter-based generator keyed on (seed, row0 + b,
+     * position, token); sum_logprobs books log_softmax(filtered logits)[token] at temperature 1, as the reference does.
+     * seed_dev (optional, two uint32 words in device memory: low, high) overrides `seed` -- a replayed graph then draws afresh. */
+    float temperature; int32_t row0;
+    uint64_t seed; const uint32_t* seed_dev;
 } wm_greedy_io;
 int wm_greedy_step(const wm_greedy_io* io, wm_stream_t stream);
 int wm_step_advance(int32_t* counter, wm_stream_t stream);

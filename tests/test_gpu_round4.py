@@ -180,3 +180,139 @@ def test_cross_attention_v_skip_is_bit_identical(lib, B, L, Tk, scale):
         pr = torch.softmax(sc, dim=-1).half()
         dead = (pr.reshape(B, H, -1)[..., : Tk // 8 * 8].reshape(B, H, -1, 8) == 0).all(dim=-1).float().mean()
         assert float(dead) > (0.5 if L == 1 else 0.2)
+
+
+# ------------------------------------------------------------------------------------------ sampling inside the greedy kernel
+def _fmix32(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x85ebca6b)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(13); x = (x * np.uint64(0xc2b2ae35)) & np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def _host_gumbel(seed_lo, seed_hi, row, cur_len, V):
+    """The kernel's counter-based generator restated (csrc/greedy.hip: fmix32, gumbel_noise)."""
+    M = np.uint64(0xffffffff)
+    key = _fmix32(np.array([(seed_lo ^ ((row * 0x9e3779b1) & 0xffffffff)) & 0xffffffff], dtype=np.uint64))
+    key = _fmix32((key ^ np.uint64(seed_hi) ^ np.uint64((cur_len * 0x85ebca77) & 0xffffffff)) & M)[0]
+    n = np.arange(V, dtype=np.uint64)
+    h = _fmix32((key ^ ((n * np.uint64(0x27d4eb2f)) & M)) & M)
+    h = _fmix32((h + ((np.uint64(0x9e3779b9) * n) & M)) & M)
+    u = ((h >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return -np.log(-np.log(u.astype(np.float64)))
+
+
+def _greedy_call(lib, lg, tok_buf, cur, s, n_done, sup_d, blank_d, n_blank, rules, temperature, seed, row0=0, sample_begin=3):
+    ids = DR.MULTILINGUAL
+    io = native.WmGreedyIO()
+    B, V = lg.shape
+    io.logits, io.row_stride, io.batch, io.n_vocab = lg.data_ptr(), V, B, V
+    io.tokens, io.tokens_ld, io.cur_len = tok_buf.data_ptr(), tok_buf.shape[1], cur
+    io.sum_logprobs = s.data_ptr()
+    io.suppress, io.n_suppress = (sup_d.data_ptr(), sup_d.numel()) if sup_d is not None else (None, 0)
+    io.blank, io.n_blank = (blank_d.data_ptr(), n_blank) if blank_d is not None else (None, 0)
+    io.sample_begin, io.eot, io.timestamp_begin = sample_begin, ids.eot, ids.timestamp_begin
+    io.max_initial_timestamp_index, io.apply_rules, io.n_done = 50, rules, n_done.data_ptr()
+    io.temperature, io.row0, io.seed = temperature, row0, seed
+    native.check(lib.wm_greedy_step(C.byref(io), stream()))
+    torch.cuda.synchronize()
+
+
+def test_device_sampling_is_a_gumbel_max_with_the_reference_bookkeeping(lib):
+    """temperature > 0 inside the greedy kernel (round 4; the reference samples on the host: GreedyDecoder.update,
+    W/decoding.py:282-290).  (1) every draw equals the host's recomputation of argmax(x / T + g) with the kernel's generator
+    (so a draw depends on (seed, global row, position, token) only: the same rows in another launch shape draw the same);
+    (2) the booked log-probability is log_softmax(x)[token] at temperature 1; (3) over many rows the tokens follow
+    softmax(x / T)."""
+    V, T, seed, cur = 1000, 0.8, 0x1234567890ABCDEF, 9
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = (torch.randn(V, device="cuda", generator=g) * 2.0).half()
+    B = 4096
+    lg = base[None].repeat(B, 1).contiguous()
+    tok = torch.zeros((B, 16), dtype=torch.int32, device="cuda")
+    tok[:, :cur] = 7
+    s = torch.zeros(B, dtype=torch.float32, device="cuda")
+    n_done = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _greedy_call(lib, lg, tok, cur, s, n_done, None, None, 0, 0, T, seed, row0=100)
+    got = tok[:, cur].cpu().numpy()
+    x = base.float().cpu().numpy().astype(np.float64)
+    lp = x - (x.max() + np.log(np.exp(x - x.max()).sum()))
+    assert np.abs(s.cpu().numpy() - lp[got]).max() < 2e-4
+    for b in (0, 1, 63, 64, 1000, 4095):                      # exact draws, recomputed on the host
+        y = x / T + _host_gumbel(seed & 0xffffffff, seed >> 32, 100 + b, cur, V)
+        assert y[got[b]] >= y.max() - 1e-3, b
+    # the same global rows in a smaller launch: same draws
+    tok2 = torch.zeros((64, 16), dtype=torch.int32, device="cuda"); tok2[:, :cur] = 7
+    s2 = torch.zeros(64, dtype=torch.float32, device="cuda")
+    _greedy_call(lib, lg[:64].contiguous(), tok2, cur, s2, n_done, None, None, 0, 0, T, seed, row0=100 + 512)
+    assert np.array_equal(tok2[:, cur].cpu().numpy(), got[512:576])
+    # distribution: the 20 likeliest tokens within 4.5 sigma of their probability
+    pr = np.exp(x / T - (x / T).max()); pr /= pr.sum()
+    freq = np.bincount(got, minlength=V) / B
+    top = np.argsort(-pr)[:20]
+    assert (np.abs(freq[top] - pr[top]) <= 4.5 * np.sqrt(pr[top] * (1 - pr[top]) / B) + 1e-4).all()
+    # another seed: other draws
+    tok3 = torch.zeros((B, 16), dtype=torch.int32, device="cuda"); tok3[:, :cur] = 7
+    _greedy_call(lib, lg, tok3, cur, torch.zeros_like(s), n_done, None, None, 0, 0, T, seed + 1, row0=100)
+    assert (tok3[:, cur].cpu().numpy() != got).mean() > 0.5
+
+
+def test_device_sampling_respects_the_rules(lib, golden_dir):
+    """Sampled tokens come from the allowed set only: with Whisper's rules on (apply_rules = 1) at the first sampled position every
+    draw is an initial timestamp <= 1.00 s, whatever the temperature (ApplyTimestampRules, W/decoding.py:134-199)."""
+    fixr = np.load(os.path.join(golden_dir, "decoding_rules.npz"))
+    ids = DR.MULTILINGUAL
+    V, tb = ids.n_vocab, ids.timestamp_begin
+    sup = sorted(set(fixr["suppress"].tolist() + [ids.no_timestamps]))
+    sup_d = torch.tensor(sup, dtype=torch.int32, device="cuda")
+    blank_d = torch.tensor(fixr["blank"].astype(np.int32), device="cuda")
+    B = 256
+    g = torch.Generator(device="cuda").manual_seed(9)
+    lg = (torch.randn(B, V, device="cuda", generator=g) * 2.0).half()
+    tok = torch.zeros((B, 16), dtype=torch.int32, device="cuda")
+    tok[:, 0], tok[:, 1], tok[:, 2] = ids.sot, ids.lang0, ids.transcribe
+    s = torch.zeros(B, dtype=torch.float32, device="cuda")
+    n_done = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _greedy_call(lib, lg, tok, 3, s, n_done, sup_d, blank_d, len(fixr["blank"]), 1, 5.0, 77)
+    first = tok[:, 3].cpu().numpy()
+    assert ((first >= tb) & (first <= tb + 50)).all() and len(set(first.tolist())) > 10          # hot: many different timestamps
+    assert np.isfinite(s.cpu().numpy()).all() and (s.cpu().numpy() < 0).all()
+
+
+def test_best_of_sampling_runs_the_fused_loop(tmp_path_factory):
+    """temperature / best_of through the fused device loop (round 3 sent them to the literal host loop): the literal loop is not
+    called, candidates are rows (n_audio x best_of), a run is repeatable under torch.manual_seed, another seed draws other
+    candidates, and `device_sampling = False` still gives the host path.  The candidates' log-probabilities under the oracle
+    are checked in tests/test_gpu_round3.py::test_sampled_candidates_logprobs_match_oracle, which runs this path now."""
+    import synthetic
+    from decoding import DecodingOptions, WhisperDecoding
+    from encoding import WhisperEncoding
+    from oracle.whisper_oracle import Dims, synthetic_mel
+    from test_gpu_model import build_engine
+    tmp = tmp_path_factory.mktemp("bestof")
+    dims = Dims(**synthetic.DIMS["micro-fullvocab"])
+    eng = build_engine(tmp, "micro-fullvocab", 3)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(6, 2 * dims.n_audio_ctx, dims.n_mels, 79).cuda())
+    dec = WhisperDecoding(eng, options=DecodingOptions(temperature=0.9, best_of=5, sample_len=8))
+    dec.detect_language(xa)
+    calls = {"ref": 0}
+    literal = dec.main_loop_reference
+    dec.main_loop_reference = lambda *a, **k: (calls.__setitem__("ref", calls["ref"] + 1), literal(*a, **k))[1]
+    torch.manual_seed(5)
+    t1, lp1, nsp1 = dec.main_loop(xa)
+    assert calls["ref"] == 0 and t1.shape[0] == 30 and len(nsp1) == 30
+    torch.manual_seed(5)
+    t2, lp2, _ = dec.main_loop(xa)
+    assert torch.equal(t1.cpu(), t2.cpu()) and torch.equal(lp1.cpu(), lp2.cpu())
+    torch.manual_seed(6)
+    t3, _, _ = dec.main_loop(xa)
+    assert not torch.equal(t1.cpu(), t3.cpu())
+    grp = t1.cpu().numpy().reshape(6, 5, -1)
+    assert sum(len({tuple(r) for r in g.tolist()}) > 1 for g in grp) >= 4          # candidates of an utterance differ
+    out = dec.post_process(t1, lp1, nsp1, xa, ["en"] * 6)
+    assert len(out) == 6 and all(np.isfinite(r.avg_logprob) for r in out)
+    dec.device_sampling = False
+    dec.main_loop(xa)
+    assert calls["ref"] == 1
