@@ -79,7 +79,6 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     const int my_tiles = (hi - lo - j0 + per_xcd - 1) > 0 ? (hi - lo - j0 + per_xcd - 1) / per_xcd : 0;
     if (my_tiles == 0) return;
     const int nk = p.K / BK;                         // stages per tile
-    const int total_stages = my_tiles * nk;
     // Order of a band's tiles.  In plain row-major order the workgroups of an XCD, which march over K roughly in step, hold
     // ~32 / nt_n row panels against ALL nt_n channel tiles: each A panel is fetched once, but the whole weight matrix streams
     // through the XCD's 4 MB L2 once per row panel (N = 5120, K = 1280: 13 MB of W per 0.66 MB of A -- the kernel fetched 11x
@@ -129,18 +128,24 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
             a_lane[q] = (uint32_t)((row_offset(gr) - off0) * 2) + c * 16;
         }
     };
-    int load_ks = 0, load_tile = 0, issued = 0;      // stage whose pieces are requested next (issued = its stream number)
-    auto issue_half = [&](int half) {                // this wave's A piece and W piece number `half` of stream stage `issued`
-        if (issued >= total_stages) return;
-        unsigned char* slot = smem + (issued % STAGES) * STAGE + (wid + NWAVE * half) * 1024;
+    // Round 4: the loader's bookkeeping off the intervals' critical path (profiles/r4h_gemm_skeleton_ablation.log: with the DMA
+    // requests and fragment reads taken out, the scalar code and branches around them still cost 3-16 % of a launch).  The
+    // loader NEVER stops: past the last stage of the workgroup's last tile it goes on requesting that tile's first stages
+    // (valid memory, slots whose stages have been multiplied) -- so there is no "anything left?" test per request, the queue
+    // always holds the same number of pieces and every stage wait is the same counted wait; the ring slot is a running offset
+    // instead of a modulo; the one stage wait that differs (the first of a tile, with the epilogue's stores in the queue) is peeled.
+    int load_ks = 0, load_tile = 0;                  // stage of its tile whose pieces are requested next
+    uint32_t load_slot = 0;                          // byte offset of that stage's ring slot
+    auto issue_half = [&](int half) {                // this wave's A piece and W piece number `half` of the stage being requested
+        unsigned char* slot = smem + load_slot + (wid + NWAVE * half) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
                                          (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_lane[half]),
                                          (__attribute__((address_space(3))) void*)(slot + A_PART), 16, 0, 0);
         if (half == 1) {
             a_base += BK * 2; w_base += BK * 2;
-            ++issued;
-            if (++load_ks == nk) { load_ks = 0; ++load_tile; if (load_tile < my_tiles) set_tile(load_tile); }
+            load_slot = (load_slot + STAGE) & (STAGES * STAGE - 1);
+            if (++load_ks == nk) { load_ks = 0; ++load_tile; set_tile(load_tile < my_tiles ? load_tile : my_tiles - 1); }
         }
     };
     set_tile(0);
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     // complete and the first half of stage STAGES - 2
 #pragma unroll 1
     for (int s2 = 0; s2 < 2 * (STAGES - 2) + 1; ++s2) issue_half(s2 & 1);
+    // (the half numbering of that loop: 0, 1, 0, 1, 0 -- stages 0 and 1 complete, the first half of stage 2)
 
     // ---- fragment addresses inside a stage --------------------------------------------------------------------------
     const int sw = (4 - ((lane >> 2) & 3)) & 3;                                   // the rows a lane reads have (r >> 2) & 3 = (lane >> 2) & 3
@@ -170,8 +176,8 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     // barriers are the clock of that alternation; waves 4-7 run one barrier behind waves 0-3.
     if (wid >= 4) __builtin_amdgcn_s_barrier();
 
-    int cons = 0;                                    // stream stage being multiplied
-    int ks = 0, t = 0;
+    uint32_t cons_slot = 0;                          // ring slot (byte offset) of the stage being multiplied
+    int t = 0;
     bool after_epilogue = false;                     // the next stage wait has this wave's epilogue stores in its queue
     auto zero_acc = [&]() {
 #pragma unroll
@@ -180,8 +186,9 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
             for (int j = 0; j < 8; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    for (;;) {
-        const unsigned char* st = smem + (cons % STAGES) * STAGE;
+    auto stage = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;      // the first stage of a tile: its wait may have the epilogue's stores in front
+        const unsigned char* st = smem + cons_slot;
         // ---- first half of the channels: fragments, DMA requests | barrier | 16 MFMAs | barrier ------------------------
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 1024);
@@ -207,10 +214,8 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         // landed before the next barrier.  Its last pieces were requested STAGES - 3 stages ago; WAIT younger requests may stay
         // in flight -- plus, on the first stage after an epilogue, the epilogue's stores, which sit behind those pieces in the
         // queue and must not be waited for here (they drain while the next stage is multiplied).
-        if (issued >= total_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT + N_STORES) : "memory");
+        if (FIRST && after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT + N_STORES) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT) : "memory");
-        after_epilogue = false;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -222,8 +227,13 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        ++cons;
-        if (++ks < nk) continue;
+        cons_slot = (cons_slot + STAGE) & (STAGES * STAGE - 1);
+    };
+    for (;;) {
+        stage(std::true_type{});
+        after_epilogue = false;
+#pragma unroll 1
+        for (int ks = 1; ks < nk; ++ks) stage(std::false_type{});
 
         // Waves 4-7 run one barrier behind: their last barrier of the tile pairs with THIS one.  Without it (round 2) it paired with
         // waves 0-3's first barrier of the next tile, i.e. waves 4-7 sat behind their finished last multiply until waves 0-3 had
@@ -455,11 +465,11 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         }
         // the store count the next stage wait adds is exact only for a tile without an M tail (rows past M skip their stores)
         if (row0 + BM <= p.M) after_epilogue = true; else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ks = 0;
         if (++t == my_tiles) break;
         zero_acc();
         if (wid >= 4) __builtin_amdgcn_s_barrier();  // one barrier behind waves 0-3 again
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loader's run-ahead requests (never read) land before the workgroup's LDS is released
 }
 
 bool gemm_f16p_supports(const GemmBigParams& p) {

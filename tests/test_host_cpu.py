@@ -378,3 +378,18 @@ def test_persistent_gemm_generated_code_matches_its_store_count():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_gemm_isa.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]
     assert r.stdout.count("ok ") == 6
+
+
+def test_encoder_attention_main_loop_stays_at_its_instruction_floor():
+    """csrc/attn_encoder.hip's tile loop is VALU-issue bound (one v_exp_f32, one mixed-precision fma, half a pair conversion each for
+    the score and the probability, ... per score: the arithmetic contract's roundings): scripts/check_attn_isa.py counts the
+    generated instructions per 64-key tile (hipcc -S, no GPU) and fails when the loop grows or spills."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_attn_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert r.stdout.count("ok ") == 2
