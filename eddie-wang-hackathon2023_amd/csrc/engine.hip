@@ -146,6 +146,9 @@ struct wm_engine {
     // decoder
     const void* emb_t = nullptr; int emb_blocks = 0; const h16 *lnfg = nullptr, *lnfb = nullptr;
     std::vector<DecLayer> dec;
+    // the one-row chain's stage descriptors (gemv_chain.hip), six per layer in chain order: out, cq | cout, mlp1, mlp2, qkv of the
+    // next layer -- on the device (the kernels read them there) and on the host (the launcher's checks)
+    wm::ChainStage* chain_dev = nullptr; std::vector<wm::ChainStage> chain_host;
     bool w8() const { return flags & WM_FLAG_WEIGHT_ONLY_INT8; }
     bool i8kv() const { return flags & WM_FLAG_INT8_KV; }
     bool i8cross() const { return flags & WM_FLAG_INT8_CROSS_KV; }
@@ -376,6 +379,31 @@ int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** ou
             e->scalars[nm] = v;
         }
     if (resolve(e)) { (void)hipFree(e->dev); delete e; return 1; }
+    if (e->kind == WM_ENGINE_DECODER && !e->dec.empty()) {
+        const int n = (int)e->dec.size();
+        e->chain_host.resize((size_t)6 * n);
+        auto fill = [](wm::ChainStage& st, const Lin& l, const h16* g, const h16* b, int mode) {
+            st.Wt = l.w; st.scale = l.s; st.bias = l.b; st.ln_g = g; st.ln_b = b; st.K = l.K; st.n_blocks = l.n_blocks; st.mode = mode; st.pad_ = 0;
+        };
+        for (int i = 0; i < n; ++i) {
+            const DecLayer& L = e->dec[i];
+            wm::ChainStage* st = &e->chain_host[(size_t)6 * i];
+            fill(st[0], L.out, nullptr, nullptr, 2);
+            fill(st[1], L.cq, L.lncg, L.lncb, 0);
+            fill(st[2], L.cout, nullptr, nullptr, 2);
+            fill(st[3], L.mlp1, L.ln2g, L.ln2b, 1);
+            fill(st[4], L.mlp2, nullptr, nullptr, 2);
+            if (i + 1 < n) fill(st[5], e->dec[i + 1].qkv, e->dec[i + 1].ln1g, e->dec[i + 1].ln1b, 0);
+            else st[5] = wm::ChainStage{};
+        }
+        const size_t bytes = e->chain_host.size() * sizeof(wm::ChainStage);
+        if (hipMalloc((void**)&e->chain_dev, bytes) != hipSuccess ||
+            hipMemcpy(e->chain_dev, e->chain_host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("wm_engine_create: the decode chain's descriptor table could not be placed on the device");
+            if (e->chain_dev) (void)hipFree(e->chain_dev);
+            (void)hipFree(e->dev); delete e; return 2;
+        }
+    }
     *out = e;
     return 0;
 }
@@ -383,6 +411,7 @@ int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** ou
 void wm_engine_destroy(wm_engine* e) {
     if (!e) return;
     if (e->dev) { (void)hipSetDevice(e->device); (void)hipFree(e->dev); }
+    if (e->chain_dev) (void)hipFree(e->chain_dev);
     delete e;
 }
 
@@ -516,7 +545,8 @@ int prof_slot(Profiler& pr, int layer, hipStream_t s) {
     return (int)pr.used++;
 }
 
-struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total; };
+struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total;
+               unsigned long long *gran_x, *gran_h; unsigned* generation; };      // granule edges of the one-row chain (gemv_chain.hip) and its call counter
 
 int cross_nsplit(int B, int H) {
     // Pieces the key range of the decode cross-attention is cut into (one workgroup per (utterance, head, piece), partial
@@ -555,6 +585,9 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
     w.part = c.take<float>(w.part_elems);
     w.nsplit = cross_nsplit(B, d.n_text_head);
     w.cross_ws = c.take<float>((size_t)B * d.n_text_head * w.nsplit * L * 66);
+    w.gran_x = c.take<unsigned long long>(C / 2 + 8);
+    w.gran_h = c.take<unsigned long long>(2 * C + 8);
+    w.generation = c.take<unsigned>(4);
     w.total = align_up(c.off);
     return w;
 }
@@ -608,6 +641,10 @@ constexpr int SMALL_PATH_DEFAULT_ROWS = 16;
 // decode step at B = 576 went from 26.1 to 30.3 ms -- profiles/r2d_b576_fused_skinny_ks1_kernel_stats.csv.  Not kept.)
 // exact V-row skipping of the decode cross-attention (attn_decode.hip, SKIP): on unless switched off (wm_set_cross_v_skip)
 std::atomic<int> g_cross_v_skip{CROSS_V_SKIP_DEFAULT};
+// the one-row chain (gemv_chain.hip): a decoder layer at batch 1 in 5 launches instead of 9 (wm_set_decode_chain)
+std::atomic<int> g_decode_chain{DECODE_CHAIN_DEFAULT};
+std::atomic<int> g_chain_cus[64];
+std::atomic<unsigned*> g_chain_err_dev[64];
 std::atomic<int> g_small_rows{-1};        // -1: not yet read from the environment
 int small_path_max_rows() {               // WM_SMALL_PATH=<rows> / wm_set_small_batch_rows: the fused path serves M <= rows (0: never)
     int r = g_small_rows.load(std::memory_order_relaxed);
@@ -654,6 +691,8 @@ struct GroupStep {
     const wm_engine* e; const wm_decoder_io* io; DecWs w;
     int B, L, T, C, H, M;
     bool small = false;                          // the fused small-batch path (gemv_small.hip)
+    bool chain = false;                          // ... with its Linears chained inside one launch (one row: gemv_chain.hip)
+    int chain_wgs = 0; unsigned* chain_err = nullptr;
     bool rows = false;                           // the fused row-split path (gemm_rows.hip)
     bool fused() const { return small || rows; }
 
@@ -698,7 +737,35 @@ struct GroupStep {
         WM_REQUIRE(io->workspace_bytes >= w.total, "decoder workspace too small: %zu < %zu", io->workspace_bytes, w.total);
         small = M <= small_path_max_rows();
         rows = !small && rows_path_min_rows() > 0 && M >= rows_path_min_rows() && !e->dec.empty() && gemm_rows_supports(C, e->dec[0].qkv.wcode);
+        chain = false;
+        if (small && M == 1 && !e->dec.empty() && e->chain_dev && g_decode_chain.load(std::memory_order_relaxed) && !io->qkv_amax) {
+            const int slot = e->device >= 0 && e->device < 64 ? e->device : 0;
+            int n_cu = g_chain_cus[slot].load(std::memory_order_relaxed);
+            unsigned* errw = g_chain_err_dev[slot].load(std::memory_order_relaxed);
+            if (n_cu == 0 || !errw) {
+                int v = 0;
+                WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, e->device));
+                n_cu = v > 0 ? v : 1;
+                if (gemv_chain_err_word(&errw)) return 2;
+                g_chain_cus[slot].store(n_cu, std::memory_order_relaxed);
+                g_chain_err_dev[slot].store(errw, std::memory_order_relaxed);
+            }
+            if (gemv_chain_supports(C, e->dec[0].qkv.wcode, n_cu)) { chain = true; chain_wgs = n_cu > 256 ? 256 : n_cu; chain_err = errw; }
+        }
         return 0;
+    }
+
+    // a chain of layer i's Linears in one launch (one row): `first` .. `first + n - 1` of the layer's six stage descriptors.
+    // launch_id: unique per launch of a step (the granules' epochs)
+    int run_chain(int i, int first, int n, const h16* in16, int launch_id, hipStream_t s) {
+        GemvChainParams p{};
+        p.n_stages = n; p.st = e->chain_dev + (size_t)6 * i + first;
+        p.out32 = w.part;
+        p.w8 = e->dec[i].out.wcode; p.gelu_kind = e->gelu();
+        p.in16 = in16; p.x = w.x; p.hid_out = nullptr;
+        p.gran_x = w.gran_x; p.gran_h = w.gran_h; p.err = chain_err;
+        p.generation = w.generation; p.launch_id = launch_id;
+        return launch_gemv_chain(p, &e->chain_host[(size_t)6 * i + first], chain_wgs, s);
     }
 
     int finish(const Lin& l, int ks, int mode, const h16* g, const h16* bta, h16* out, int ldo, int N, hipStream_t s) {
@@ -713,7 +780,8 @@ struct GroupStep {
     int begin(hipStream_t s) {
         const wm_dims& d = e->dims;
         EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
-                       (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev};
+                       (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev, nullptr};
+        ep.generation = chain ? w.generation : nullptr;      // the chain's granule epochs count the calls on this workspace
         if (launch_embed(ep, s)) return 2;
         if (small) return 0;                         // the first LayerNorm happens inside the qkv projection
         return launch_layernorm(w.x, C, M, C, e->dec[0].ln1g, e->dec[0].ln1b, w.xn, C, s);
@@ -725,7 +793,8 @@ struct GroupStep {
         int ks = 0;
         mark(i, 0, s);
         if (small) {
-            if (gemv(Lr.qkv, w.x, C, 0, Lr.ln1g, Lr.ln1b, nullptr, 0, s)) return 2;      // LN + qkv sums -> w.part [M][3C]
+            // (chained: layers > 0 got their qkv sums from the chain that closed the layer before)
+            if (!(chain && i > 0) && gemv(Lr.qkv, w.x, C, 0, Lr.ln1g, Lr.ln1b, nullptr, 0, s)) return 2;      // LN + qkv sums -> w.part [M][3C]
             ks = 1;
         } else if (rows) {     // xn = LayerNorm(x) came with the row kernel that closed the previous layer (or from begin())
             if (gemv(Lr.qkv, w.xn, C, 0, nullptr, nullptr, nullptr, 0, s)) return 2;
@@ -748,6 +817,12 @@ struct GroupStep {
         p.waves = self_attn_waves(M);
         if (launch_attn_self(p, s)) return 2;
         mark(i, 2, s);
+        if (chain) {                                   // [x += out(ctx)] -> [LN + q sums -> w.part] in one launch
+            if (run_chain(i, 0, 2, w.ctx, 2 * i, s)) return 2;
+            mark(i, 5, s);
+            cq_ks = 1;
+            return 0;
+        }
         if (fused()) {
             if (gemv(Lr.out, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;    // x += out(ctx)
             mark(i, 3, s);
@@ -798,6 +873,12 @@ struct GroupStep {
         const wm_dims& d = e->dims;
         int ks = 0;
         mark(i, 6, s);
+        if (chain) {             // [x += cout(ctx)] -> [LN + mlp1 + GELU] -> [x += mlp2] -> [LN + qkv sums of the next layer] in one launch
+            const bool more = i + 1 < d.n_text_layer;
+            const int rc = run_chain(i, 2, more ? 4 : 3, w.ctx, 2 * i + 1, s);
+            mark(i, 12, s);
+            return rc;
+        }
         if (fused()) {
             if (gemv(Lr.cout, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;
             mark(i, 7, s);
@@ -1123,6 +1204,23 @@ int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void
     p.out = (h16*)out; p.ldo = H * 64; p.nsplit = nsplit; p.ws = ws;
     p.skip_zero_rows = g_cross_v_skip.load(std::memory_order_relaxed);
     return launch_attn_cross(p, (hipStream_t)stream);
+}
+
+int wm_set_decode_chain(int on) {
+    const int prev = g_decode_chain.load(std::memory_order_relaxed);
+    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on ? 1 : 0), std::memory_order_relaxed);
+    return prev;
+}
+
+int wm_decode_chain_error(int* out) {
+    WM_REQUIRE(out, "wm_decode_chain_error: null argument");
+    unsigned* errw = nullptr;
+    if (gemv_chain_err_word(&errw)) return 2;
+    unsigned v[4] = {0, 0, 0, 0};
+    WM_CHECK_HIP(hipMemcpy(v, errw, sizeof(v), hipMemcpyDeviceToHost));
+    *out = (int)v[0];
+    if (v[0]) { const unsigned z[4] = {0, 0, 0, 0}; WM_CHECK_HIP(hipMemcpy(errw, z, sizeof(z), hipMemcpyHostToDevice)); }
+    return 0;
 }
 
 int wm_set_cross_v_skip(int on) {

@@ -1,0 +1,367 @@
+// ONE launch for a CHAIN of the small-batch path's fused Linears (gemv_small.hip) at one activation row -- the reference's own
+// operating point, batch 1 (W/run.py:43-46, W/decoding.py:785-821):
+//
+//     [out projection + residual] -> [LayerNorm + cross-attention query projection]                      (2 stages)
+//     [out projection + residual] -> [LayerNorm + mlp1 + GELU] -> [mlp2 + residual] -> [LayerNorm + qkv of the next layer]   (4)
+//
+// so that a decoder layer is 5 launches instead of 9.  Replaces the same reference code as gemv_small.hip (weight_only_gemv_launcher,
+// weightOnlyMatrixVectorMultiplication.cu:136-277; the small-M branch of WeightOnlyQuantMatmulPlugin::enqueue; the element-wise
+// layers around the Linears, whisper/model.py:61-122) -- with gemv_small's arithmetic, bit for bit (tests/test_gpu_round4.py).
+//
+// Why, and why only one row.  At batch 1 a token step is ~ 300 dependent launches of ~ 5.5 us: ~ 2.5 us of kernel boundary and
+// ~ 3 us of body, most of the body the round trip of the weights.  Rounds 2-3 removed launches by REDUNDANT recomputation and
+// gained nothing; every hand-off between workgroups inside a launch they tried went through fences or flags
+// and was slower than the boundary.  scripts/lab/edge_lab.hip (profiles/r4d_*, r4k_*) measured the one form that is not: the
+// activation vector as 8-byte {epoch, value} GRANULES, each written by one write-through (sc1) store, every consumer sweeping
+// the whole vector with 16-byte sc1 loads (all in flight, one wait) until every tag carries the stage's epoch -- no flag, no
+// fence, no barrier: 1.9 us per all-to-all edge for 2 048 halves, 2.6 us for 5 120, against 2.0-4.2 us for a kernel boundary
+// around a trivial body.  The edge grows with rows x width (4 rows: 3.5 us, 16 rows of 8-byte loads: 25 us) where a boundary
+// does not, so the chain serves ONE row; and a workgroup requests the weights of its next stage BEFORE it waits for that
+// stage's input, so the weights' round trip runs under the wait instead of behind it.
+//
+// Structure.  Workgroups of eight waves, one per CU, alive for the whole chain.  A stage with K <= 4 x 320 inputs is run by
+// "slots" of four waves (a slot = one group of 16 output channels = gemv_small's workgroup: its waves split K as there, meet in
+// LDS in wave order), two slots per workgroup; K = 4 n_state (mlp2) by all eight waves as one slot, two K slices per wave,
+// the sixteen slices added in slice order as gemv_small's sixteen waves are.  The workgroup that owns channels 16 c .. 16 c + 15
+// of the residual stream owns them in every stage (its copy lives in LDS), so the residual adds need no exchange.
+// Every wait is bounded: a wave that gives up sets *err and the rest of the chain falls through (the host checks the word).
+#include "common.h"
+#include "kernels.h"
+
+namespace wm {
+
+typedef __attribute__((address_space(1))) unsigned long long chain_gu64;
+
+constexpr int CHAIN_MAX_IN = 4 * 1536;     // widest stage input (halves): mlp2's K = 4 n_state
+
+__device__ __forceinline__ bool chain_failed(const unsigned* err) {
+    return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
+// NL 16-byte sc1 loads per lane (two granules each) from granule indices first[k] (even), repeated until every tag is `epoch`.
+// All loads of a pass are in flight together; the destinations are named in the wait statement (cdna_hip_programming.md 5.7,
+// form (ii)).  Returns false when the wait was given up.
+template <int NL>
+__device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran, const int (&first)[NL], unsigned epoch, u32x4 (&val)[NL],
+                                                 unsigned* err, int lane) {
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(val[k]) : "v"(gran + first[k]) : "memory");
+        if constexpr (NL == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]) :: "memory");
+        else if constexpr (NL == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]) :: "memory");
+        else static_assert(NL == 3 || NL == 6, "sweep sizes of the chain");
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) ok &= val[k].y == epoch && val[k].w == epoch;
+        if (__all(ok)) return true;
+        if ((spins & 63) == 63 && chain_failed(err)) return false;
+        if (spins > (1u << 20)) {                     // ~ a second: a workgroup of the chain is not running
+            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// one stage of the chain.  WIDE: one slot of eight waves, two K slices per wave (K = 4 n_state); LN: LayerNorm of the
+// residual-stream row in the prologue.
+template <int WB, bool WIDE, bool LN>
+__device__ __forceinline__ void chain_stage(const GemvChainParams& p, const ChainStage& st, int s, unsigned epoch, bool& own_valid,
+                                            float (*s_red)[64][4], h16 (*s_in)[CHAIN_MAX_IN + 8], h16 (*s_own)[16]) {
+    constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);   // inputs per 1 KiB weight tile
+    constexpr int NM = KT / 32;
+    constexpr int TB = WB == 16 ? 10 : 5;
+    constexpr int NS = WIDE ? 2 : 1;                          // K slices per wave
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, rl = lane & 15;
+    const int kt_total = st.K / KT;
+    const int slices = (kt_total + TB - 1) / TB;
+    const int tps = (kt_total + slices - 1) / slices;         // tiles per K slice (gemv_small: ksplit = slices)
+    const int slot = WIDE ? 0 : wid >> 2, wslot = WIDE ? wid : wid & 3;
+    const int grp = blockIdx.x + slot * gridDim.x;            // this slot's group of 16 output channels
+    const bool has_group = grp < st.n_blocks;
+    const int nb = has_group ? grp : st.n_blocks - 1;         // (idle slots re-read valid memory; nothing of theirs is stored)
+
+    // ---- 1. every weight tile of this wave's K slices is requested now, before anything is waited for -------------------
+    u32x4 wreg[NS][TB];
+    int t_begin[NS], t_end[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int slice = wslot + 8 * j;
+        t_begin[j] = min(slice, slices - 1) * tps;
+        t_end[j] = (slice < slices && has_group) ? min(kt_total, t_begin[j] + tps) : t_begin[j];     // (an absent slice multiplies nothing)
+        const u32x4* wt = (const u32x4*)st.Wt + (size_t)nb * kt_total * 64 + lane;
+        const int t_last = max(min(kt_total, t_begin[j] + tps) - 1, 0);
+        if (slice < slices && has_group) {                    // (wave-uniform: an idle slot or an absent slice streams nothing)
+#pragma unroll
+            for (int i = 0; i < TB; ++i) wreg[j][i] = __builtin_nontemporal_load(wt + (size_t)min(t_begin[j] + i, t_last) * 64);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TB; ++i) wreg[j][i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    half8v a[NS][TB][NM];
+
+    // ---- 2. the stage's input row ------------------------------------------------------------------------------------------
+    if constexpr (LN) {
+        // gemv_small's LayerNorm at one row: wave 0 of the slot holds the row in registers (a lane: pieces lane, lane + 64,
+        // lane + 128 of 8 halves), two-pass fp32 statistics, affine step, the normalised row to LDS -- same operations, same order
+        constexpr int XP = 3;
+        const int pieces_per_row = st.K >> 3;
+        if (wslot == 0 && has_group) {
+            half8v xr[XP], gp[XP], bp[XP];
+#pragma unroll
+            for (int u = 0; u < XP; ++u) {
+                gp[u] = *(const half8v*)(st.ln_g + min(lane + 64 * u, pieces_per_row - 1) * 8);
+                bp[u] = *(const half8v*)(st.ln_b + min(lane + 64 * u, pieces_per_row - 1) * 8);
+            }
+            bool ok = true;
+            if (s == 0) {                                     // the row as the launches before this one left it (plain memory)
+#pragma unroll
+                for (int u = 0; u < XP; ++u) xr[u] = *(const half8v*)(p.x + min(lane + 64 * u, pieces_per_row - 1) * 8);
+            } else {                                          // the row the previous stage's owners have just published
+                int first[2 * XP];
+                u32x4 val[2 * XP];
+#pragma unroll
+                for (int u = 0; u < XP; ++u) {                // piece q = granules 4 q .. 4 q + 3 = two 16-byte loads
+                    const int q = min(lane + 64 * u, pieces_per_row - 1);
+                    first[2 * u] = 4 * q; first[2 * u + 1] = 4 * q + 2;
+                }
+                ok = sweep_granules16<2 * XP>(p.gran_x, first, epoch - 1, val, p.err, lane);
+#pragma unroll
+                for (int u = 0; u < XP; ++u) {
+                    const u32x4 v = u32x4{val[2 * u].x, val[2 * u].z, val[2 * u + 1].x, val[2 * u + 1].z};
+                    xr[u] = __builtin_bit_cast(half8v, v);
+                }
+            }
+            if (ok) {
+                float sum = 0.f;
+#pragma unroll
+                for (int u = 0; u < XP; ++u)
+                    if (lane + 64 * u < pieces_per_row) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum += (float)xr[u][e];
+                    }
+                const float mean = wave_sum_pre_mfma(sum) / (float)st.K;
+                float sq = 0.f;
+#pragma unroll
+                for (int u = 0; u < XP; ++u)
+                    if (lane + 64 * u < pieces_per_row) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = (float)xr[u][e] - mean; sq += d * d; }
+                    }
+                const float rstd = rsqrtf(wave_sum_pre_mfma(sq) / (float)st.K + 1e-5f);
+#pragma unroll
+                for (int u = 0; u < XP; ++u) {
+                    half8v x = xr[u];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = (h16)(((float)x[e] - mean) * rstd * (float)gp[u][e] + (float)bp[u][e]);
+                    if (lane + 64 * u < pieces_per_row) *(half8v*)(&s_in[slot][(lane + 64 * u) * 8]) = x;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            const int t_last = max(t_end[0] - 1, t_begin[0]);
+            const h16* arow = &s_in[slot][0] + (KT / 4) * g + (size_t)min(t_begin[0] + i, t_last) * KT;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) a[0][i][m] = *(const half8v*)(arow + m * 8);
+        }
+    } else if (s == 0) {
+        // the input row left by the launch before this one (attention context): fragments straight from memory, as gemv_small
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int t_last = max(min(kt_total, t_begin[j] + tps) - 1, 0);
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                const h16* arow = p.in16 + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
+            }
+        }
+    } else {
+        // the hidden row the previous stage has just published (mode 1): every wave sweeps the granules of ITS K slices into LDS
+        // (tps x KT halves per slice = 3 16-byte loads per lane at most) and reads its fragments back -- no barrier, its own data
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int n_in = (t_end[j] - t_begin[j]) * KT;                    // halves of this slice (0: absent)
+            const int g0 = t_begin[j] * KT / 2;                               // first granule
+            const int n_ld = n_in / 4;                                        // 16-byte loads (4 halves each)
+            int first[3];
+            u32x4 val[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) first[k] = g0 + 2 * min(lane + 64 * k, max(n_ld - 1, 0));
+            const bool ok = n_ld > 0 && sweep_granules16<3>(p.gran_h, first, epoch - 1, val, p.err, lane);
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (lane + 64 * k < n_ld) *(uint2*)(&s_in[0][t_begin[j] * KT + (lane + 64 * k) * 4]) = make_uint2(val[k].x, val[k].z);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave's LDS writes before its reads
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int t_last = max(t_end[j] - 1, t_begin[j]);
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                const h16* arow = &s_in[0][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
+            }
+        }
+    }
+
+    // ---- 3. multiply (gemv_small's loop), K slices to LDS scaled, in slice order ------------------------------------------
+    const int col = nb * 16 + rl;
+    const float sc = (WB != 16 && st.scale) ? (float)st.scale[col] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            const bool valid = t_begin[j] + i < t_end[j];     // wave-uniform
+            half8v b[NM];
+            if constexpr (WB == 16) {
+                b[0] = __builtin_bit_cast(half8v, wreg[j][i]);
+            } else if constexpr (WB == 8) {
+                half2v h[8];
+                cvt_s8x4_f16x4(wreg[j][i].x, h[0], h[1]);
+                cvt_s8x4_f16x4(wreg[j][i].y, h[2], h[3]);
+                cvt_s8x4_f16x4(wreg[j][i].z, h[4], h[5]);
+                cvt_s8x4_f16x4(wreg[j][i].w, h[6], h[7]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    b[0][2 * q] = h[q][0]; b[0][2 * q + 1] = h[q][1];
+                    b[1][2 * q] = h[4 + q][0]; b[1][2 * q + 1] = h[4 + q][1];
+                }
+            } else {
+                const uint32_t wv[4] = {wreg[j][i].x, wreg[j][i].y, wreg[j][i].z, wreg[j][i].w};
+                const half2v bias8 = {(h16)1032.0f, (h16)1032.0f};
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int sft = 0; sft < 4; ++sft) {
+                        const uint32_t bits = ((wv[m] >> (4 * sft)) & 0x000F000Fu) | 0x64006400u;
+                        const half2v pr = __builtin_bit_cast(half2v, bits) - bias8;
+                        b[m][2 * sft] = pr[0]; b[m][2 * sft + 1] = pr[1];
+                    }
+            }
+            if (valid) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j][i][m], b[m], acc, 0, 0, 0);
+            }
+        }
+        const int slice = wslot + 8 * j;
+        if (slice < slices) {
+            float4v v = acc;
+            v[0] *= sc; v[1] *= sc; v[2] *= sc; v[3] *= sc;
+            *(float4v*)&s_red[(WIDE ? 0 : 4 * slot) + slice][lane][0] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. epilogue of the slot (its wave 0; row 0 sits in the lanes of the first 16-lane group): gemv_small's, the result
+    // published as granules for the stages behind it ------------------------------------------------------------------------
+    if (wslot == 0 && has_group) {
+        float4v sum = *(const float4v*)&s_red[(WIDE ? 0 : 4 * slot)][lane][0];
+        for (int w = 1; w < slices; ++w) {
+            const float4v tw = *(const float4v*)&s_red[(WIDE ? 0 : 4 * slot) + w][lane][0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] += tw[r];
+        }
+        const float y = sum[0];                               // row 0 (lanes 0-15); the other lanes hold rows that do not exist
+        const float bias = (st.mode == 1 || st.mode == 2) && st.bias ? (float)st.bias[col] : 0.f;
+        if (st.mode == 0) {
+            if (g == 0) p.out32[col] = y;                     // raw sums for the attention kernel of the next launch
+        } else {
+            const float y16 = r16(y + bias);                  // the Linear's fp16 output
+            h16 out;
+            if (st.mode == 1) {
+                out = (h16)(p.gelu_kind == 2 ? gelu_tanh(y16) : gelu_erf(y16));
+            } else {                                          // mode 2: the residual stream, this slot's 16 channels
+                const h16 xo = own_valid ? s_own[slot][rl] : p.x[col];
+                out = (h16)r16((float)xo + y16);
+                if (g == 0) { s_own[slot][rl] = out; p.x[col] = out; }
+            }
+            if (st.mode == 1 && p.hid_out && g == 0) p.hid_out[col] = out;
+            // two channels per granule: the even lane stores {epoch, own | neighbour << 16}
+            const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, out);
+            const unsigned nb_bits = __shfl_xor(bits, 1);
+            if (g == 0 && (rl & 1) == 0) {
+                unsigned long long* dst = (st.mode == 1 ? p.gran_h : p.gran_x) + (col >> 1);
+                __hip_atomic_store((chain_gu64*)dst, ((unsigned long long)epoch << 32) | (bits | (nb_bits << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (st.mode == 2) own_valid = true;
+    __syncthreads();                                          // s_red / s_in are the next stage's
+}
+
+template <int WB>
+__global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
+    __shared__ __attribute__((aligned(16))) float s_red[16][64][4];
+    __shared__ __attribute__((aligned(16))) h16 s_in[2][CHAIN_MAX_IN + 8];
+    __shared__ __attribute__((aligned(16))) h16 s_own[2][16];
+    constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);
+    constexpr int TB = WB == 16 ? 10 : 5;
+    // epochs never repeat: the generation word counts the decoder calls on this workspace (the embedding kernel that opens a call
+    // increments it), the launch id the chains of a call, the low bits the stages of a chain
+    const unsigned epoch0 = (*p.generation << 9) | ((unsigned)p.launch_id << 2);
+    bool own_valid = false;
+    for (int s = 0; s < p.n_stages; ++s) {
+        const ChainStage st = p.st[s];                        // (uniform: scalar loads of a descriptor no kernel writes)
+        const bool wide = (st.K / KT + TB - 1) / TB > 4;
+        const unsigned epoch = epoch0 + (unsigned)s + 1;      // the tag this stage's results carry; its inputs carry epoch - 1
+        if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own);
+        else if (st.ln_g) chain_stage<WB, false, true>(p, st, s, epoch, own_valid, s_red, s_in, s_own);
+        else chain_stage<WB, false, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own);
+    }
+}
+
+// the word a wave sets when it gives up a bounded wait: one per device (the kernels get its address, wm_decode_chain_error reads it)
+__device__ unsigned g_chain_err[4];
+int gemv_chain_err_word(unsigned** out) {
+    void* ptr = nullptr;
+    WM_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_chain_err)));
+    *out = (unsigned*)ptr;
+    return 0;
+}
+
+bool gemv_chain_supports(int C, int w8, int n_cu) {
+    // LayerNorm rows in three 16-byte pieces per lane (K <= 1536), two slots per workgroup for the widest n_state-deep stage
+    // (mlp1: 4 C / 16 groups), at most 16 K slices for mlp2, one workgroup per CU
+    const int KT = w8 == 4 ? 128 : (w8 ? 64 : 32), TB = w8 ? 5 : 10;
+    const int slices_c = (C / KT + TB - 1) / TB, slices_4c = (4 * C / KT + TB - 1) / TB;
+    return C % KT == 0 && C % 16 == 0 && C <= 1536 && slices_c <= 4 && slices_4c <= 16 && (4 * C / 16 + 1) / 2 <= n_cu && C / 16 <= n_cu;
+}
+
+int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs, int n_wg, hipStream_t stream) {
+    WM_REQUIRE(p.n_stages >= 1 && p.n_stages <= CHAIN_MAX_STAGES, "gemv_chain: %d stages", p.n_stages);
+    WM_REQUIRE(p.x && p.gran_x && p.gran_h && p.err && p.generation && p.st && hs, "gemv_chain: null argument");
+    WM_REQUIRE(p.launch_id >= 0 && p.launch_id < 128, "gemv_chain: launch_id=%d", p.launch_id);
+    WM_REQUIRE(p.w8 == 0 || p.w8 == 1 || p.w8 == 4, "gemv_chain: w8=%d", p.w8);
+    const int KT = p.w8 == 4 ? 128 : (p.w8 ? 64 : 32);
+    int widest = 0;
+    for (int s = 0; s < p.n_stages; ++s) {
+        const ChainStage& st = hs[s];
+        WM_REQUIRE(st.Wt && st.K % KT == 0 && st.K <= CHAIN_MAX_IN && st.n_blocks >= 1, "gemv_chain: stage %d shape", s);
+        WM_REQUIRE(st.mode >= 0 && st.mode <= 2 && (st.mode != 0 || p.out32), "gemv_chain: stage %d mode %d", s, st.mode);
+        WM_REQUIRE(!st.ln_g || (st.ln_b && st.K <= 1536), "gemv_chain: stage %d LayerNorm needs beta and K <= 1536", s);
+        WM_REQUIRE(s > 0 || st.ln_g || p.in16, "gemv_chain: the first stage needs its input row");
+        WM_REQUIRE(s == 0 || st.ln_g || hs[s - 1].mode == 1, "gemv_chain: stage %d reads the hidden row, stage %d must produce it", s, s - 1);
+        WM_REQUIRE(s == 0 || !st.ln_g || hs[s - 1].mode == 2, "gemv_chain: stage %d normalises the residual row, stage %d must produce it", s, s - 1);
+        const int TB = p.w8 ? 5 : 10, slices = (st.K / KT + TB - 1) / TB;
+        const int need = slices > 4 ? st.n_blocks : (st.n_blocks + 1) / 2;
+        widest = widest > need ? widest : need;
+    }
+    WM_REQUIRE(n_wg >= widest, "gemv_chain: %d workgroups for stages that need %d", n_wg, widest);
+    if (p.w8 == 4) hipLaunchKernelGGL(gemv_chain_kernel<4>, dim3(n_wg), dim3(512), 0, stream, p);
+    else if (p.w8) hipLaunchKernelGGL(gemv_chain_kernel<8>, dim3(n_wg), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(gemv_chain_kernel<16>, dim3(n_wg), dim3(512), 0, stream, p);
+    WM_LAUNCH_CHECK(stream, "gemv_chain");
+    return 0;
+}
+
+}  // namespace wm

@@ -70,6 +70,33 @@ struct GemvSmallParams {
 constexpr int GEMV_SMALL_MAX_M = 32;
 int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
 
+// ---------------------------------------------------------------- gemv_chain.hip
+// A chain of gemv_small Linears at ONE activation row in one launch (batch 1): stage inputs / outputs between the stages travel
+// as {epoch, value} granules, the first stage reads plain memory, mode-0 results and the residual row go back to plain memory.
+constexpr int CHAIN_MAX_STAGES = 4;
+constexpr int DECODE_CHAIN_DEFAULT = 1;
+struct ChainStage {                                           // (an engine keeps its layers' stages in DEVICE memory: a chain's
+    const void* Wt; const h16* scale; const h16* bias;         // arguments stay small -- by value they were 330 bytes, and the runtime
+    const h16* ln_g; const h16* ln_b;                         // staged such argument blocks with a blit per launch under graph replay)
+    int K, n_blocks;                                          // tile-linear weights as GemvSmallParams; inputs; groups of 16 output channels
+    int mode;                                                 // 0: fp32 sums -> out32   1: gelu -> hidden row   2: residual row += ...
+    int pad_;
+};
+struct GemvChainParams {
+    int n_stages; const ChainStage* st;                       // n_stages consecutive descriptors in device memory
+    float* out32;                                             // where a mode-0 stage leaves its sums
+    int w8, gelu_kind;
+    const h16* in16;                                          // the first stage's input row when it has no LayerNorm (attention context)
+    h16* x;                                                   // residual row [C]: read by the first stage that needs it, rewritten by every mode-2 stage
+    h16* hid_out;                                             // optional copy of a mode-1 stage's output in plain memory (tests)
+    unsigned long long* gran_x; unsigned long long* gran_h;   // granule edges: C / 2 and 4 C / 2 entries
+    unsigned* err;                                            // set non-zero when a bounded wait gives up
+    const unsigned* generation; int launch_id;                // epochs: (*generation << 9) | (launch_id << 2), + stage + 1 (generation: one per decoder call)
+};
+bool gemv_chain_supports(int C, int w8, int n_cu);
+int gemv_chain_err_word(unsigned** out);                      // device address of this device's "a wait was given up" word
+int launch_gemv_chain(const GemvChainParams& p, const ChainStage* host_stages, int n_wg, hipStream_t stream);     // host_stages: the same descriptors, for the argument checks
+
 // ---------------------------------------------------------------- gemm_rows.hip
 // The same contract (GemvSmallParams, modes 0-2, optional LayerNorm prologue; ksplit unused) for ANY number of rows: the rows
 // are split over workgroups (16 or 32 rows x 64 channels each), the whole K per wave.  K <= 1536 (the input block sits in LDS).
@@ -103,6 +130,7 @@ struct EmbedParams {
     h16* x; int ldx;
     int n_vocab;
     const int32_t* t_dev;                    // optional device counter: token column / position row offset
+    unsigned* generation;                    // optional: incremented once per call (the one-row chain's epoch counter)
 };
 int launch_embed(const EmbedParams& p, hipStream_t stream);
 

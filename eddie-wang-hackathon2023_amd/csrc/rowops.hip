@@ -242,6 +242,9 @@ int launch_layernorm(const h16* x, int ldx, int M, int N, const h16* g, const h1
 __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
     const int m = blockIdx.x;
     const int T = p.t_dev ? *p.t_dev : 0;            // graph replay: column / position offset read on the device
+    // the step's generation number for the one-row chain's granule epochs (gemv_chain.hip): this kernel opens every decoder call,
+    // every chain of the call starts behind it
+    if (p.generation && m == 0 && threadIdx.x == 0) *p.generation += 1u;
     int tok = p.tokens[(size_t)(m / p.L) * p.tokens_ld + m % p.L + T];
     if (tok < 0) tok = 0;
     if (tok >= p.n_vocab) tok = p.n_vocab - 1;

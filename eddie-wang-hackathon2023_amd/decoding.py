@@ -876,8 +876,17 @@ class WhisperDecoding:
                             gr['active'] = False
         for s_ in streams:
             main.wait_stream(s_)
-        return self._finish_main_loop(st, cur, L0, n_batch, ignore_eot,
-                                      nsp_dev if self.tokenizer.no_speech is not None else None)
+        out = self._finish_main_loop(st, cur, L0, n_batch, ignore_eot,
+                                     nsp_dev if self.tokenizer.no_speech is not None else None)
+        if any(hi - lo == 1 for lo, hi in bounds):
+            # one-row groups run their Linears as in-launch chains (csrc/gemv_chain.hip) whose workgroups wait for each other with
+            # bounded spins: a wait that was given up (the chain's workgroups were not resident together) invalidates the step
+            err = C.c_int(0)
+            native.check(lib.wm_decode_chain_error(C.byref(err)), "wm_decode_chain_error")
+            if err.value:
+                raise RuntimeError("whisper_mi355: a decode-chain workgroup gave up waiting for its input (the GPU was not free to hold the "
+                                   "chain's workgroups together); rerun with wm_set_decode_chain(0)")
+        return out
 
     def _main_loop_partitioned(self, audio_features, st, cross, L0, n_micro, bounds, ignore_eot):
         """The decode loop scheduled for the chip (wm_decoder_step_multi): every group's cross-attention kernel

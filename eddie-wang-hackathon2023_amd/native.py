@@ -77,7 +77,7 @@ EXPORTS = (
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
     "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
-    "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_gemv_fused", "wm_gemm_rows", "wm_set_rows_path", "wm_set_small_batch_rows", "wm_set_self_attn_waves", "wm_set_gemm_small_tiles", "wm_lab_knobs", "wm_set_cross_v_skip", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
+    "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_gemv_fused", "wm_gemm_rows", "wm_set_rows_path", "wm_set_small_batch_rows", "wm_set_self_attn_waves", "wm_set_gemm_small_tiles", "wm_lab_knobs", "wm_set_cross_v_skip", "wm_set_decode_chain", "wm_decode_chain_error", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
     "wm_step_finish",
 )
 
@@ -203,6 +203,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_set_gemm_small_tiles.argtypes = [i32]
     lib.wm_lab_knobs.argtypes = [C.c_char_p, sz]
     lib.wm_set_cross_v_skip.argtypes = [i32]
+    lib.wm_set_decode_chain.argtypes = [i32]
+    lib.wm_decode_chain_error.argtypes = [C.POINTER(C.c_int)]
     lib.wm_gemm_skinny.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.wm_gemm_skinny_default_ksplit.argtypes = [i32, i32, i32, i32]
     lib.wm_layernorm.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp]

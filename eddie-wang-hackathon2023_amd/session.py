@@ -102,7 +102,9 @@ class Session(object):
     def _workspace(self, key: tuple, nbytes: int) -> torch.Tensor:
         ws = self._workspaces.get(key)
         if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=f"cuda:{self._device}")
+            # zeroed: the decoder's one-row chain keeps a call counter and tagged granules in its workspace (csrc/gemv_chain.hip);
+            # they must not start from whatever the allocator hands back
+            ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=f"cuda:{self._device}")
             self._workspaces[key] = ws
         return ws
 

@@ -268,6 +268,19 @@ int wm_set_self_attn_waves(int waves);
  * default.  Returns the previous value.  Both forms add an output element's products in the same order and share the
  * epilogue arithmetic: the results are bit-identical, a clip's encoder output does not depend on the batch it is in.     */
 int wm_set_gemm_small_tiles(int tiles);
+/* Batch 1 (one activation row: the reference's own operating point, W/run.py:43-46): the fused Linears of a decoder layer run as
+ * two CHAINS inside one launch each -- [out + residual -> LayerNorm + cross-attention q] and [out + residual -> LayerNorm + mlp1 +
+ * GELU -> mlp2 + residual -> LayerNorm + qkv of the next layer] -- 5 launches per layer instead of 9 (csrc/gemv_chain.hip: the
+ * stages hand the activation row over as tagged 8-byte granules, no fences, no barriers; weights of the next stage are requested
+ * before its input is waited for).  Same arithmetic as the launch-per-Linear form, bit for bit.  1 = on (default), 0 = off,
+ * < 0 = default; returns the previous value.  Captured graphs keep the form they were captured with.
+ * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a (bounded) wait since the last call -- the results of
+ * that step are not valid (a chain needs its <= 256 workgroups resident together; the word is cleared by the call; it
+ * synchronises with the device).
+ * The chain keeps a call counter and its tagged granules in the decoder WORKSPACE: zero the workspace once before its first
+ * use and leave it alone between calls (session.py allocates it zeroed).                                                     */
+int wm_set_decode_chain(int on);
+int wm_decode_chain_error(int* out);
 /* Exact V-row skipping in the decode cross-attention (fp16 K/V, single-pass form): a key whose softmax probability rounds to
  * fp16 zero contributes exactly nothing to P.V, so the wave instructions whose 8 rows all weigh zero do not fetch them from
  * HBM (they re-read 8 rows the workgroup has just used).  Outputs are bit-identical with it on or off for finite V.  1 = on

@@ -27,6 +27,61 @@ constexpr int NWG = 256;
 __device__ __forceinline__ unsigned mix(unsigned a, unsigned b) { return (a * 2654435761u) ^ (b + 0x9e3779b9u + (a << 6) + (a >> 2)); }
 
 // ROWS activation rows, G granules per WG and row (vector width = 2 * G * NWG halves), SWEEPERS waves share the sweep
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+// 16-byte sc1 load (two granules) -- inline asm: the builtin atomic load is 8 bytes wide at most
+__device__ __forceinline__ u32x4v load16_sc1(const unsigned long long* p) {
+    u32x4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// WIDE = 1: the sweep reads two granules per 16-byte load, all loads of a pass in flight together; SLEEP: s_sleep argument between passes
+template <int ROWS, int G, int SWEEPERS, int SLEEP>
+__global__ __launch_bounds__(256) void edge16_kernel(unsigned long long* gran, int rounds, unsigned* out, unsigned* tmo) {
+    __shared__ unsigned vec[ROWS * NWG * G];
+    const int w = blockIdx.x, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    constexpr int N = NWG * G;
+    static_assert((ROWS * N) % (128 * SWEEPERS) == 0, "whole 16-byte loads per lane");
+    for (int i = tid; i < ROWS * N; i += 256) vec[i] = 0;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned epoch = r + 1;
+        unsigned long long* buf = gran + (size_t)(r & 1) * ROWS * N;
+        if (tid < ROWS * G) {
+            const int row = tid / G, g = tid % G;
+            unsigned v = mix(vec[row * N + ((w * G + g) * 7 + r) % N], w * 131 + g);
+            v = mix(v, vec[row * N + (w + 17 * g + 3 * r) % N]);
+            __hip_atomic_store((gu64*)(buf + row * N + w * G + g), ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (wid < SWEEPERS) {
+            constexpr int PER_WAVE = ROWS * N / SWEEPERS;        // granules
+            constexpr int LOADS = PER_WAVE / 128;                // 16-byte loads per lane
+            const int base = wid * PER_WAVE;
+            unsigned spins = 0;
+            for (;;) {
+                u32x4v val[LOADS];
+                // all loads of the pass in flight, one wait
+#pragma unroll
+                for (int k = 0; k < LOADS; ++k)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(val[k]) : "v"(buf + base + (k * 64 + lane) * 2) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < LOADS; ++k) { asm volatile("" : "+v"(val[k])); ok &= val[k][1] == epoch && val[k][3] == epoch; }
+                if (__all(ok)) {
+#pragma unroll
+                    for (int k = 0; k < LOADS; ++k) { vec[base + (k * 64 + lane) * 2] = val[k][0]; vec[base + (k * 64 + lane) * 2 + 1] = val[k][2]; }
+                    break;
+                }
+                if (++spins > (1u << 22)) { if (lane == 0) atomicAdd(tmo, 1u); break; }
+                __builtin_amdgcn_s_sleep(SLEEP);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { unsigned h = 0; for (int i = 0; i < ROWS * N; ++i) h = mix(h, vec[i]); out[w] = h; }
+}
+
 template <int ROWS, int G, int SWEEPERS>
 __global__ __launch_bounds__(256) void edge_kernel(unsigned long long* gran /* [2][ROWS][NWG * G] */, int rounds, unsigned* out, unsigned* tmo) {
     __shared__ unsigned vec[ROWS * NWG * G];
@@ -167,6 +222,38 @@ static void run(int rounds) {
     CHECK(hipFree(gran)); CHECK(hipFree(out)); CHECK(hipFree(tmo)); CHECK(hipFree(a)); CHECK(hipFree(b));
 }
 
+template <int ROWS, int G, int SWEEPERS, int SLEEP>
+static void run16(int rounds) {
+    constexpr int N = NWG * G;
+    unsigned long long* gran; unsigned *out, *tmo;
+    CHECK(hipMalloc(&gran, sizeof(unsigned long long) * 2 * ROWS * N));
+    CHECK(hipMalloc(&out, sizeof(unsigned) * NWG));
+    CHECK(hipMalloc(&tmo, 16));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    std::vector<unsigned> h(NWG);
+    unsigned tm = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipMemset(gran, 0, sizeof(unsigned long long) * 2 * ROWS * N));
+        CHECK(hipMemset(tmo, 0, 16));
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((edge16_kernel<ROWS, G, SWEEPERS, SLEEP>), dim3(NWG), dim3(256), 0, 0, gran, rounds, out, tmo);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+        CHECK(hipMemcpy(h.data(), out, sizeof(unsigned) * NWG, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(&tm, tmo, 4, hipMemcpyDeviceToHost));
+    }
+    const unsigned want = host_hash<ROWS, G>(rounds);
+    int bad = 0;
+    for (int w = 0; w < NWG; ++w) bad += h[w] != want;
+    printf("rows %2d, %4d halves wide, %d sweeping wave(s), 16-byte loads, s_sleep %d: in-launch edge %.2f us per round (%s, timeouts %u)\n",
+           ROWS, 2 * N, SWEEPERS, SLEEP, best * 1e3f / rounds, bad ? "WRONG" : "checked", tm);
+    CHECK(hipFree(gran)); CHECK(hipFree(out)); CHECK(hipFree(tmo));
+}
+
 int main() {
     const int rounds = 2000;
     run<1, 2, 1>(rounds);      // 1024 halves
@@ -177,5 +264,13 @@ int main() {
     run<4, 4, 4>(rounds);
     run<8, 4, 4>(rounds);
     run<16, 4, 4>(rounds);
+    run16<1, 4, 1, 1>(rounds);     // 2048 halves, one wave, 8 loads of 16 bytes per lane
+    run16<1, 4, 1, 8>(rounds);
+    run16<1, 4, 2, 8>(rounds);
+    run16<1, 10, 1, 4>(rounds);    // 5120 halves, one wave: 20 loads per lane
+    run16<1, 10, 2, 4>(rounds);
+    run16<1, 10, 4, 4>(rounds);
+    run16<2, 4, 1, 4>(rounds);
+    run16<4, 4, 2, 4>(rounds);
     return 0;
 }

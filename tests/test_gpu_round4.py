@@ -389,3 +389,58 @@ print(json.dumps({"ms_per_token": best * 1e3 / 96, "runtime": native.runtime_rep
     assert ours["runtime"]["set_by"] == "package" and ours["runtime"]["in_time"] is True and ours["runtime"]["effective_env"] == "0"
     assert theirs["runtime"]["set_by"] == "caller"
     assert ours["ms_per_token"] < theirs["ms_per_token"] * 0.99, (ours["ms_per_token"], theirs["ms_per_token"])
+
+
+# ------------------------------------------------------------------------------------------ batch 1: the Linears of a layer as in-launch chains
+@pytest.mark.parametrize("model,weight_only,int8_kv", [("micro-fullvocab", False, False), ("micro-fullvocab", True, True),
+                                                        ("tiny", True, False), ("tiny", "int4", True), ("large-v2-6layer", True, True),
+                                                        ("large-v2-6layer", False, False)])
+def test_one_row_chain_equals_the_launch_per_linear_path(tmp_path_factory, model, weight_only, int8_kv):
+    """csrc/gemv_chain.hip: at one activation row the fused Linears of a decoder layer run as two chains inside one launch each
+    (granule hand-offs between the stages).  Same arithmetic as one gemv_small launch per Linear: token ids, log-probabilities
+    and the whole KV cache of a batch-1 decode are IDENTICAL with the chain on and off, eagerly and under graph replay, and no
+    workgroup gave up a wait."""
+    import synthetic
+    from decoding import DecodingOptions, WhisperDecoding
+    from encoding import WhisperEncoding
+    from oracle.whisper_oracle import Dims, synthetic_mel
+    from test_gpu_model import build_engine
+    if model not in synthetic.DIMS:
+        pytest.skip(f"no synthetic model {model}")
+    tmp = tmp_path_factory.mktemp("chain")
+    dims = Dims(**synthetic.DIMS[model])
+    kv_scales = [0.05 + 0.01 * i for i in range(dims.n_text_layer)] if int8_kv else None
+    eng = build_engine(tmp, model, 3, weight_only, int8_kv, kv_scales)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    outs = []
+    prev = lib_().wm_set_decode_chain(-1)
+    try:
+        for on in (0, 1):
+            lib_().wm_set_decode_chain(on)
+            dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
+            dec.detect_language(xa)
+            for use_graphs in (False, True):
+                dec.use_graphs = use_graphs
+                for st in dec._state.values():
+                    st['graphs'].clear()
+                t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+                kv = [c.clone() for c in dec._state[1]['kv']]
+                outs.append((on, use_graphs, t.cpu(), lp.cpu(), kv))
+            err = C.c_int(0)
+            native.check(lib_().wm_decode_chain_error(C.byref(err)))
+            assert err.value == 0
+            del dec
+    finally:
+        lib_().wm_set_decode_chain(prev)
+    ref = outs[0]
+    for on, use_graphs, t, lp, kv in outs[1:]:
+        assert torch.equal(t, ref[2]), (on, use_graphs)
+        assert torch.equal(lp, ref[3]), (on, use_graphs)
+        for a, b in zip(kv, ref[4]):
+            assert torch.equal(a, b), (on, use_graphs)
+    assert len(set(ref[2][0, 3:].tolist())) > 3                      # a real decode, not one token repeated
+
+
+def lib_():
+    return native.load_library()
