@@ -757,8 +757,9 @@ struct GroupStep {
 
     // a chain of layer i's Linears in one launch (one row): `first` .. `first + n - 1` of the layer's six stage descriptors.
     // launch_id: unique per launch of a step (the granules' epochs)
-    int run_chain(int i, int first, int n, const h16* in16, int launch_id, hipStream_t s) {
+    int run_chain(int i, int first, int n, const h16* in16, int launch_id, hipStream_t s, bool merge = false) {
         GemvChainParams p{};
+        if (merge) { p.merge_ws = w.cross_ws; p.merge_nsplit = w.nsplit; p.merge_heads = H; }
         p.n_stages = n; p.st = e->chain_dev + (size_t)6 * i + first;
         p.out32 = w.part;
         p.w8 = e->dec[i].out.wcode; p.gelu_kind = e->gelu();
@@ -862,6 +863,7 @@ struct GroupStep {
         p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
         p.live = io->live_rows;
         p.skip_zero_rows = g_cross_v_skip.load(std::memory_order_relaxed);
+        p.no_combine = chain && w.nsplit > 1;          // the chain behind this launch merges the pieces in its first stage
         const int slot = (L == 1) ? prof_slot(*prof, i, s) : -1;
         if (launch_attn_cross(p, s, slot >= 0 ? prof->start[slot] : nullptr, slot >= 0 ? prof->stop[slot] : nullptr)) return 2;
         return 0;
@@ -875,7 +877,7 @@ struct GroupStep {
         mark(i, 6, s);
         if (chain) {             // [x += cout(ctx)] -> [LN + mlp1 + GELU] -> [x += mlp2] -> [LN + qkv sums of the next layer] in one launch
             const bool more = i + 1 < d.n_text_layer;
-            const int rc = run_chain(i, 2, more ? 4 : 3, w.ctx, 2 * i + 1, s);
+            const int rc = run_chain(i, 2, more ? 4 : 3, w.ctx, 2 * i + 1, s, w.nsplit > 1);
             mark(i, 12, s);
             return rc;
         }

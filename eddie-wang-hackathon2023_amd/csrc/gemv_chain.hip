@@ -169,6 +169,43 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 #pragma unroll
             for (int m = 0; m < NM; ++m) a[0][i][m] = *(const half8v*)(arow + m * 8);
         }
+    } else if (s == 0 && p.merge_ws) {
+        // The launch before this one was the cross-attention over key-range pieces: its partial softmaxes (max, sum, unnormalised
+        // output per piece) are merged HERE instead of by a merge launch of their own -- attn_cross_combine_kernel's arithmetic, a
+        // wave per head (lane = dim), the heads dealt over the workgroup's waves; the merged row goes to LDS.  Every workgroup
+        // repeats the merge (21 KB of L2 reads at large-v2, all in flight at once) and the layer loses a launch.
+        const int nsp = p.merge_nsplit;
+        for (int h = wid; h < p.merge_heads; h += 8) {
+            const float* w = p.merge_ws + (size_t)h * nsp * 66;
+            float ms = w[min(lane, nsp - 1) * 66], ls = w[min(lane, nsp - 1) * 66 + 1];
+            if (lane >= nsp) { ms = -INFINITY; ls = 0.f; }
+            float ov[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ov[q] = w[min(q, nsp - 1) * 66 + 2 + lane];
+            const float m = wave_max_nomfma(ms);
+            const float f = lane < nsp ? __expf(ms - m) : 0.f;
+            const float lf = ls * f;
+            float den = 0.f, num = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q < nsp) {                                // wave-uniform
+                    den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), q));
+                    num += ov[q] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), q));
+                }
+            }
+            s_in[0][h * 64 + lane] = (h16)(num / den);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int t_last = max(t_end[j] - 1, t_begin[j]);
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                const h16* arow = &s_in[0][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
+            }
+        }
     } else if (s == 0) {
         // the input row left by the launch before this one (attention context): fragments straight from memory, as gemv_small
 #pragma unroll
@@ -349,7 +386,9 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs, int n_wg, 
         WM_REQUIRE(st.Wt && st.K % KT == 0 && st.K <= CHAIN_MAX_IN && st.n_blocks >= 1, "gemv_chain: stage %d shape", s);
         WM_REQUIRE(st.mode >= 0 && st.mode <= 2 && (st.mode != 0 || p.out32), "gemv_chain: stage %d mode %d", s, st.mode);
         WM_REQUIRE(!st.ln_g || (st.ln_b && st.K <= 1536), "gemv_chain: stage %d LayerNorm needs beta and K <= 1536", s);
-        WM_REQUIRE(s > 0 || st.ln_g || p.in16, "gemv_chain: the first stage needs its input row");
+        WM_REQUIRE(s > 0 || st.ln_g || p.in16 || p.merge_ws, "gemv_chain: the first stage needs its input row");
+        WM_REQUIRE(!p.merge_ws || (p.merge_nsplit >= 1 && p.merge_nsplit <= 16 && p.merge_heads * 64 == hs[0].K && !hs[0].ln_g),
+                   "gemv_chain: merged input: %d pieces, %d heads for K=%d", p.merge_nsplit, p.merge_heads, hs[0].K);
         WM_REQUIRE(s == 0 || st.ln_g || hs[s - 1].mode == 1, "gemv_chain: stage %d reads the hidden row, stage %d must produce it", s, s - 1);
         WM_REQUIRE(s == 0 || !st.ln_g || hs[s - 1].mode == 2, "gemv_chain: stage %d normalises the residual row, stage %d must produce it", s, s - 1);
         const int TB = p.w8 ? 5 : 10, slices = (st.K / KT + TB - 1) / TB;

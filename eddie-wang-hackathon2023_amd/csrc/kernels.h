@@ -87,6 +87,8 @@ struct GemvChainParams {
     float* out32;                                             // where a mode-0 stage leaves its sums
     int w8, gelu_kind;
     const h16* in16;                                          // the first stage's input row when it has no LayerNorm (attention context)
+    const float* merge_ws; int merge_nsplit, merge_heads;     // instead of in16: the cross-attention's key-range partial results [H][nsplit][66]
+                                                              // of this row, merged by the stage itself (attn_cross_combine_kernel's arithmetic)
     h16* x;                                                   // residual row [C]: read by the first stage that needs it, rewritten by every mode-2 stage
     h16* hid_out;                                             // optional copy of a mode-1 stage's output in plain memory (tests)
     unsigned long long* gran_x; unsigned long long* gran_h;   // granule edges: C / 2 and 4 C / 2 entries
@@ -178,6 +180,7 @@ struct AttnCrossParams {
     float* ws;                               // [B*H*nsplit][L][66] partial (m, l, o[64]) when nsplit > 1
     const int32_t* live;                     // optional [1 + B]: count, then the rows to process (others are skipped)
     int skip_zero_rows;                      // fp16 K/V, nsplit == 1: V rows whose probabilities all round to fp16 zero are not fetched (exact)
+    int no_combine;                          // nsplit > 1: leave the partial results in ws (the consumer merges them: gemv_chain.hip)
 };
 constexpr int CROSS_V_SKIP_DEFAULT = 1;      // measured: profiles/r4e_* (diffuse attention: no slower; peaked: FETCH_SIZE falls with the skipped rows)
 int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
