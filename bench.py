@@ -611,6 +611,17 @@ def main():
             if args.encoder_cus > 0 and args.steps > 1:
                 b = in_situ_probe(dec, lib, last["xa"], B, n_micro, algo_bytes, beside=(enc, mel, args.encoder_cus))
                 roofline["in_situ_beside_encoder"] = {k.replace("in_situ_", ""): v for k, v in b.items() if k != "in_situ_note"}
+        else:
+            # one-row utterance groups: the cross-attention is a stage of the in-launch chain (gemv_chain.hip), no launch of the
+            # K/V kernel exists to sample.  The token step as a whole is the unit then (decode_step_* below): achieved = its bytes / its time
+            roofline = {"kernel": "gemv_chain_kernel (one-row decode step: Linears, cross-attention pieces and merge in two launches per layer)",
+                        "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "note": "batch-1 groups: achieved / frac are the whole token step's (decode_step_bytes.total over decode_step_ms), "
+                                "a latency-bound chain of dependent stages, not a streaming kernel"}
+        if roofline is not None:
+            H, Tk = dims["n_text_head"], dims["n_audio_ctx"]
+            n_micro, bounds = dec._groups(B)
+            kv_bytes = 1 if args.config == "int8x" else 2
             if decode_loop_ms is not None:
                 step_ms = decode_loop_ms / T
                 cross_bytes = B * dims["n_text_layer"] * H * 2 * Tk * 64 * kv_bytes          # B x 245.76 MB at large-v2
@@ -631,6 +642,9 @@ def main():
                                  "decode_step_note": "SURVEY 8d bytes of one token step -- (Linear weights + logits matrix) x utterance groups + cross K/V of the "
                                                      "whole batch + self-attention cache at the loop's mean length -- / (decode loop time / tokens) / 8 TB/s"
                                                      + ("; decode loops with nothing beside them (the last step's)" if shared else "")})
+                if roofline["achieved"] is None:
+                    roofline["achieved"] = round(all_bytes / (step_ms * 1e-3) / 1e9, 1)
+                    roofline["frac"] = roofline["decode_step_frac"]
                 if decode_loop_shared_ms is not None:
                     roofline.update({"decode_loop_beside_encoder_ms": round(decode_loop_shared_ms, 2),
                                      "decode_step_beside_encoder_ms": round(decode_loop_shared_ms / T, 3)})

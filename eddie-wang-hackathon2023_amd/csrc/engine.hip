@@ -546,7 +546,7 @@ int prof_slot(Profiler& pr, int layer, hipStream_t s) {
 }
 
 struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total;
-               unsigned long long *gran_x, *gran_h; unsigned* generation; };      // granule edges of the one-row chain (gemv_chain.hip) and its call counter
+               unsigned long long *gran_x, *gran_h, *gran_q; unsigned* generation; };      // granule edges of the one-row chain (gemv_chain.hip) and its call counter
 
 int cross_nsplit(int B, int H) {
     // Pieces the key range of the decode cross-attention is cut into (one workgroup per (utterance, head, piece), partial
@@ -587,6 +587,7 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
     w.cross_ws = c.take<float>((size_t)B * d.n_text_head * w.nsplit * L * 66);
     w.gran_x = c.take<unsigned long long>(C / 2 + 8);
     w.gran_h = c.take<unsigned long long>(2 * C + 8);
+    w.gran_q = c.take<unsigned long long>(C + 8);
     w.generation = c.take<unsigned>(4);
     w.total = align_up(c.off);
     return w;
@@ -757,9 +758,13 @@ struct GroupStep {
 
     // a chain of layer i's Linears in one launch (one row): `first` .. `first + n - 1` of the layer's six stage descriptors.
     // launch_id: unique per launch of a step (the granules' epochs)
-    int run_chain(int i, int first, int n, const h16* in16, int launch_id, hipStream_t s, bool merge = false) {
+    int run_chain(int i, int first, int n, const h16* in16, int launch_id, hipStream_t s, bool merge = false, bool cross_stage = false) {
         GemvChainParams p{};
         if (merge) { p.merge_ws = w.cross_ws; p.merge_nsplit = w.nsplit; p.merge_heads = H; }
+        if (cross_stage) {           // this layer's cross-attention pieces as the chain's last stage
+            p.cross_kv = (const h16*)io->cross[i]; p.cross_Tk = e->dims.n_audio_ctx; p.cross_heads = H; p.cross_nsplit = w.nsplit;
+            p.cross_ws = w.cross_ws; p.cross_qbias = e->dec[i].cq.b; p.gran_q = w.gran_q;
+        }
         p.n_stages = n; p.st = e->chain_dev + (size_t)6 * i + first;
         p.out32 = w.part;
         p.w8 = e->dec[i].out.wcode; p.gelu_kind = e->gelu();
@@ -819,7 +824,11 @@ struct GroupStep {
         if (launch_attn_self(p, s)) return 2;
         mark(i, 2, s);
         if (chain) {                                   // [x += out(ctx)] -> [LN + q sums -> w.part] in one launch
-            if (run_chain(i, 0, 2, w.ctx, 2 * i, s)) return 2;
+            WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
+            // (a live-row list is not consulted: a one-row group is stepped while its row decodes; the steps between the row's EOT and
+            // the host's next poll compute values nobody reads)
+            chain_cross = w.nsplit > 1 && !e->i8cross() && g_decode_chain.load(std::memory_order_relaxed) >= 2;
+            if (run_chain(i, 0, 2, w.ctx, 2 * i, s, false, chain_cross)) return 2;
             mark(i, 5, s);
             cq_ks = 1;
             return 0;
@@ -841,9 +850,11 @@ struct GroupStep {
         return 0;
     }
     int cq_ks = 0;
+    bool chain_cross = false;                    // the chain behind the self-attention ran this layer's cross-attention pieces too
 
     // the HBM-bound kernel: K and V of every utterance of the group, once
     int cross(int i, hipStream_t s) {
+        if (chain && chain_cross) return 0;           // done by the chain behind the self-attention
         if (!prof->timeline) return cross_launch(i, s);
         hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, prof->timeline, prof->timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i));
         const int rc = cross_launch(i, s);
@@ -1210,7 +1221,7 @@ int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void
 
 int wm_set_decode_chain(int on) {
     const int prev = g_decode_chain.load(std::memory_order_relaxed);
-    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on ? 1 : 0), std::memory_order_relaxed);
+    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on > 2 ? 2 : on), std::memory_order_relaxed);
     return prev;
 }
 

@@ -25,6 +25,8 @@
 // the sixteen slices added in slice order as gemv_small's sixteen waves are.  The workgroup that owns channels 16 c .. 16 c + 15
 // of the residual stream owns them in every stage (its copy lives in LDS), so the residual adds need no exchange.
 // Every wait is bounded: a wave that gives up sets *err and the rest of the chain falls through (the host checks the word).
+#include <atomic>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -48,9 +50,10 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
 #pragma unroll
         for (int k = 0; k < NL; ++k)
             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(val[k]) : "v"(gran + first[k]) : "memory");
-        if constexpr (NL == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]) :: "memory");
+        if constexpr (NL == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]) :: "memory");
+        else if constexpr (NL == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]) :: "memory");
         else if constexpr (NL == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]) :: "memory");
-        else static_assert(NL == 3 || NL == 6, "sweep sizes of the chain");
+        else static_assert(NL == 1 || NL == 3 || NL == 6, "sweep sizes of the chain");
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) ok &= val[k].y == epoch && val[k].w == epoch;
@@ -82,6 +85,15 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     const int grp = blockIdx.x + slot * gridDim.x;            // this slot's group of 16 output channels
     const bool has_group = grp < st.n_blocks;
     const int nb = has_group ? grp : st.n_blocks - 1;         // (idle slots re-read valid memory; nothing of theirs is stored)
+
+    // an idle slot (no group of this stage falls to it) only keeps the workgroup's barriers company: it touches no memory, so that
+    // waves which carry LDS-DMA requests for a later stage (the cross-attention's K / V rows) are not made to wait for them here
+    if (!has_group) {
+        const int nbar = (LN ? 3 : 2) + ((!LN && s == 0 && p.merge_ws) ? 1 : 0);
+        for (int b = 0; b < nbar; ++b) __syncthreads();
+        if (st.mode == 2) own_valid = true;
+        return;
+    }
 
     // ---- 1. every weight tile of this wave's K slices is requested now, before anything is waited for -------------------
     u32x4 wreg[NS][TB];
@@ -175,7 +187,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         // wave per head (lane = dim), the heads dealt over the workgroup's waves; the merged row goes to LDS.  Every workgroup
         // repeats the merge (21 KB of L2 reads at large-v2, all in flight at once) and the layer loses a launch.
         const int nsp = p.merge_nsplit;
-        for (int h = wid; h < p.merge_heads; h += 8) {
+        for (int h = wslot; h < p.merge_heads; h += 4) {      // (the slot's four waves; an idle slot only joins the barrier)
             const float* w = p.merge_ws + (size_t)h * nsp * 66;
             float ms = w[min(lane, nsp - 1) * 66], ls = w[min(lane, nsp - 1) * 66 + 1];
             if (lane >= nsp) { ms = -INFINITY; ls = 0.f; }
@@ -193,7 +205,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
                     num += ov[q] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), q));
                 }
             }
-            s_in[0][h * 64 + lane] = (h16)(num / den);
+            s_in[slot][h * 64 + lane] = (h16)(num / den);
         }
         __syncthreads();
 #pragma unroll
@@ -201,7 +213,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             const int t_last = max(t_end[j] - 1, t_begin[j]);
 #pragma unroll
             for (int i = 0; i < TB; ++i) {
-                const h16* arow = &s_in[0][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
+                const h16* arow = &s_in[slot][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
 #pragma unroll
                 for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
             }
@@ -311,7 +323,12 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         const float y = sum[0];                               // row 0 (lanes 0-15); the other lanes hold rows that do not exist
         const float bias = (st.mode == 1 || st.mode == 2) && st.bias ? (float)st.bias[col] : 0.f;
         if (st.mode == 0) {
-            if (g == 0) p.out32[col] = y;                     // raw sums for the attention kernel of the next launch
+            if (g == 0) {
+                p.out32[col] = y;                             // raw sums for the attention kernel of the next launch
+                if (p.gran_q)                                 // ... or of this launch's last stage
+                    __hip_atomic_store((chain_gu64*)(p.gran_q + col), ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, y),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             const float y16 = r16(y + bias);                  // the Linear's fp16 output
             h16 out;
@@ -336,6 +353,161 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     __syncthreads();                                          // s_red / s_in are the next stage's
 }
 
+// ---- the cross-attention of the row as the chain's last stage --------------------------------------------------------------
+// attn_cross_kernel<1>'s arithmetic for ONE (head, key-range piece) per workgroup (attn_decode.hip: lane -> 8 dims of a key row,
+// 8 rows per wave instruction, wave w takes rows 32 w + 128 k ..., scores in LDS, maxima and sums met in wave order, P.V per lane
+// over its rows in sequence, the partial (max, sum, o[64]) left for the merge) -- bit for bit: the same expressions in the same
+// order, only the rows come from LDS, where waves 4-7 put them by DMA at the START of the launch (K and V do not depend on the
+// activations: their 96 KB fly while the chain's Linears run) instead of from memory through a register pipeline.
+constexpr int CHAIN_CROSS_KEYS = 1536;
+constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
+
+__device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, unsigned char* kv_lds, int per_split) {
+    // waves 4-7: this workgroup's piece of K, then of V, as 1 KiB pieces (8 rows of 128 B) into LDS, linear
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x, n_items = p.cross_heads * p.cross_nsplit;
+    if (wid < 4 || item >= n_items) return;
+    const int h = item % p.cross_heads, sp = item / p.cross_heads;
+    const int k_begin = sp * per_split, nkeys = max(0, min(p.cross_Tk, k_begin + per_split) - k_begin);
+    if (nkeys == 0) return;
+    const int n_pieces = (nkeys + 7) >> 3;
+    for (int m = 0; m < 2; ++m) {
+        const unsigned char* src = (const unsigned char*)p.cross_kv + ((size_t)(m * p.cross_heads + h) * p.cross_Tk + k_begin) * 128;
+        for (int pc = wid - 4; pc < n_pieces; pc += 4) {
+            const int row = min(pc * 8 + (lane >> 3), nkeys - 1);        // rows past the piece re-read its last row (never used)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * 128 + (lane & 7) * 16),
+                                             (__attribute__((address_space(3))) void*)(kv_lds + m * per_split * 128 + pc * 1024), 16, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, unsigned epoch_q, const unsigned char* kv_lds, int per_split,
+                                                  float* s_sc, float (*s_redc)[2], float (*s_o)[64], float* s_q) {
+    constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
+    constexpr int STRIDE = 4 * RPI * UNR;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x, n_items = p.cross_heads * p.cross_nsplit;
+    const bool has_item = item < n_items;
+    const int h = has_item ? item % p.cross_heads : 0, sp = has_item ? item / p.cross_heads : 0;
+    const int k_begin = sp * per_split, nkeys = has_item ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
+    const int sub = lane % LPR, rowi = lane / LPR;
+    const int first = (wid & 3) * (RPI * UNR);
+    const bool worker = wid < 4 && has_item && nkeys > 0;
+    float* w_out = p.cross_ws + (size_t)(h * p.cross_nsplit + sp) * 66;
+
+    if (wid >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's K / V pieces have landed
+    if (wid == 0 && has_item) {                                               // the head's 64 q sums, as the last Linear published them
+        int fst[1] = {h * 64 + 2 * min(lane, 31)};
+        u32x4 val[1];
+        if (sweep_granules16<1>(p.gran_q, fst, epoch_q, val, p.err, lane) && lane < 32) {
+            unsigned q0 = val[0].x, q1 = val[0].z;
+            asm volatile("" : "+v"(q0), "+v"(q1));            // (kept apart: the pair was stored as (x, x) when the compiler formed it itself)
+            s_q[2 * lane] = __builtin_bit_cast(float, q0);
+            s_q[2 * lane + 1] = __builtin_bit_cast(float, q1);
+        }
+    }
+    __syncthreads();                                                           // (A) rows and q sums are in LDS
+    if (has_item && nkeys == 0) {                                              // an empty piece: the neutral element (attn_cross_kernel)
+        if (tid < 66) w_out[tid] = (tid == 0) ? -INFINITY : 0.f;
+    }
+    const unsigned char* K = kv_lds;
+    const unsigned char* V = kv_lds + (size_t)per_split * 128;
+    const int nb = (nkeys + STRIDE - 1) / STRIDE;
+    float qf[DPL];
+    float mx = -INFINITY;
+    if (worker) {
+        // q of this lane's 8 dims: one slab, bias, the two roundings (attn_cross_kernel's prologue at ksplit = 1)
+        const int col0 = h * 64 + sub * DPL;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            const float x = s_q[sub * DPL + e];
+            float qa = 0.f;
+            qa += x + 0.f;
+            qa += 0.f + 0.f;
+            const float bs = p.cross_qbias ? (float)p.cross_qbias[col0 + e] : 0.f;
+            qf[e] = r16(r16(qa + bs) * CHAIN_ATTN_SCALE);
+        }
+        // ---- pass 1: scores ------------------------------------------------------------------------------------------------
+        for (int k = 0; k < nb; ++k) {
+            const int r0 = first + k * STRIDE;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * RPI + rowi;
+                const int rr = min(r, nkeys - 1);
+                const half8v hv = *(const half8v*)(K + (size_t)rr * 128 + sub * 16);
+                float ks[DPL];
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) ks[e] = r16((float)hv[e] * CHAIN_ATTN_SCALE);
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) acc += qf[e] * ks[e];
+                acc += wave_dpp<0xB1>(acc);
+                acc += wave_dpp<0x4E>(acc);
+                acc += wave_dpp<0x141>(acc);
+                const float sc = r16(acc);
+                if (r < nkeys) {
+                    if (sub == 0) s_sc[r] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            }
+        }
+        const float m = wave_max_nomfma(mx);
+        if (lane == 0) s_redc[wid][0] = m;
+    }
+    __syncthreads();                                                           // (B)
+    float gmax = 0.f, gsum = 0.f;
+    if (worker) {
+        gmax = fmaxf(fmaxf(s_redc[0][0], s_redc[1][0]), fmaxf(s_redc[2][0], s_redc[3][0]));
+        float sm = 0.f;
+        for (int j = tid; j < nkeys; j += 256) {
+            const float e = __expf(s_sc[j] - gmax);
+            s_sc[j] = e;
+            sm += e;
+        }
+        sm = wave_sum_nomfma(sm);
+        if (lane == 0) s_redc[wid][1] = sm;
+    }
+    __syncthreads();                                                           // (C)
+    if (worker) {
+        gsum = s_redc[0][1] + s_redc[1][1] + s_redc[2][1] + s_redc[3][1];
+        // ---- pass 2: P.V (probabilities unnormalised: the merge divides) ---------------------------------------------------
+        float o[DPL];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+        for (int k = 0; k < nb; ++k) {
+            const int r0 = first + k * STRIDE;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = r0 + u * RPI + rowi;
+                const half8v hv = *(const half8v*)(V + (size_t)min(r, nkeys - 1) * 128 + sub * 16);
+                const float pr = r < nkeys ? s_sc[min(r, nkeys - 1)] : 0.f;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) o[e] += pr * (float)hv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) asm volatile("" : "+v"(o[e]) : : "memory");
+        }
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            float v = o[e];
+            v += wave_dpp<0x128>(v);
+            v = wave_add_xor16(v);
+            v = wave_add_xor32(v);
+            o[e] = v;
+        }
+        if (rowi == 0) {
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) s_o[wid][sub * DPL + e] = o[e];
+        }
+    }
+    __syncthreads();                                                           // (D)
+    if (worker && tid < 64) {
+        const float v = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
+        w_out[2 + tid] = v;
+        if (tid == 0) { w_out[0] = gmax; w_out[1] = gsum; }
+    }
+}
+
 template <int WB>
 __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     __shared__ __attribute__((aligned(16))) float s_red[16][64][4];
@@ -346,6 +518,13 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     // epochs never repeat: the generation word counts the decoder calls on this workspace (the embedding kernel that opens a call
     // increments it), the launch id the chains of a call, the low bits the stages of a chain
     const unsigned epoch0 = (*p.generation << 9) | ((unsigned)p.launch_id << 2);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char kv_lds[];      // the cross-attention stage's K and V rows (only then)
+    __shared__ float s_sc[CHAIN_CROSS_KEYS];
+    __shared__ float s_redc[4][2];
+    __shared__ float s_o[4][64];
+    __shared__ float s_q[64];
+    const int per_split = p.cross_kv ? ((((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7) : 0;
+    if (p.cross_kv) chain_cross_prefetch(p, kv_lds, per_split);
     bool own_valid = false;
     for (int s = 0; s < p.n_stages; ++s) {
         const ChainStage st = p.st[s];                        // (uniform: scalar loads of a descriptor no kernel writes)
@@ -355,6 +534,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
         else if (st.ln_g) chain_stage<WB, false, true>(p, st, s, epoch, own_valid, s_red, s_in, s_own);
         else chain_stage<WB, false, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own);
     }
+    if (p.cross_kv) chain_cross_stage(p, epoch0 + (unsigned)p.n_stages, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
 }
 
 // the word a wave sets when it gives up a bounded wait: one per device (the kernels get its address, wm_decode_chain_error reads it)
@@ -395,10 +575,30 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs, int n_wg, 
         const int need = slices > 4 ? st.n_blocks : (st.n_blocks + 1) / 2;
         widest = widest > need ? widest : need;
     }
+    size_t dyn = 0;
+    if (p.cross_kv) {
+        WM_REQUIRE(p.cross_ws && p.gran_q && hs[p.n_stages - 1].mode == 0 && p.cross_nsplit > 1 && p.cross_nsplit <= 16 && p.cross_Tk >= 1 &&
+                   p.cross_heads * 64 == hs[p.n_stages - 1].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
+        const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
+        WM_REQUIRE(per_split <= CHAIN_CROSS_KEYS, "gemv_chain: %d keys per piece", per_split);
+        dyn = (size_t)2 * per_split * 128 + 1024;
+        WM_REQUIRE(dyn <= 112 * 1024, "gemv_chain: cross-attention pieces of %d keys do not fit LDS", per_split);
+        widest = widest > p.cross_heads * p.cross_nsplit ? widest : p.cross_heads * p.cross_nsplit;
+        static std::atomic<unsigned long long> attr_set{0};       // per device (the dynamic-LDS limit is a per-device attribute of the function)
+        int dev = 0;
+        WM_CHECK_HIP(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+            WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+            WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+            WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+            attr_set.fetch_or(bit, std::memory_order_release);
+        }
+    }
     WM_REQUIRE(n_wg >= widest, "gemv_chain: %d workgroups for stages that need %d", n_wg, widest);
-    if (p.w8 == 4) hipLaunchKernelGGL(gemv_chain_kernel<4>, dim3(n_wg), dim3(512), 0, stream, p);
-    else if (p.w8) hipLaunchKernelGGL(gemv_chain_kernel<8>, dim3(n_wg), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL(gemv_chain_kernel<16>, dim3(n_wg), dim3(512), 0, stream, p);
+    if (p.w8 == 4) hipLaunchKernelGGL(gemv_chain_kernel<4>, dim3(n_wg), dim3(512), dyn, stream, p);
+    else if (p.w8) hipLaunchKernelGGL(gemv_chain_kernel<8>, dim3(n_wg), dim3(512), dyn, stream, p);
+    else hipLaunchKernelGGL(gemv_chain_kernel<16>, dim3(n_wg), dim3(512), dyn, stream, p);
     WM_LAUNCH_CHECK(stream, "gemv_chain");
     return 0;
 }

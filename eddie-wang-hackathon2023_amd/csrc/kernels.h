@@ -74,7 +74,7 @@ int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
 // A chain of gemv_small Linears at ONE activation row in one launch (batch 1): stage inputs / outputs between the stages travel
 // as {epoch, value} granules, the first stage reads plain memory, mode-0 results and the residual row go back to plain memory.
 constexpr int CHAIN_MAX_STAGES = 4;
-constexpr int DECODE_CHAIN_DEFAULT = 1;
+constexpr int DECODE_CHAIN_DEFAULT = 2;      // 0: off, 1: the Linears chained, 2: + the cross-attention pieces as the first chain's last stage
 struct ChainStage {                                           // (an engine keeps its layers' stages in DEVICE memory: a chain's
     const void* Wt; const h16* scale; const h16* bias;         // arguments stay small -- by value they were 330 bytes, and the runtime
     const h16* ln_g; const h16* ln_b;                         // staged such argument blocks with a blit per launch under graph replay)
@@ -92,6 +92,11 @@ struct GemvChainParams {
     h16* x;                                                   // residual row [C]: read by the first stage that needs it, rewritten by every mode-2 stage
     h16* hid_out;                                             // optional copy of a mode-1 stage's output in plain memory (tests)
     unsigned long long* gran_x; unsigned long long* gran_h;   // granule edges: C / 2 and 4 C / 2 entries
+    // optional last stage: the decode cross-attention of this row over key-range pieces (attn_cross_kernel<1>'s arithmetic, nsplit > 1),
+    // one (head, piece) per workgroup, its K / V rows prefetched into LDS from the start of the launch; q = the sums the chain's last
+    // Linear (mode 0) has just published on gran_q; the pieces' partial results go to cross_ws for the next launch to merge
+    const h16* cross_kv; int cross_Tk, cross_heads, cross_nsplit; float* cross_ws; const h16* cross_qbias;
+    unsigned long long* gran_q;                               // C entries ({epoch, fp32 bits})
     unsigned* err;                                            // set non-zero when a bounded wait gives up
     const unsigned* generation; int launch_id;                // epochs: (*generation << 9) | (launch_id << 2), + stage + 1 (generation: one per decoder call)
 };

@@ -270,10 +270,13 @@ int wm_set_self_attn_waves(int waves);
 int wm_set_gemm_small_tiles(int tiles);
 /* Batch 1 (one activation row: the reference's own operating point, W/run.py:43-46): the fused Linears of a decoder layer run as
  * two CHAINS inside one launch each -- [out + residual -> LayerNorm + cross-attention q] and [out + residual -> LayerNorm + mlp1 +
- * GELU -> mlp2 + residual -> LayerNorm + qkv of the next layer] -- 5 launches per layer instead of 9 (csrc/gemv_chain.hip: the
- * stages hand the activation row over as tagged 8-byte granules, no fences, no barriers; weights of the next stage are requested
- * before its input is waited for).  Same arithmetic as the launch-per-Linear form, bit for bit.  1 = on (default), 0 = off,
- * < 0 = default; returns the previous value.  Captured graphs keep the form they were captured with.
+ * GELU -> mlp2 + residual -> LayerNorm + qkv of the next layer] (csrc/gemv_chain.hip: the stages hand the activation row over
+ * as tagged 8-byte granules, no fences, no barriers; weights of the next stage are requested before its input is waited for); the
+ * merge of the cross-attention's key-range pieces is the second chain's prologue.  Mode 2 also runs the cross-attention pieces
+ * themselves as the first chain's last stage (their K / V rows are put into LDS by DMA while the chain's Linears run): 3 launches
+ * per layer -- self-attention, chain, chain -- instead of 9.  Same arithmetic as the launch-per-Linear form, bit for bit.
+ * 0 = off, 1 = the Linears chained, 2 = + the cross-attention stage (default), < 0 = default; returns the previous value.
+ * Captured graphs keep the form they were captured with.
  * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a (bounded) wait since the last call -- the results of
  * that step are not valid (a chain needs its <= 256 workgroups resident together; the word is cleared by the call; it
  * synchronises with the device).
