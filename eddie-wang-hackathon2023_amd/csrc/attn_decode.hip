@@ -5,7 +5,9 @@
 //   q, k are multiplied by d^-0.25 and rounded to fp16 (W/torch_model.py:93-95), scores are
 //   fp32 dot products rounded to fp16, softmax runs in fp32 over the whole key range
 //   (torch_model.py:100-101; attention.py:385-398), probabilities are rounded to fp16, P.V
-//   accumulates in fp32 and is rounded to fp16.
+//   accumulates in fp32 and is rounded to fp16.  The self-attention's dot products and P.V sums are chains of fused
+//   multiply-adds (fmaf, written out: left to the compiler the same loop came out partly fused, partly not, differently in
+//   every copy of it -- and gemv_chain.hip runs a copy of the four-wave form that must agree with it bit for bit).
 //   int8 KV: present = sat_s8(rne(x * (1/t))), past is used as fp16(q8) * t, the tokens of the
 //   current call are used un-quantised (attention.py:281-348; same contract as the MMHA kernel,
 //   decoderMaskedMultiheadAttentionTemplate.h:1501-1517, Utils.h:2276-2286,2357-2390).
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
                             for (int e = 0; e < 16; ++e) {
                                 const int8_t q8 = (int8_t)((ws[e >> 2] >> (8 * (e & 3))) & 0xff);
                                 const float kd = r16(r16((float)q8 * t_dq) * ATTN_SCALE);
-                                acc += (float)s_q[c * 16 + e] * kd;
+                                acc = fmaf((float)s_q[c * 16 + e], kd, acc);
                             }
                         }
                     } else {
@@ -170,15 +172,15 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
                             const half8v w = j0 == 0 ? __builtin_bit_cast(half8v, kpre[c]) : kr[c];
 #pragma unroll
                             for (int e = 0; e < 8; ++e)
-                                acc += (float)s_q[c * 8 + e] * r16((float)w[e] * ATTN_SCALE);
+                                acc = fmaf((float)s_q[c * 8 + e], r16((float)w[e] * ATTN_SCALE), acc);
                         }
                     }
                 } else {
                     const h16* kn = s_knew[j - T];
 #pragma unroll 8
-                    for (int e = 0; e < 64; ++e) acc += (float)s_q[e] * r16((float)kn[e] * ATTN_SCALE);
+                    for (int e = 0; e < 64; ++e) acc = fmaf((float)s_q[e], r16((float)kn[e] * ATTN_SCALE), acc);
                 }
-                sc = r16(acc);
+                sc = r16(f32_as_is(acc));
             }
             if (j < MAXT) s_p[j] = sc;
             mx = fmaxf(mx, sc);
@@ -203,47 +205,47 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
             const int8_t* pv = (const int8_t*)pastV + lane;
 #pragma unroll
             for (int u = 0; u < 32; ++u)          // the prefetched rows (same ascending order as the loops below)
-                if (u < T) o += s_p[u] * r16((float)vpre8[u] * t_dq);
+                if (u < T) o = fmaf(s_p[u], r16((float)vpre8[u] * t_dq), o);
             j = min(T, 32);
             for (; j + 32 <= T; j += 32) {        // 32 loads in flight per lane: the loop is HBM-latency bound
                 int8_t vq[32];
 #pragma unroll
                 for (int u = 0; u < 32; ++u) vq[u] = pv[(size_t)(j + u) * 64];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) o += s_p[j + u] * r16((float)vq[u] * t_dq);
+                for (int u = 0; u < 32; ++u) o = fmaf(s_p[j + u], r16((float)vq[u] * t_dq), o);
             }
             for (; j + 8 <= T; j += 8) {
                 int8_t vq[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) vq[u] = pv[(size_t)(j + u) * 64];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) o += s_p[j + u] * r16((float)vq[u] * t_dq);
+                for (int u = 0; u < 8; ++u) o = fmaf(s_p[j + u], r16((float)vq[u] * t_dq), o);
             }
-            for (; j < T; ++j) o += s_p[j] * r16((float)pv[(size_t)j * 64] * t_dq);
+            for (; j < T; ++j) o = fmaf(s_p[j], r16((float)pv[(size_t)j * 64] * t_dq), o);
         } else {
             const h16* pv = (const h16*)pastV + lane;
 #pragma unroll
             for (int u = 0; u < 32; ++u)          // the prefetched rows (same ascending order as the loops below)
-                if (u < T) o += s_p[u] * (float)vpre16[u];
+                if (u < T) o = fmaf(s_p[u], (float)vpre16[u], o);
             j = min(T, 32);
             for (; j + 32 <= T; j += 32) {
                 h16 vh[32];
 #pragma unroll
                 for (int u = 0; u < 32; ++u) vh[u] = pv[(size_t)(j + u) * 64];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) o += s_p[j + u] * (float)vh[u];
+                for (int u = 0; u < 32; ++u) o = fmaf(s_p[j + u], (float)vh[u], o);
             }
             for (; j + 8 <= T; j += 8) {
                 h16 vh[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) vh[u] = pv[(size_t)(j + u) * 64];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) o += s_p[j + u] * (float)vh[u];
+                for (int u = 0; u < 8; ++u) o = fmaf(s_p[j + u], (float)vh[u], o);
             }
-            for (; j < T; ++j) o += s_p[j] * (float)pv[(size_t)j * 64];
+            for (; j < T; ++j) o = fmaf(s_p[j], (float)pv[(size_t)j * 64], o);
         }
-        for (; j < nk; ++j) o += s_p[j] * (float)s_vnew[j - T][lane];
-        p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)o;
+        for (; j < nk; ++j) o = fmaf(s_p[j], (float)s_vnew[j - T][lane], o);
+        p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)f32_as_is(o);
         __syncthreads();
     }
 }
@@ -377,20 +379,20 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
                             for (int e = 0; e < 16; ++e) {
                                 const int8_t q8 = (int8_t)((ws[e >> 2] >> (8 * (e & 3))) & 0xff);
                                 const float kd = r16(r16((float)q8 * t_dq) * ATTN_SCALE);
-                                acc += (float)s_q[c * 16 + e] * kd;
+                                acc = fmaf((float)s_q[c * 16 + e], kd, acc);
                             }
                         } else {
                             const half8v wh = __builtin_bit_cast(half8v, w);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) acc += (float)s_q[c * 8 + e] * r16((float)wh[e] * ATTN_SCALE);
+                            for (int e = 0; e < 8; ++e) acc = fmaf((float)s_q[c * 8 + e], r16((float)wh[e] * ATTN_SCALE), acc);
                         }
                     }
                 } else {
                     const h16* kn = s_knew[j - T];
 #pragma unroll 8
-                    for (int e = 0; e < 64; ++e) acc += (float)s_q[e] * r16((float)kn[e] * ATTN_SCALE);
+                    for (int e = 0; e < 64; ++e) acc = fmaf((float)s_q[e], r16((float)kn[e] * ATTN_SCALE), acc);
                 }
-                sc = r16(acc);
+                sc = r16(f32_as_is(acc));
                 s_p[j] = sc;
             }
             mx = fmaxf(mx, sc);
@@ -421,12 +423,12 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
 #pragma unroll
                 for (int d = 0; d < 16; ++d) {
                     const int8_t q8 = (int8_t)((ws[d >> 2] >> (8 * (d & 3))) & 0xff);
-                    o[d] += pj * r16((float)q8 * t_dq);
+                    o[d] = fmaf(pj, r16((float)q8 * t_dq), o[d]);
                 }
             } else {
                 const half8v wh = __builtin_bit_cast(half8v, w);
 #pragma unroll
-                for (int d = 0; d < 8; ++d) o[d] += pj * (float)wh[d];
+                for (int d = 0; d < 8; ++d) o[d] = fmaf(pj, (float)wh[d], o[d]);
             }
         };
 #pragma unroll
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
             for (int w = 0; w < SELF_WAVES; ++w)
 #pragma unroll
                 for (int r = 0; r < VROWS; ++r) acc += s_o[w * 64 + r * NCH + ch][d];
-            for (int j = T; j < nk; ++j) acc += s_p[j] * (float)s_vnew[j - T][lane];
-            p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)acc;
+            for (int j = T; j < nk; ++j) acc = fmaf(s_p[j], (float)s_vnew[j - T][lane], acc);
+            p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)f32_as_is(acc);
         }
         __syncthreads();
     }
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(64) void attn_cross_combine_kernel(AttnCrossParams 
     for (int s = 0; s < CROSS_MAX_SPLIT; ++s) {
         if (s < p.nsplit) {                       // wave-uniform
             den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), s));     // (v_readlane: s is a constant after unrolling)
-            num += ov[s] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), s));
+            num += mul_rn(ov[s], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), s)));     // (product and sum rounded separately, as this loop always compiled: common.h)
         }
     }
     p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + d] = (h16)(num / den);

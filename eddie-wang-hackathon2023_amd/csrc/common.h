@@ -62,6 +62,21 @@ const char* lab_env_str(const char* name);          // nullptr unless set and WM
 // the small kernels' LayerNorm / softmax tails.  The values added are the ones the xor butterfly adds, in its order (after
 // the steps 32, 16, 8 a lane's value depends on lane mod 8 only, so the lane a rotation by 4 reaches holds exactly what lane ^ 4
 // holds; likewise for 2 and 1 with the quad permutations): results are bit-identical to the __shfl_xor form.
+// a * b rounded to fp32 ON ITS OWN: the statement keeps the compiler from fusing the product into a following addition (hipcc
+// contracts by default and decides per context -- two copies of one expression can round differently; the merges of the
+// cross-attention's key-range pieces exist in three places that must agree bit for bit)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float r = a * b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+// An fp32 value as it stands, ahead of a conversion to fp16: without the statement the compiler may fold the conversion into the
+// operation that produced the value (v_fma_mixlo_f16 rounds a * b + c ONCE, straight to fp16, instead of to fp32 and then to fp16)
+// -- in one copy of a loop and not in another, depending on what it knows about the trip count.
+__device__ __forceinline__ float f32_as_is(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 template <int CTRL>
 __device__ __forceinline__ float wave_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));

@@ -546,7 +546,7 @@ int prof_slot(Profiler& pr, int layer, hipStream_t s) {
 }
 
 struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total;
-               unsigned long long *gran_x, *gran_h, *gran_q; unsigned* generation; };      // granule edges of the one-row chain (gemv_chain.hip) and its call counter
+               unsigned long long *gran_x, *gran_h, *gran_q, *gran_c, *gran_p; unsigned* generation; };      // granule edges of the one-row chain (gemv_chain.hip) and its call counter
 
 int cross_nsplit(int B, int H) {
     // Pieces the key range of the decode cross-attention is cut into (one workgroup per (utterance, head, piece), partial
@@ -588,6 +588,8 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
     w.gran_x = c.take<unsigned long long>(C / 2 + 8);
     w.gran_h = c.take<unsigned long long>(2 * C + 8);
     w.gran_q = c.take<unsigned long long>(C + 8);
+    w.gran_c = c.take<unsigned long long>(C / 2 + 8);
+    w.gran_p = c.take<unsigned long long>((size_t)d.n_text_head * 66 * 4 + 8);
     w.generation = c.take<unsigned>(4);
     w.total = align_up(c.off);
     return w;
@@ -758,12 +760,19 @@ struct GroupStep {
 
     // a chain of layer i's Linears in one launch (one row): `first` .. `first + n - 1` of the layer's six stage descriptors.
     // launch_id: unique per launch of a step (the granules' epochs)
-    int run_chain(int i, int first, int n, const h16* in16, int launch_id, hipStream_t s, bool merge = false, bool cross_stage = false) {
+    int run_chain(int i, int first, int n, const h16* in16, int launch_id, hipStream_t s, bool merge = false, bool cross_stage = false, bool whole_layer = false) {
         GemvChainParams p{};
-        if (merge) { p.merge_ws = w.cross_ws; p.merge_nsplit = w.nsplit; p.merge_heads = H; }
+        if (merge) { p.merge_ws = w.cross_ws; p.merge_nsplit = w.nsplit; p.merge_heads = H; p.merge_at = 0; }
         if (cross_stage) {           // this layer's cross-attention pieces as the chain's last stage
             p.cross_kv = (const h16*)io->cross[i]; p.cross_Tk = e->dims.n_audio_ctx; p.cross_heads = H; p.cross_nsplit = w.nsplit;
-            p.cross_ws = w.cross_ws; p.cross_qbias = e->dec[i].cq.b; p.gran_q = w.gran_q;
+            p.cross_ws = w.cross_ws; p.cross_qbias = e->dec[i].cq.b; p.gran_q = w.gran_q; p.cross_at = n - 1;
+        }
+        if (whole_layer) {           // the whole layer: self-attention first, the cross-attention behind stage 1 (cq), its pieces merged by stage 2 (cout)
+            p.cross_at = 1; p.cross_ws = nullptr; p.gran_p = w.gran_p; p.merge_at = 2; p.merge_nsplit = w.nsplit; p.merge_heads = H;
+            const DecLayer& Lr = e->dec[i];
+            p.self_part = w.part; p.self_bias = Lr.qkv.b; p.self_cache = io->present[i]; p.self_cap = io->present_capacity;
+            p.self_T = T; p.self_t_dev = io->n_past_dev; p.self_heads = H; p.self_i8 = e->i8kv() ? 1 : 0; p.self_kv_scale = Lr.kv_scale;
+            p.self_out = nullptr; p.gran_c = w.gran_c;
         }
         p.n_stages = n; p.st = e->chain_dev + (size_t)6 * i + first;
         p.out32 = w.part;
@@ -821,6 +830,20 @@ struct GroupStep {
         p.t_dev = io->n_past_dev;
         p.live = io->live_rows;
         p.waves = self_attn_waves(M);
+        // One launch for the WHOLE layer (mode 3): the self-attention as the chain's first stage (the four-wave form's arithmetic: the
+        // form one-row groups take anyway), the cross-attention behind the q projection, its pieces merged -- as tagged granules, inside
+        // the launch -- by the cross-attention output projection.  In-place cache only (past == present), four key-range pieces.
+        layer_done = false;
+        if (chain && g_decode_chain.load(std::memory_order_relaxed) >= 3 && w.nsplit == 4 && !e->i8cross() && p.waves == 4 &&
+            p.present_cap <= 512 && (T == 0 ? !io->n_past_dev : (p.past == p.present && p.past_cap == p.present_cap)) &&
+            H + H * w.nsplit <= chain_wgs) {
+            WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
+            const bool more = i + 1 < e->dims.n_text_layer;
+            chain_cross = true; layer_done = true;
+            if (run_chain(i, 0, more ? 6 : 5, nullptr, i, s, false, true, true)) return 2;
+            mark(i, 12, s);
+            return 0;
+        }
         if (launch_attn_self(p, s)) return 2;
         mark(i, 2, s);
         if (chain) {                                   // [x += out(ctx)] -> [LN + q sums -> w.part] in one launch
@@ -851,6 +874,7 @@ struct GroupStep {
     }
     int cq_ks = 0;
     bool chain_cross = false;                    // the chain behind the self-attention ran this layer's cross-attention pieces too
+    bool layer_done = false;                     // ... and everything behind them (mode 3: one launch per layer)
 
     // the HBM-bound kernel: K and V of every utterance of the group, once
     int cross(int i, hipStream_t s) {
@@ -886,6 +910,7 @@ struct GroupStep {
         const wm_dims& d = e->dims;
         int ks = 0;
         mark(i, 6, s);
+        if (chain && layer_done) return 0;
         if (chain) {             // [x += cout(ctx)] -> [LN + mlp1 + GELU] -> [x += mlp2] -> [LN + qkv sums of the next layer] in one launch
             const bool more = i + 1 < d.n_text_layer;
             const int rc = run_chain(i, 2, more ? 4 : 3, w.ctx, 2 * i + 1, s, w.nsplit > 1);
@@ -1221,7 +1246,7 @@ int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void
 
 int wm_set_decode_chain(int on) {
     const int prev = g_decode_chain.load(std::memory_order_relaxed);
-    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on > 2 ? 2 : on), std::memory_order_relaxed);
+    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on > 3 ? 3 : on), std::memory_order_relaxed);
     return prev;
 }
 

@@ -27,6 +27,8 @@
 // Every wait is bounded: a wave that gives up sets *err and the rest of the chain falls through (the host checks the word).
 #include <atomic>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -53,7 +55,11 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
         if constexpr (NL == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]) :: "memory");
         else if constexpr (NL == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]) :: "memory");
         else if constexpr (NL == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]) :: "memory");
-        else static_assert(NL == 1 || NL == 3 || NL == 6, "sweep sizes of the chain");
+        else if constexpr (NL == 18)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
+                         "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]), "+v"(val[12]), "+v"(val[13]), "+v"(val[14]), "+v"(val[15]),
+                         "+v"(val[16]), "+v"(val[17]) :: "memory");
+        else static_assert(NL == 1 || NL == 3 || NL == 6 || NL == 18, "sweep sizes of the chain");
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) ok &= val[k].y == epoch && val[k].w == epoch;
@@ -69,9 +75,17 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
 
 // one stage of the chain.  WIDE: one slot of eight waves, two K slices per wave (K = 4 n_state); LN: LayerNorm of the
 // residual-stream row in the prologue.
+// Where a stage without LayerNorm takes its input row from (wave-uniform):
+enum ChainIn : int {
+    CHAIN_IN_PLAIN = 0,        // p.in16, plain memory: left by the launch before this one
+    CHAIN_IN_MERGE = 1,        // the cross-attention's partial results in plain memory (p.merge_ws), merged by the stage's own slots
+    CHAIN_IN_LDS = 2,          // the row is in s_in[0] already (chain_merge_tagged has put it there)
+    CHAIN_IN_GRANULES = 3      // an fp16 row published as granules in this launch: `gran`, tagged `tag`
+};
 template <int WB, bool WIDE, bool LN>
 __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const ChainStage& st, int s, unsigned epoch, bool& own_valid,
-                                            float (*s_red)[64][4], h16 (*s_in)[CHAIN_MAX_IN + 8], h16 (*s_own)[16]) {
+                                            float (*s_red)[64][4], h16 (*s_in)[CHAIN_MAX_IN + 8], h16 (*s_own)[16],
+                                            int in_kind, const unsigned long long* gran, unsigned tag, bool x_in_granules) {
     constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);   // inputs per 1 KiB weight tile
     constexpr int NM = KT / 32;
     constexpr int TB = WB == 16 ? 10 : 5;
@@ -89,7 +103,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     // an idle slot (no group of this stage falls to it) only keeps the workgroup's barriers company: it touches no memory, so that
     // waves which carry LDS-DMA requests for a later stage (the cross-attention's K / V rows) are not made to wait for them here
     if (!has_group) {
-        const int nbar = (LN ? 3 : 2) + ((!LN && s == 0 && p.merge_ws) ? 1 : 0);
+        const int nbar = (LN ? 3 : 2) + ((!LN && in_kind == CHAIN_IN_MERGE) ? 1 : 0);
         for (int b = 0; b < nbar; ++b) __syncthreads();
         if (st.mode == 2) own_valid = true;
         return;
@@ -129,7 +143,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
                 bp[u] = *(const half8v*)(st.ln_b + min(lane + 64 * u, pieces_per_row - 1) * 8);
             }
             bool ok = true;
-            if (s == 0) {                                     // the row as the launches before this one left it (plain memory)
+            if (!x_in_granules) {                             // the row as the launches before this one left it (plain memory)
 #pragma unroll
                 for (int u = 0; u < XP; ++u) xr[u] = *(const half8v*)(p.x + min(lane + 64 * u, pieces_per_row - 1) * 8);
             } else {                                          // the row the previous stage's owners have just published
@@ -181,32 +195,49 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 #pragma unroll
             for (int m = 0; m < NM; ++m) a[0][i][m] = *(const half8v*)(arow + m * 8);
         }
-    } else if (s == 0 && p.merge_ws) {
+    } else if (in_kind == CHAIN_IN_MERGE) {
         // The launch before this one was the cross-attention over key-range pieces: its partial softmaxes (max, sum, unnormalised
         // output per piece) are merged HERE instead of by a merge launch of their own -- attn_cross_combine_kernel's arithmetic, a
         // wave per head (lane = dim), the heads dealt over the workgroup's waves; the merged row goes to LDS.  Every workgroup
         // repeats the merge (21 KB of L2 reads at large-v2, all in flight at once) and the layer loses a launch.
+        // The partials of ALL of a wave's heads are requested before the first is used (one memory round trip for the prologue, not one
+        // per head: 4.1 -> about 1 us at large-v2, where a wave has five heads): five heads per pass with <= 4 pieces -- the only
+        // count the engine uses below 160 (utterance, head) pairs -- one head per pass otherwise.
         const int nsp = p.merge_nsplit;
-        for (int h = wslot; h < p.merge_heads; h += 4) {      // (the slot's four waves; an idle slot only joins the barrier)
-            const float* w = p.merge_ws + (size_t)h * nsp * 66;
-            float ms = w[min(lane, nsp - 1) * 66], ls = w[min(lane, nsp - 1) * 66 + 1];
-            if (lane >= nsp) { ms = -INFINITY; ls = 0.f; }
-            float ov[16];
+        auto merge_heads = [&](auto nq_tag, auto mh_tag) {
+            constexpr int NQ = decltype(nq_tag)::value, MH = decltype(mh_tag)::value;
+            for (int h0 = wslot; h0 < p.merge_heads; h0 += 4 * MH) {      // (the slot's four waves; an idle slot only joins the barrier)
+                float ms[MH], ls[MH], ov[MH][NQ];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) ov[q] = w[min(q, nsp - 1) * 66 + 2 + lane];
-            const float m = wave_max_nomfma(ms);
-            const float f = lane < nsp ? __expf(ms - m) : 0.f;
-            const float lf = ls * f;
-            float den = 0.f, num = 0.f;
+                for (int u = 0; u < MH; ++u) {
+                    const float* w = p.merge_ws + (size_t)min(h0 + 4 * u, p.merge_heads - 1) * nsp * 66;
+                    ms[u] = w[min(lane, nsp - 1) * 66]; ls[u] = w[min(lane, nsp - 1) * 66 + 1];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if (q < nsp) {                                // wave-uniform
-                    den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), q));
-                    num += ov[q] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), q));
+                    for (int q = 0; q < NQ; ++q) ov[u][q] = w[min(q, nsp - 1) * 66 + 2 + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < MH; ++u) {
+                    const int h = h0 + 4 * u;
+                    if (h >= p.merge_heads) break;                    // wave-uniform
+                    float m_s = ms[u], l_s = ls[u];
+                    if (lane >= nsp) { m_s = -INFINITY; l_s = 0.f; }
+                    const float m = wave_max_nomfma(m_s);
+                    const float f = lane < nsp ? __expf(m_s - m) : 0.f;
+                    const float lf = l_s * f;
+                    float den = 0.f, num = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if (q < nsp) {                                // wave-uniform
+                            den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), q));
+                            num += mul_rn(ov[u][q], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), q)));
+                        }
+                    }
+                    s_in[slot][h * 64 + lane] = (h16)(num / den);
                 }
             }
-            s_in[slot][h * 64 + lane] = (h16)(num / den);
-        }
+        };
+        if (nsp <= 4) merge_heads(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
+        else merge_heads(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -218,7 +249,19 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
                 for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
             }
         }
-    } else if (s == 0) {
+    } else if (in_kind == CHAIN_IN_LDS) {
+        // the merged attention row is in s_in[0] (chain_merge_tagged, all eight waves, ended by a barrier)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int t_last = max(t_end[j] - 1, t_begin[j]);
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                const h16* arow = &s_in[0][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
+            }
+        }
+    } else if (in_kind == CHAIN_IN_PLAIN) {
         // the input row left by the launch before this one (attention context): fragments straight from memory, as gemv_small
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -242,11 +285,11 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             u32x4 val[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) first[k] = g0 + 2 * min(lane + 64 * k, max(n_ld - 1, 0));
-            const bool ok = n_ld > 0 && sweep_granules16<3>(p.gran_h, first, epoch - 1, val, p.err, lane);
+            const bool ok = n_ld > 0 && sweep_granules16<3>(gran, first, tag, val, p.err, lane);
             if (ok) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    if (lane + 64 * k < n_ld) *(uint2*)(&s_in[0][t_begin[j] * KT + (lane + 64 * k) * 4]) = make_uint2(val[k].x, val[k].z);
+                    if (lane + 64 * k < n_ld) *(uint2*)(&s_in[slot][t_begin[j] * KT + (lane + 64 * k) * 4]) = make_uint2(val[k].x, val[k].z);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave's LDS writes before its reads
@@ -255,7 +298,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             const int t_last = max(t_end[j] - 1, t_begin[j]);
 #pragma unroll
             for (int i = 0; i < TB; ++i) {
-                const h16* arow = &s_in[0][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
+                const h16* arow = &s_in[slot][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
 #pragma unroll
                 for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
             }
@@ -325,7 +368,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         if (st.mode == 0) {
             if (g == 0) {
                 p.out32[col] = y;                             // raw sums for the attention kernel of the next launch
-                if (p.gran_q)                                 // ... or of this launch's last stage
+                if (p.gran_q && s == p.cross_at)              // ... or of this launch's cross-attention stage
                     __hip_atomic_store((chain_gu64*)(p.gran_q + col), ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, y),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -365,8 +408,8 @@ constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_de
 __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, unsigned char* kv_lds, int per_split) {
     // waves 4-7: this workgroup's piece of K, then of V, as 1 KiB pieces (8 rows of 128 B) into LDS, linear
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int item = blockIdx.x, n_items = p.cross_heads * p.cross_nsplit;
-    if (wid < 4 || item >= n_items) return;
+    const int n_items = p.cross_heads * p.cross_nsplit, item = (int)blockIdx.x - ((int)gridDim.x - n_items);     // the LAST workgroups (see the kernel)
+    if (wid < 4 || item < 0) return;
     const int h = item % p.cross_heads, sp = item / p.cross_heads;
     const int k_begin = sp * per_split, nkeys = max(0, min(p.cross_Tk, k_begin + per_split) - k_begin);
     if (nkeys == 0) return;
@@ -386,8 +429,8 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, unsi
     constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
     constexpr int STRIDE = 4 * RPI * UNR;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int item = blockIdx.x, n_items = p.cross_heads * p.cross_nsplit;
-    const bool has_item = item < n_items;
+    const int n_items = p.cross_heads * p.cross_nsplit, item = (int)blockIdx.x - ((int)gridDim.x - n_items);
+    const bool has_item = item >= 0;
     const int h = has_item ? item % p.cross_heads : 0, sp = has_item ? item / p.cross_heads : 0;
     const int k_begin = sp * per_split, nkeys = has_item ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
     const int sub = lane % LPR, rowi = lane / LPR;
@@ -407,8 +450,16 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, unsi
         }
     }
     __syncthreads();                                                           // (A) rows and q sums are in LDS
+    // the piece's partial result (max, sum, o[64]): plain memory for the NEXT launch to merge, or -- when the merge is a later stage
+    // of this launch -- tagged granules, [head][66][4 pieces] so that a consumer lane finds the four pieces of a value side by side
+    auto put = [&](int r, float v) {
+        if (p.gran_p)
+            __hip_atomic_store((chain_gu64*)(p.gran_p + ((size_t)h * 66 + r) * 4 + sp), ((unsigned long long)epoch_q << 32) | __builtin_bit_cast(unsigned, v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else w_out[r] = v;
+    };
     if (has_item && nkeys == 0) {                                              // an empty piece: the neutral element (attn_cross_kernel)
-        if (tid < 66) w_out[tid] = (tid == 0) ? -INFINITY : 0.f;
+        if (tid < 66) put(tid, (tid == 0) ? -INFINITY : 0.f);
     }
     const unsigned char* K = kv_lds;
     const unsigned char* V = kv_lds + (size_t)per_split * 128;
@@ -503,9 +554,221 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, unsi
     __syncthreads();                                                           // (D)
     if (worker && tid < 64) {
         const float v = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
-        w_out[2 + tid] = v;
-        if (tid == 0) { w_out[0] = gmax; w_out[1] = gsum; }
+        put(2 + tid, v);
+        if (tid == 0) { put(0, gmax); put(1, gsum); }
     }
+}
+
+// The merge of the cross-attention's four key-range pieces when they were produced by THIS launch (tagged granules, p.gran_p):
+// attn_cross_combine_kernel's arithmetic -- m = max of the pieces' maxima, f_q = exp(m_q - m), den = sum_q l_q f_q and
+// num = sum_q o_q f_q in piece order, (h16)(num / den) -- with every lane holding all four (m, l) pairs itself instead of taking
+// them from lanes 0-3 (the same values: fmaxf and the products do not depend on who computes them).  All eight waves share the
+// heads (three per wave at 20 heads), a wave's 18 loads are in flight together; the merged row goes to s_in[0].  Ends with a barrier.
+__device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, unsigned tag, h16* s_row) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int MH = 3;
+    for (int h0 = wid; h0 < p.merge_heads; h0 += 8 * MH) {
+        int first[6 * MH];
+        u32x4 val[6 * MH];
+#pragma unroll
+        for (int u = 0; u < MH; ++u) {
+            const int h = min(h0 + 8 * u, p.merge_heads - 1);
+            first[6 * u + 0] = (h * 66 + 0) * 4; first[6 * u + 1] = (h * 66 + 0) * 4 + 2;
+            first[6 * u + 2] = (h * 66 + 1) * 4; first[6 * u + 3] = (h * 66 + 1) * 4 + 2;
+            first[6 * u + 4] = (h * 66 + 2 + lane) * 4; first[6 * u + 5] = (h * 66 + 2 + lane) * 4 + 2;
+        }
+        if (!sweep_granules16<6 * MH>(p.gran_p, first, tag, val, p.err, lane)) break;
+#pragma unroll
+        for (int u = 0; u < MH; ++u) {
+            const int h = h0 + 8 * u;
+            if (h >= p.merge_heads) break;                            // wave-uniform
+            unsigned mb[4] = {val[6 * u + 0].x, val[6 * u + 0].z, val[6 * u + 1].x, val[6 * u + 1].z};
+            unsigned lb[4] = {val[6 * u + 2].x, val[6 * u + 2].z, val[6 * u + 3].x, val[6 * u + 3].z};
+            unsigned ob[4] = {val[6 * u + 4].x, val[6 * u + 4].z, val[6 * u + 5].x, val[6 * u + 5].z};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(mb[q]), "+v"(lb[q]), "+v"(ob[q]));      // (see chain_cross_stage: pairs formed by the compiler from a granule load came out as (x, x))
+            float mq[4], lq[4], oq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mq[q] = __builtin_bit_cast(float, mb[q]); lq[q] = __builtin_bit_cast(float, lb[q]); oq[q] = __builtin_bit_cast(float, ob[q]); }
+            const float m = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
+            float den = 0.f, num = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float f = __expf(mq[q] - m);
+                den += mul_rn(lq[q], f);                              // (products of their own, as attn_cross_combine_kernel forms them: common.h)
+                num += mul_rn(oq[q], f);
+            }
+            s_row[h * 64 + lane] = (h16)(num / den);
+        }
+    }
+    __syncthreads();
+}
+
+// ---- the self-attention of the row as the launch's first stage -----------------------------------------------------------------
+// attn_self_wg_kernel (attn_decode.hip) at one new token of one utterance, for ONE head per workgroup: its four waves are this
+// workgroup's waves 0-3, same expressions in the same order (q / k / v = the qkv sums of the launch before + bias, rounded; the
+// cache append at position T; key blocks of 64 dealt over the waves, a key per lane; the two-pass softmax with fp16 probabilities;
+// P.V by wave-wide 16-byte loads of whole V rows, partial sums added in (wave, row, block) order) -- bit for bit.  The head's 64
+// outputs are published as granules (p.gran_c, tagged with the launch's epoch) for the out projection, this launch's next stage.
+template <bool I8>
+__device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, unsigned epoch0, int h, float* s_p, h16 (*s_new)[64],
+                                                 float (*s_r2)[4], float* s_o_flat) {
+    constexpr float SCALE = 0.35355339059327373f;     // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
+    constexpr int ES = I8 ? 1 : 2;
+    constexpr int ROW_B = 64 * ES;
+    constexpr int DIMS = 16 / ES;
+    constexpr int NCH = 64 / DIMS;
+    constexpr int VROWS = 64 / NCH;
+    constexpr int KCH = ROW_B / 16;
+    constexpr int VPRE = 4;
+    constexpr int NW = 4, NT = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool worker = wid < NW;
+    h16* s_q = s_new[0]; h16* s_knew = s_new[1]; h16* s_vnew = s_new[2];
+    const int T = p.self_t_dev ? *p.self_t_dev : p.self_T;
+    const int H = p.self_heads, C = H * 64;
+    const unsigned char* pastK = (const unsigned char*)p.self_cache + ((size_t)(0 * H + h) * p.self_cap * 64) * ES;
+    const unsigned char* pastV = (const unsigned char*)p.self_cache + ((size_t)(1 * H + h) * p.self_cap * 64) * ES;
+    const int vr = lane / NCH, vc = lane % NCH;
+    uint4 kpre[KCH], vpre[VPRE];
+    if (worker && T > 0) {
+        const int kr = min(64 * wid + lane, T - 1);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) kpre[c] = ((const uint4*)(pastK + (size_t)kr * ROW_B))[c];
+#pragma unroll
+        for (int n = 0; n < VPRE; ++n) {
+            const int row = min((wid + NW * n) * VROWS + vr, T - 1);
+            vpre[n] = *(const uint4*)(pastV + (size_t)row * ROW_B + vc * 16);
+        }
+    }
+    const float t_dq = p.self_kv_scale;
+    const float inv_t = 1.0f / p.self_kv_scale;
+    if (wid == 0) {                                   // this call's q, k, v of the head (lane = dim): one slab, bias, fp16; the cache append
+        float q = 0.f, k = 0.f, v = 0.f;
+        const float* row = p.self_part + h * 64 + lane;
+        q += row[0]; k += row[C]; v += row[2 * C];
+        q = r16(q + (p.self_bias ? (float)p.self_bias[h * 64 + lane] : 0.f));
+        k = r16(k + (p.self_bias ? (float)p.self_bias[C + h * 64 + lane] : 0.f));
+        v = r16(v + (p.self_bias ? (float)p.self_bias[2 * C + h * 64 + lane] : 0.f));
+        s_knew[lane] = (h16)k;
+        s_vnew[lane] = (h16)v;
+        const size_t off_k = ((size_t)(0 * H + h) * p.self_cap + T) * 64 + lane;
+        const size_t off_v = ((size_t)(1 * H + h) * p.self_cap + T) * 64 + lane;
+        if (I8) {
+            ((int8_t*)p.self_cache)[off_k] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(k * inv_t)));
+            ((int8_t*)p.self_cache)[off_v] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(v * inv_t)));
+        } else {
+            ((h16*)p.self_cache)[off_k] = (h16)k;
+            ((h16*)p.self_cache)[off_v] = (h16)v;
+        }
+        s_q[lane] = (h16)r16(q * SCALE);
+    }
+    __syncthreads();
+    const int nk = T + 1;
+    float mx = -INFINITY;
+    if (worker) {
+        for (int kb = wid; kb * 64 < nk; kb += NW) {
+            const int j = kb * 64 + lane;
+            float sc = -INFINITY;
+            if (j < nk) {
+                float acc = 0.f;
+                if (j < T) {
+                    const uint4* kr = (const uint4*)(pastK + (size_t)j * ROW_B);
+#pragma unroll
+                    for (int c = 0; c < KCH; ++c) {
+                        const uint4 w = kb == wid ? kpre[c] : kr[c];
+                        if (I8) {
+                            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int8_t q8 = (int8_t)((ws[e >> 2] >> (8 * (e & 3))) & 0xff);
+                                const float kd = r16(r16((float)q8 * t_dq) * SCALE);
+                                acc = fmaf((float)s_q[c * 16 + e], kd, acc);
+                            }
+                        } else {
+                            const half8v wh = __builtin_bit_cast(half8v, w);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc = fmaf((float)s_q[c * 8 + e], r16((float)wh[e] * SCALE), acc);
+                        }
+                    }
+                } else {
+                    const h16* kn = s_knew;
+#pragma unroll 8
+                    for (int e = 0; e < 64; ++e) acc = fmaf((float)s_q[e], r16((float)kn[e] * SCALE), acc);
+                }
+                sc = r16(f32_as_is(acc));
+                s_p[j] = sc;
+            }
+            mx = fmaxf(mx, sc);
+        }
+        mx = wave_max_nomfma(mx);
+        if (lane == 0) s_r2[0][wid] = mx;
+    }
+    __syncthreads();
+    float e0 = 0.f, e1 = 0.f;
+    if (worker) {
+        mx = fmaxf(fmaxf(s_r2[0][0], s_r2[0][1]), fmaxf(s_r2[0][2], s_r2[0][3]));
+        e0 = tid < nk ? __expf(s_p[tid] - mx) : 0.f;
+        e1 = tid + NT < nk ? __expf(s_p[tid + NT] - mx) : 0.f;
+        const float wsum = wave_sum_nomfma(e0 + e1);
+        if (lane == 0) s_r2[1][wid] = wsum;
+    }
+    __syncthreads();
+    if (worker) {
+        const float inv = 1.0f / ((s_r2[1][0] + s_r2[1][1]) + (s_r2[1][2] + s_r2[1][3]));
+        if (tid < nk) s_p[tid] = r16(e0 * inv);
+        if (tid + NT < nk) s_p[tid + NT] = r16(e1 * inv);
+    }
+    __syncthreads();
+    if (worker) {
+        float o[DIMS];
+#pragma unroll
+        for (int d = 0; d < DIMS; ++d) o[d] = 0.f;
+        auto add_block = [&](int vb, const uint4& w) {
+            const int row = vb * VROWS + vr;
+            const float pj = row < T ? s_p[row] : 0.f;
+            if (I8) {
+                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const int8_t q8 = (int8_t)((ws[d >> 2] >> (8 * (d & 3))) & 0xff);
+                    o[d] = fmaf(pj, r16((float)q8 * t_dq), o[d]);
+                }
+            } else {
+                const half8v wh = __builtin_bit_cast(half8v, w);
+#pragma unroll
+                for (int d = 0; d < 8; ++d) o[d] = fmaf(pj, (float)wh[d], o[d]);
+            }
+        };
+#pragma unroll
+        for (int n = 0; n < VPRE; ++n) {
+            const int vb = wid + NW * n;
+            if (vb * VROWS < T) add_block(vb, vpre[n]);
+        }
+        for (int vb = wid + NW * VPRE; vb * VROWS < T; vb += NW) {
+            const int row = min(vb * VROWS + vr, T - 1);
+            add_block(vb, *(const uint4*)(pastV + (size_t)row * ROW_B + vc * 16));
+        }
+#pragma unroll
+        for (int d = 0; d < DIMS; ++d) s_o_flat[tid * (DIMS + 1) + d] = o[d];
+    }
+    __syncthreads();
+    if (wid == 0) {
+        const int ch = lane / DIMS, d = lane % DIMS;
+        float acc = 0.f;
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int r = 0; r < VROWS; ++r) acc += s_o_flat[(w * 64 + r * NCH + ch) * (DIMS + 1) + d];
+        for (int j = T; j < nk; ++j) acc = fmaf(s_p[j], (float)s_vnew[lane], acc);
+        const h16 out = (h16)f32_as_is(acc);
+        if (p.self_out) p.self_out[h * 64 + lane] = out;      // (plain copy: tests)
+        const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, out);
+        const unsigned nb_bits = __shfl_xor(bits, 1);
+        if ((lane & 1) == 0)
+            __hip_atomic_store((chain_gu64*)(p.gran_c + ((h * 64 + lane) >> 1)), ((unsigned long long)epoch0 << 32) | (bits | (nb_bits << 16)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
 }
 
 template <int WB>
@@ -517,24 +780,52 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     constexpr int TB = WB == 16 ? 10 : 5;
     // epochs never repeat: the generation word counts the decoder calls on this workspace (the embedding kernel that opens a call
     // increments it), the launch id the chains of a call, the low bits the stages of a chain
-    const unsigned epoch0 = (*p.generation << 9) | ((unsigned)p.launch_id << 2);
+    const unsigned epoch0 = (*p.generation << 10) | ((unsigned)p.launch_id << 3);
     extern __shared__ __attribute__((aligned(1024))) unsigned char kv_lds[];      // the cross-attention stage's K and V rows (only then)
     __shared__ float s_sc[CHAIN_CROSS_KEYS];
     __shared__ float s_redc[4][2];
     __shared__ float s_o[4][64];
     __shared__ float s_q[64];
     const int per_split = p.cross_kv ? ((((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7) : 0;
+    // Who does what besides the Linears.  The cross-attention's (head, piece) items go to the LAST workgroups of the launch and the
+    // self-attention's heads to the ones before them: the first workgroups own the output groups of every n_state-wide Linear (and
+    // both slots of the widest), the last ones idle through most stages -- and the four upper waves of a workgroup that carries
+    // K / V rows in flight must not meet a stage's "everything of mine has landed" wait before those rows are due.
     if (p.cross_kv) chain_cross_prefetch(p, kv_lds, per_split);
-    bool own_valid = false;
+    if (p.self_part) {
+        const int n_items = p.cross_kv ? p.cross_heads * p.cross_nsplit : 0;
+        const int base = max((int)gridDim.x - n_items - p.self_heads, 0);
+        const int h = (int)blockIdx.x - base;
+        if (h >= 0 && h < p.self_heads) {             // (workgroup-uniform) LDS: the Linears' buffers, not in use yet
+            float* s_p = &s_red[0][0][0];
+            h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
+            float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
+            float* s_o_flat = (float*)&s_in[0][0];
+            if (p.self_i8) chain_self_stage<true>(p, epoch0, h, s_p, s_new, s_r2, s_o_flat);
+            else chain_self_stage<false>(p, epoch0, h, s_p, s_new, s_r2, s_o_flat);
+        }
+    }
+    bool own_valid = false, x_in_granules = false;
     for (int s = 0; s < p.n_stages; ++s) {
         const ChainStage st = p.st[s];                        // (uniform: scalar loads of a descriptor no kernel writes)
         const bool wide = (st.K / KT + TB - 1) / TB > 4;
         const unsigned epoch = epoch0 + (unsigned)s + 1;      // the tag this stage's results carry; its inputs carry epoch - 1
-        if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own);
-        else if (st.ln_g) chain_stage<WB, false, true>(p, st, s, epoch, own_valid, s_red, s_in, s_own);
-        else chain_stage<WB, false, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own);
+        int in_kind = CHAIN_IN_GRANULES;
+        const unsigned long long* gran = p.gran_h;
+        unsigned tag = epoch - 1;
+        if (p.merge_ws && s == p.merge_at) in_kind = CHAIN_IN_MERGE;
+        else if (p.gran_p && s == p.merge_at) {               // (only the workgroups that own a group of this stage need the row)
+            if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged(p, epoch0 + (unsigned)p.cross_at + 1, &s_in[0][0]);
+            in_kind = CHAIN_IN_LDS;
+        }
+        else if (s == 0 && p.self_part) { gran = p.gran_c; tag = epoch0; }
+        else if (s == 0) in_kind = CHAIN_IN_PLAIN;
+        if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+        else if (st.ln_g) chain_stage<WB, false, true>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+        else chain_stage<WB, false, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+        if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
+        if (p.cross_kv && s == p.cross_at) chain_cross_stage(p, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
     }
-    if (p.cross_kv) chain_cross_stage(p, epoch0 + (unsigned)p.n_stages, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
 }
 
 // the word a wave sets when it gives up a bounded wait: one per device (the kernels get its address, wm_decode_chain_error reads it)
@@ -557,7 +848,7 @@ bool gemv_chain_supports(int C, int w8, int n_cu) {
 int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs, int n_wg, hipStream_t stream) {
     WM_REQUIRE(p.n_stages >= 1 && p.n_stages <= CHAIN_MAX_STAGES, "gemv_chain: %d stages", p.n_stages);
     WM_REQUIRE(p.x && p.gran_x && p.gran_h && p.err && p.generation && p.st && hs, "gemv_chain: null argument");
-    WM_REQUIRE(p.launch_id >= 0 && p.launch_id < 128, "gemv_chain: launch_id=%d", p.launch_id);
+    WM_REQUIRE(p.launch_id >= 0 && p.launch_id < 128, "gemv_chain: launch_id=%d", p.launch_id);      // (7 bits under the stage index)
     WM_REQUIRE(p.w8 == 0 || p.w8 == 1 || p.w8 == 4, "gemv_chain: w8=%d", p.w8);
     const int KT = p.w8 == 4 ? 128 : (p.w8 ? 64 : 32);
     int widest = 0;
@@ -566,19 +857,31 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs, int n_wg, 
         WM_REQUIRE(st.Wt && st.K % KT == 0 && st.K <= CHAIN_MAX_IN && st.n_blocks >= 1, "gemv_chain: stage %d shape", s);
         WM_REQUIRE(st.mode >= 0 && st.mode <= 2 && (st.mode != 0 || p.out32), "gemv_chain: stage %d mode %d", s, st.mode);
         WM_REQUIRE(!st.ln_g || (st.ln_b && st.K <= 1536), "gemv_chain: stage %d LayerNorm needs beta and K <= 1536", s);
-        WM_REQUIRE(s > 0 || st.ln_g || p.in16 || p.merge_ws, "gemv_chain: the first stage needs its input row");
-        WM_REQUIRE(!p.merge_ws || (p.merge_nsplit >= 1 && p.merge_nsplit <= 16 && p.merge_heads * 64 == hs[0].K && !hs[0].ln_g),
-                   "gemv_chain: merged input: %d pieces, %d heads for K=%d", p.merge_nsplit, p.merge_heads, hs[0].K);
-        WM_REQUIRE(s == 0 || st.ln_g || hs[s - 1].mode == 1, "gemv_chain: stage %d reads the hidden row, stage %d must produce it", s, s - 1);
+        const bool merged_in = (p.merge_ws || p.gran_p) && s == p.merge_at;
+        WM_REQUIRE(s > 0 || st.ln_g || p.in16 || merged_in || p.self_part, "gemv_chain: the first stage needs its input row");
+        WM_REQUIRE(!merged_in || (p.merge_nsplit >= 1 && p.merge_nsplit <= 16 && p.merge_heads * 64 == st.K && !st.ln_g && st.n_blocks <= n_wg),
+                   "gemv_chain: merged input: %d pieces, %d heads for K=%d", p.merge_nsplit, p.merge_heads, st.K);
+        WM_REQUIRE(s == 0 || st.ln_g || merged_in || hs[s - 1].mode == 1, "gemv_chain: stage %d reads the hidden row, stage %d must produce it", s, s - 1);
         WM_REQUIRE(s == 0 || !st.ln_g || hs[s - 1].mode == 2, "gemv_chain: stage %d normalises the residual row, stage %d must produce it", s, s - 1);
         const int TB = p.w8 ? 5 : 10, slices = (st.K / KT + TB - 1) / TB;
         const int need = slices > 4 ? st.n_blocks : (st.n_blocks + 1) / 2;
         widest = widest > need ? widest : need;
     }
+    WM_REQUIRE(!(p.merge_ws && p.gran_p) && (!(p.merge_ws || p.gran_p) || (p.merge_at >= 0 && p.merge_at < p.n_stages)), "gemv_chain: merge stage %d", p.merge_at);
+    WM_REQUIRE(!p.merge_ws || p.merge_at == 0, "gemv_chain: partial results in plain memory are the FIRST stage's input");
+    WM_REQUIRE(!p.gran_p || (p.cross_kv && p.merge_at > p.cross_at && p.merge_nsplit == 4 && p.cross_nsplit == 4 && p.merge_heads == p.cross_heads),
+               "gemv_chain: tagged partial results need this launch's cross-attention stage before the merge, 4 pieces");
+    if (p.self_part) {
+        WM_REQUIRE(p.self_cache && p.gran_c && p.self_heads >= 1 && p.self_heads * 64 == hs[0].K && !hs[0].ln_g && !(p.merge_at == 0 && (p.merge_ws || p.gran_p)) &&
+                   (p.self_t_dev || (p.self_T >= 0 && p.self_T < p.self_cap)) && p.self_cap <= 512 && (!p.self_i8 || p.self_kv_scale > 0.f),
+                   "gemv_chain: self-attention stage: bad arguments");
+        WM_REQUIRE(n_wg >= p.self_heads + (p.cross_kv ? p.cross_heads * p.cross_nsplit : 0), "gemv_chain: %d workgroups for the attention stages", n_wg);
+    }
     size_t dyn = 0;
     if (p.cross_kv) {
-        WM_REQUIRE(p.cross_ws && p.gran_q && hs[p.n_stages - 1].mode == 0 && p.cross_nsplit > 1 && p.cross_nsplit <= 16 && p.cross_Tk >= 1 &&
-                   p.cross_heads * 64 == hs[p.n_stages - 1].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
+        WM_REQUIRE(p.cross_at >= 0 && p.cross_at < p.n_stages, "gemv_chain: cross-attention behind stage %d", p.cross_at);
+        WM_REQUIRE((p.cross_ws || p.gran_p) && p.gran_q && hs[p.cross_at].mode == 0 && p.cross_nsplit > 1 && p.cross_nsplit <= 16 && p.cross_Tk >= 1 &&
+                   p.cross_heads * 64 == hs[p.cross_at].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
         const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
         WM_REQUIRE(per_split <= CHAIN_CROSS_KEYS, "gemv_chain: %d keys per piece", per_split);
         dyn = (size_t)2 * per_split * 128 + 1024;

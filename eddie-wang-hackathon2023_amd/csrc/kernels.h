@@ -73,8 +73,8 @@ int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
 // ---------------------------------------------------------------- gemv_chain.hip
 // A chain of gemv_small Linears at ONE activation row in one launch (batch 1): stage inputs / outputs between the stages travel
 // as {epoch, value} granules, the first stage reads plain memory, mode-0 results and the residual row go back to plain memory.
-constexpr int CHAIN_MAX_STAGES = 4;
-constexpr int DECODE_CHAIN_DEFAULT = 2;      // 0: off, 1: the Linears chained, 2: + the cross-attention pieces as the first chain's last stage
+constexpr int CHAIN_MAX_STAGES = 6;
+constexpr int DECODE_CHAIN_DEFAULT = 3;      // 0: off, 1: the Linears chained, 2: + the cross-attention pieces as the first chain's last stage, 3: one launch per layer
 struct ChainStage {                                           // (an engine keeps its layers' stages in DEVICE memory: a chain's
     const void* Wt; const h16* scale; const h16* bias;         // arguments stay small -- by value they were 330 bytes, and the runtime
     const h16* ln_g; const h16* ln_b;                         // staged such argument blocks with a blit per launch under graph replay)
@@ -97,8 +97,15 @@ struct GemvChainParams {
     // Linear (mode 0) has just published on gran_q; the pieces' partial results go to cross_ws for the next launch to merge
     const h16* cross_kv; int cross_Tk, cross_heads, cross_nsplit; float* cross_ws; const h16* cross_qbias;
     unsigned long long* gran_q;                               // C entries ({epoch, fp32 bits})
+    int cross_at;                                             // ... which is stage `cross_at` (mode 0); the cross-attention runs behind it
+    int merge_at;                                             // the stage whose input is the merged attention row: merge_ws (plain memory, the launch
+    unsigned long long* gran_p;                               // before) or gran_p (this launch's pieces, tagged: [H][66][4], 4 pieces only)
+    // optional first stage: the self-attention of this row (attn_self_wg_kernel's arithmetic, one head per workgroup) from the qkv sums
+    // the launch before left in self_part [3C] -- cache append included (in place) -- its output row on gran_c for stage 0
+    const float* self_part; const h16* self_bias; void* self_cache; int self_cap, self_T, self_heads, self_i8; const int32_t* self_t_dev;
+    float self_kv_scale; h16* self_out; unsigned long long* gran_c;     // C / 2 entries; self_out: optional plain copy [C]
     unsigned* err;                                            // set non-zero when a bounded wait gives up
-    const unsigned* generation; int launch_id;                // epochs: (*generation << 9) | (launch_id << 2), + stage + 1 (generation: one per decoder call)
+    const unsigned* generation; int launch_id;                // epochs: (*generation << 10) | (launch_id << 3), + stage + 1 (generation: one per decoder call)
 };
 bool gemv_chain_supports(int C, int w8, int n_cu);
 int gemv_chain_err_word(unsigned** out);                      // device address of this device's "a wait was given up" word

@@ -14,8 +14,9 @@ import bench
 bench.main()
 """ % (ROOT, os.path.join(ROOT, "eddie-wang-hackathon2023_amd"))
 for r in range(rounds):
-    for on in (0, 1, 2):
+    for on in (0, 1, 2, 3):
         out = subprocess.run([sys.executable, "-c", code, str(on), batch], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
         line = [l for l in out.splitlines() if l.startswith("{")][-1]
         res = json.loads(line)
-        print(f"batch {batch} chain {('off', 'linears', 'linears + cross')[on]} round {r}: {res['roofline']['decode_step_ms']} ms per token, {res['value']} tokens/s whole job", flush=True)
+        name = ("off", "linears", "linears + cross", "whole layer")[on]
+        print(f"batch {batch} chain {name} round {r}: {res['roofline']['decode_step_ms']} ms per token, {res['value']} tokens/s whole job", flush=True)

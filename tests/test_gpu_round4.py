@@ -347,9 +347,10 @@ def test_a_batch_that_straddles_the_decode_path_switches_matches_the_literal_loo
 # ------------------------------------------------------------------------------------------ the HIP runtime's graph-replay switch
 def test_graph_node_replay_still_pays():
     """native.py sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (replay captured graphs node by node) because it makes the small-batch
-    token step 6-10 % faster -- an undocumented debug switch of the HIP runtime that a ROCm update may drop or invert.  This test
-    measures it: a batch-1 decode loop on a large-v2-wide, 6-layer model in two fresh processes, with the package's default and
-    with the runtime's own default (=1).  It fails when the switch no longer helps (time to revisit native.py and the batch-1
+    token step 5-8 % faster -- an undocumented debug switch of the HIP runtime that a ROCm update may drop or invert.  This test
+    measures it: a batch-4 decode loop (a launch per fused Linear; at batch 1 a layer is ONE launch since round 4 and the switch
+    is worth 2 % there) on a large-v2-wide, 6-layer model in two fresh processes, with the package's default and with the
+    runtime's own default (=1).  It fails when the switch no longer helps (time to revisit native.py and the batch-1
     numbers in DESIGN.md), and when the package's setting did not reach the runtime in time."""
     import json
     import subprocess
@@ -368,7 +369,7 @@ out = Path(tempfile.mkdtemp()) / "eng"
 B.build_from_checkpoint(ck, B.parse_arguments(["--output_dir", str(out), "--log_level", "error", "--use_weight_only"]))
 d = ck["dims"]; del ck
 enc, dec = WhisperEncoding(out), WhisperDecoding(out, options=DecodingOptions(sample_len=96))
-mel = synthetic.synthetic_mel(1, 2 * d["n_audio_ctx"], d["n_mels"], 5).cuda()
+mel = synthetic.synthetic_mel(4, 2 * d["n_audio_ctx"], d["n_mels"], 5).cuda()
 xa = enc.get_audio_features(mel)
 dec.detect_language(xa)
 best = 1e9
@@ -416,7 +417,7 @@ def test_one_row_chain_equals_the_launch_per_linear_path(tmp_path_factory, model
     outs = []
     prev = lib_().wm_set_decode_chain(-1)
     try:
-        for on in (0, 1, 2):                                 # off | the Linears chained | + the cross-attention pieces as a chain stage
+        for on in (0, 1, 2, 3):                              # off | the Linears chained | + the cross-attention pieces as a chain stage | one launch per layer
             lib_().wm_set_decode_chain(on)
             dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
             dec.detect_language(xa)
