@@ -35,6 +35,9 @@
 namespace wm {
 
 typedef __attribute__((address_space(1))) unsigned long long chain_gu64;
+// The stage descriptors are read from memory, so the compiler knows nothing about the pointers in them and would use FLAT loads
+// (both wait counters, the slower path) for the weights: they are device memory, and said to be so.
+#define CHAIN_GLOBAL(T, ptr) ((const __attribute__((address_space(1))) T*)(ptr))
 
 constexpr int CHAIN_MAX_IN = 4 * 1536;     // widest stage input (halves): mlp2's K = 4 n_state
 
@@ -117,7 +120,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         const int slice = wslot + 8 * j;
         t_begin[j] = min(slice, slices - 1) * tps;
         t_end[j] = (slice < slices && has_group) ? min(kt_total, t_begin[j] + tps) : t_begin[j];     // (an absent slice multiplies nothing)
-        const u32x4* wt = (const u32x4*)st.Wt + (size_t)nb * kt_total * 64 + lane;
+        const __attribute__((address_space(1))) u32x4* wt = CHAIN_GLOBAL(u32x4, st.Wt) + (size_t)nb * kt_total * 64 + lane;
         const int t_last = max(min(kt_total, t_begin[j] + tps) - 1, 0);
         if (slice < slices && has_group) {                    // (wave-uniform: an idle slot or an absent slice streams nothing)
 #pragma unroll
@@ -139,8 +142,8 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             half8v xr[XP], gp[XP], bp[XP];
 #pragma unroll
             for (int u = 0; u < XP; ++u) {
-                gp[u] = *(const half8v*)(st.ln_g + min(lane + 64 * u, pieces_per_row - 1) * 8);
-                bp[u] = *(const half8v*)(st.ln_b + min(lane + 64 * u, pieces_per_row - 1) * 8);
+                gp[u] = *CHAIN_GLOBAL(half8v, st.ln_g + min(lane + 64 * u, pieces_per_row - 1) * 8);
+                bp[u] = *CHAIN_GLOBAL(half8v, st.ln_b + min(lane + 64 * u, pieces_per_row - 1) * 8);
             }
             bool ok = true;
             if (!x_in_granules) {                             // the row as the launches before this one left it (plain memory)
@@ -307,7 +310,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 
     // ---- 3. multiply (gemv_small's loop), K slices to LDS scaled, in slice order ------------------------------------------
     const int col = nb * 16 + rl;
-    const float sc = (WB != 16 && st.scale) ? (float)st.scale[col] : 1.0f;
+    const float sc = (WB != 16 && st.scale) ? (float)CHAIN_GLOBAL(h16, st.scale)[col] : 1.0f;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
@@ -364,7 +367,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             for (int r = 0; r < 4; ++r) sum[r] += tw[r];
         }
         const float y = sum[0];                               // row 0 (lanes 0-15); the other lanes hold rows that do not exist
-        const float bias = (st.mode == 1 || st.mode == 2) && st.bias ? (float)st.bias[col] : 0.f;
+        const float bias = (st.mode == 1 || st.mode == 2) && st.bias ? (float)CHAIN_GLOBAL(h16, st.bias)[col] : 0.f;
         if (st.mode == 0) {
             if (g == 0) {
                 p.out32[col] = y;                             // raw sums for the attention kernel of the next launch
@@ -438,6 +441,8 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, unsi
     const bool worker = wid < 4 && has_item && nkeys > 0;
     float* w_out = p.cross_ws + (size_t)(h * p.cross_nsplit + sp) * 66;
 
+    half8v qb8 = half8v{0, 0, 0, 0, 0, 0, 0, 0};                              // the lane's 8 q-bias values: requested now, not behind the wait for q
+    if (worker && p.cross_qbias) qb8 = *(const half8v*)(p.cross_qbias + h * 64 + sub * DPL);
     if (wid >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's K / V pieces have landed
     if (wid == 0 && has_item) {                                               // the head's 64 q sums, as the last Linear published them
         int fst[1] = {h * 64 + 2 * min(lane, 31)};
@@ -468,14 +473,13 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, unsi
     float mx = -INFINITY;
     if (worker) {
         // q of this lane's 8 dims: one slab, bias, the two roundings (attn_cross_kernel's prologue at ksplit = 1)
-        const int col0 = h * 64 + sub * DPL;
 #pragma unroll
         for (int e = 0; e < DPL; ++e) {
             const float x = s_q[sub * DPL + e];
             float qa = 0.f;
             qa += x + 0.f;
             qa += 0.f + 0.f;
-            const float bs = p.cross_qbias ? (float)p.cross_qbias[col0 + e] : 0.f;
+            const float bs = (float)qb8[e];
             qf[e] = r16(r16(qa + bs) * CHAIN_ATTN_SCALE);
         }
         // ---- pass 1: scores ------------------------------------------------------------------------------------------------
