@@ -13,6 +13,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -148,7 +149,11 @@ struct wm_engine {
     std::vector<DecLayer> dec;
     // the one-row chain's stage descriptors (gemv_chain.hip), six per layer in chain order: out, cq | cout, mlp1, mlp2, qkv of the
     // next layer -- on the device (the kernels read them there) and on the host (the launcher's checks)
-    wm::ChainStage* chain_dev = nullptr; std::vector<wm::ChainStage> chain_host;
+    wm::ChainStage* chain_dev = nullptr; std::vector<wm::ChainStage> chain_host;      // [qkv of layer 0] + 6 per layer (gemv_chain.hip)
+    wm::ChainLayerStatic* chain_lstat = nullptr;                                       // per layer: biases of the attention stages, cache scale
+    // the caller's per-layer pointers (cross K/V, cache) as last written to a workspace's table (whole-step launch): keyed by the table's address
+    mutable std::mutex chain_io_mu;
+    mutable std::unordered_map<const void*, std::vector<wm::ChainLayerIo>> chain_io_seen;
     bool w8() const { return flags & WM_FLAG_WEIGHT_ONLY_INT8; }
     bool i8kv() const { return flags & WM_FLAG_INT8_KV; }
     bool i8cross() const { return flags & WM_FLAG_INT8_CROSS_KV; }
@@ -381,13 +386,13 @@ int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** ou
     if (resolve(e)) { (void)hipFree(e->dev); delete e; return 1; }
     if (e->kind == WM_ENGINE_DECODER && !e->dec.empty()) {
         const int n = (int)e->dec.size();
-        e->chain_host.resize((size_t)6 * n);
+        e->chain_host.resize((size_t)6 * n + 1);
         auto fill = [](wm::ChainStage& st, const Lin& l, const h16* g, const h16* b, int mode) {
             st.Wt = l.w; st.scale = l.s; st.bias = l.b; st.ln_g = g; st.ln_b = b; st.K = l.K; st.n_blocks = l.n_blocks; st.mode = mode; st.pad_ = 0;
         };
         for (int i = 0; i < n; ++i) {
             const DecLayer& L = e->dec[i];
-            wm::ChainStage* st = &e->chain_host[(size_t)6 * i];
+            wm::ChainStage* st = &e->chain_host[(size_t)6 * i + 1];
             fill(st[0], L.out, nullptr, nullptr, 2);
             fill(st[1], L.cq, L.lncg, L.lncb, 0);
             fill(st[2], L.cout, nullptr, nullptr, 2);
@@ -396,11 +401,16 @@ int wm_engine_create(const void* blob, size_t nbytes, int device, wm_engine** ou
             if (i + 1 < n) fill(st[5], e->dec[i + 1].qkv, e->dec[i + 1].ln1g, e->dec[i + 1].ln1b, 0);
             else st[5] = wm::ChainStage{};
         }
-        const size_t bytes = e->chain_host.size() * sizeof(wm::ChainStage);
-        if (hipMalloc((void**)&e->chain_dev, bytes) != hipSuccess ||
-            hipMemcpy(e->chain_dev, e->chain_host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
-            set_error("wm_engine_create: the decode chain's descriptor table could not be placed on the device");
+        fill(e->chain_host[0], e->dec[0].qkv, e->dec[0].ln1g, e->dec[0].ln1b, 0);
+        std::vector<wm::ChainLayerStatic> lstat((size_t)n);
+        for (int i = 0; i < n; ++i) lstat[i] = wm::ChainLayerStatic{e->dec[i].qkv.b, e->dec[i].cq.b, e->dec[i].kv_scale, 0};
+        const size_t bytes = e->chain_host.size() * sizeof(wm::ChainStage), lbytes = lstat.size() * sizeof(wm::ChainLayerStatic);
+        if (hipMalloc((void**)&e->chain_dev, bytes) != hipSuccess || hipMalloc((void**)&e->chain_lstat, lbytes) != hipSuccess ||
+            hipMemcpy(e->chain_dev, e->chain_host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(e->chain_lstat, lstat.data(), lbytes, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("wm_engine_create: the decode chain's descriptor tables could not be placed on the device");
             if (e->chain_dev) (void)hipFree(e->chain_dev);
+            if (e->chain_lstat) (void)hipFree(e->chain_lstat);
             (void)hipFree(e->dev); delete e; return 2;
         }
     }
@@ -412,6 +422,7 @@ void wm_engine_destroy(wm_engine* e) {
     if (!e) return;
     if (e->dev) { (void)hipSetDevice(e->device); (void)hipFree(e->dev); }
     if (e->chain_dev) (void)hipFree(e->chain_dev);
+    if (e->chain_lstat) (void)hipFree(e->chain_lstat);
     delete e;
 }
 
@@ -546,7 +557,7 @@ int prof_slot(Profiler& pr, int layer, hipStream_t s) {
 }
 
 struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t part_elems; int nsplit; size_t total;
-               unsigned long long *gran_x, *gran_h, *gran_q, *gran_c, *gran_p; unsigned* generation; };      // granule edges of the one-row chain (gemv_chain.hip) and its call counter
+               unsigned long long *gran_x, *gran_h, *gran_q, *gran_c, *gran_p, *gran_s; wm::ChainLayerIo* layer_io; unsigned* generation; };      // granule edges of the one-row chain (gemv_chain.hip) and its call counter
 
 int cross_nsplit(int B, int H) {
     // Pieces the key range of the decode cross-attention is cut into (one workgroup per (utterance, head, piece), partial
@@ -590,6 +601,8 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
     w.gran_q = c.take<unsigned long long>(C + 8);
     w.gran_c = c.take<unsigned long long>(C / 2 + 8);
     w.gran_p = c.take<unsigned long long>((size_t)d.n_text_head * 66 * 4 + 8);
+    w.gran_s = c.take<unsigned long long>(3 * C + 8);
+    w.layer_io = c.take<wm::ChainLayerIo>((size_t)d.n_text_layer);
     w.generation = c.take<unsigned>(4);
     w.total = align_up(c.off);
     return w;
@@ -774,13 +787,13 @@ struct GroupStep {
             p.self_T = T; p.self_t_dev = io->n_past_dev; p.self_heads = H; p.self_i8 = e->i8kv() ? 1 : 0; p.self_kv_scale = Lr.kv_scale;
             p.self_out = nullptr; p.gran_c = w.gran_c;
         }
-        p.n_stages = n; p.st = e->chain_dev + (size_t)6 * i + first;
+        p.n_stages = n; p.st = e->chain_dev + 1 + (size_t)6 * i + first;
         p.out32 = w.part;
         p.w8 = e->dec[i].out.wcode; p.gelu_kind = e->gelu();
         p.in16 = in16; p.x = w.x; p.hid_out = nullptr;
         p.gran_x = w.gran_x; p.gran_h = w.gran_h; p.err = chain_err;
         p.generation = w.generation; p.launch_id = launch_id;
-        return launch_gemv_chain(p, &e->chain_host[(size_t)6 * i + first], chain_wgs, s);
+        return launch_gemv_chain(p, &e->chain_host[1 + (size_t)6 * i + first], chain_wgs, s);
     }
 
     int finish(const Lin& l, int ks, int mode, const h16* g, const h16* bta, h16* out, int ldo, int N, hipStream_t s) {
@@ -803,9 +816,52 @@ struct GroupStep {
     }
 
     // self-attention block and the cross-attention query projection of layer i
+    // The whole token step of a one-row group as ONE launch (mode 4): [LayerNorm + qkv of layer 0], then per layer self-attention,
+    // out, cq, cross-attention, merge + cout, mlp1, mlp2, qkv of the next layer -- gemv_chain.hip walks over the layers itself; the
+    // per-layer cross K/V and cache pointers reach it through a table in the workspace, rewritten (small launches on this stream)
+    // only when the caller's pointers differ from the ones last written there.  Same conditions as the one-launch-per-layer form,
+    // for every layer: in-place cache, four key-range pieces, fp16 cross K/V.
+    bool step_done = false;
+    int whole_step(hipStream_t s) {
+        const wm_dims& d = e->dims;
+        const int n = d.n_text_layer;
+        if (!(chain && g_decode_chain.load(std::memory_order_relaxed) >= 4 && w.nsplit == 4 && !e->i8cross() && self_attn_waves(M) == 4 &&
+              io->present_capacity <= 512 && H + H * w.nsplit <= chain_wgs && n <= 62 && e->chain_lstat)) return 0;
+        std::vector<ChainLayerIo> tab((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            if (!io->present[i] || !io->cross[i]) return 0;
+            if (T == 0 ? io->n_past_dev != nullptr : !(io->past[i] == io->present[i] && io->past_capacity == io->present_capacity)) return 0;
+            tab[i] = ChainLayerIo{io->cross[i], io->present[i]};
+        }
+        {
+            std::lock_guard<std::mutex> lk(e->chain_io_mu);
+            std::vector<ChainLayerIo>& seen = e->chain_io_seen[w.layer_io];
+            const bool same = seen.size() == tab.size() && memcmp(seen.data(), tab.data(), tab.size() * sizeof(ChainLayerIo)) == 0;
+            if (!same) {
+                if (launch_chain_io_table(w.layer_io, tab.data(), n, s)) return 2;
+                seen = tab;
+            }
+        }
+        GemvChainParams p{};
+        p.n_layers = n; p.lstat = e->chain_lstat; p.lio = w.layer_io; p.gran_s = w.gran_s;
+        p.st = e->chain_dev; p.n_stages = 0;
+        p.cross_Tk = d.n_audio_ctx; p.cross_heads = H; p.cross_nsplit = w.nsplit; p.gran_q = w.gran_q; p.cross_at = 1;
+        p.gran_p = w.gran_p; p.merge_at = 2; p.merge_nsplit = w.nsplit; p.merge_heads = H;
+        p.self_cap = io->present_capacity; p.self_T = T; p.self_t_dev = io->n_past_dev; p.self_heads = H; p.self_i8 = e->i8kv() ? 1 : 0;
+        p.gran_c = w.gran_c;
+        p.out32 = w.part; p.w8 = e->dec[0].out.wcode; p.gelu_kind = e->gelu();
+        p.x = w.x; p.gran_x = w.gran_x; p.gran_h = w.gran_h; p.err = chain_err;
+        p.generation = w.generation; p.launch_id = 0;
+        if (launch_gemv_chain(p, e->chain_host.data(), chain_wgs, s)) return 2;
+        step_done = true;
+        return 0;
+    }
+
     int pre_cross(int i, hipStream_t s) {
         const DecLayer& Lr = e->dec[i];
         int ks = 0;
+        if (i == 0) { step_done = false; if (int rc = whole_step(s)) return rc; }
+        if (step_done) return 0;
         mark(i, 0, s);
         if (small) {
             // (chained: layers > 0 got their qkv sums from the chain that closed the layer before)
@@ -878,7 +934,7 @@ struct GroupStep {
 
     // the HBM-bound kernel: K and V of every utterance of the group, once
     int cross(int i, hipStream_t s) {
-        if (chain && chain_cross) return 0;           // done by the chain behind the self-attention
+        if (step_done || (chain && chain_cross)) return 0;           // done by the chain behind the self-attention
         if (!prof->timeline) return cross_launch(i, s);
         hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, prof->timeline, prof->timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i));
         const int rc = cross_launch(i, s);
@@ -910,7 +966,7 @@ struct GroupStep {
         const wm_dims& d = e->dims;
         int ks = 0;
         mark(i, 6, s);
-        if (chain && layer_done) return 0;
+        if (step_done || (chain && layer_done)) return 0;
         if (chain) {             // [x += cout(ctx)] -> [LN + mlp1 + GELU] -> [x += mlp2] -> [LN + qkv sums of the next layer] in one launch
             const bool more = i + 1 < d.n_text_layer;
             const int rc = run_chain(i, 2, more ? 4 : 3, w.ctx, 2 * i + 1, s, w.nsplit > 1);
@@ -1246,7 +1302,7 @@ int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void
 
 int wm_set_decode_chain(int on) {
     const int prev = g_decode_chain.load(std::memory_order_relaxed);
-    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on > 3 ? 3 : on), std::memory_order_relaxed);
+    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on > 4 ? 4 : on), std::memory_order_relaxed);
     return prev;
 }
 

@@ -371,8 +371,9 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         if (st.mode == 0) {
             if (g == 0) {
                 p.out32[col] = y;                             // raw sums for the attention kernel of the next launch
-                if (p.gran_q && s == p.cross_at)              // ... or of this launch's cross-attention stage
-                    __hip_atomic_store((chain_gu64*)(p.gran_q + col), ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, y),
+                unsigned long long* gq = s == p.cross_at ? p.gran_q : p.gran_s;      // ... or of this launch's attention stages: cross (q) | self (q, k, v of the next layer)
+                if (gq)
+                    __hip_atomic_store((chain_gu64*)(gq + col), ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, y),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
@@ -406,9 +407,11 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 // order, only the rows come from LDS, where waves 4-7 put them by DMA at the START of the launch (K and V do not depend on the
 // activations: their 96 KB fly while the chain's Linears run) instead of from memory through a register pipeline.
 constexpr int CHAIN_CROSS_KEYS = 1536;
+// what the attention stages take per LAYER (kernel arguments for a one-layer launch, the two tables in a whole-step launch)
+struct ChainLayerArgs { const h16* cross_kv; const h16* cross_qbias; void* self_cache; const h16* self_bias; float self_kv_scale; };
 constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
 
-__device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, unsigned char* kv_lds, int per_split) {
+__device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, const void* cross_kv, unsigned char* kv_lds, int per_split) {
     // waves 4-7: this workgroup's piece of K, then of V, as 1 KiB pieces (8 rows of 128 B) into LDS, linear
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_items = p.cross_heads * p.cross_nsplit, item = (int)blockIdx.x - ((int)gridDim.x - n_items);     // the LAST workgroups (see the kernel)
@@ -418,7 +421,7 @@ __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, u
     if (nkeys == 0) return;
     const int n_pieces = (nkeys + 7) >> 3;
     for (int m = 0; m < 2; ++m) {
-        const unsigned char* src = (const unsigned char*)p.cross_kv + ((size_t)(m * p.cross_heads + h) * p.cross_Tk + k_begin) * 128;
+        const unsigned char* src = (const unsigned char*)cross_kv + ((size_t)(m * p.cross_heads + h) * p.cross_Tk + k_begin) * 128;
         for (int pc = wid - 4; pc < n_pieces; pc += 4) {
             const int row = min(pc * 8 + (lane >> 3), nkeys - 1);        // rows past the piece re-read its last row (never used)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * 128 + (lane & 7) * 16),
@@ -427,7 +430,7 @@ __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, u
     }
 }
 
-__device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, unsigned epoch_q, const unsigned char* kv_lds, int per_split,
+__device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, const ChainLayerArgs& la, unsigned epoch_q, const unsigned char* kv_lds, int per_split,
                                                   float* s_sc, float (*s_redc)[2], float (*s_o)[64], float* s_q) {
     constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
     constexpr int STRIDE = 4 * RPI * UNR;
@@ -442,7 +445,7 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, unsi
     float* w_out = p.cross_ws + (size_t)(h * p.cross_nsplit + sp) * 66;
 
     half8v qb8 = half8v{0, 0, 0, 0, 0, 0, 0, 0};                              // the lane's 8 q-bias values: requested now, not behind the wait for q
-    if (worker && p.cross_qbias) qb8 = *(const half8v*)(p.cross_qbias + h * 64 + sub * DPL);
+    if (worker && la.cross_qbias) qb8 = *(const half8v*)(la.cross_qbias + h * 64 + sub * DPL);
     if (wid >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's K / V pieces have landed
     if (wid == 0 && has_item) {                                               // the head's 64 q sums, as the last Linear published them
         int fst[1] = {h * 64 + 2 * min(lane, 31)};
@@ -615,7 +618,7 @@ __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, uns
 // P.V by wave-wide 16-byte loads of whole V rows, partial sums added in (wave, row, block) order) -- bit for bit.  The head's 64
 // outputs are published as granules (p.gran_c, tagged with the launch's epoch) for the out projection, this launch's next stage.
 template <bool I8>
-__device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, unsigned epoch0, int h, float* s_p, h16 (*s_new)[64],
+__device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const ChainLayerArgs& la, unsigned epoch0, unsigned tag_s, int h, float* s_p, h16 (*s_new)[64],
                                                  float (*s_r2)[4], float* s_o_flat) {
     constexpr float SCALE = 0.35355339059327373f;     // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
     constexpr int ES = I8 ? 1 : 2;
@@ -631,8 +634,8 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, unsig
     h16* s_q = s_new[0]; h16* s_knew = s_new[1]; h16* s_vnew = s_new[2];
     const int T = p.self_t_dev ? *p.self_t_dev : p.self_T;
     const int H = p.self_heads, C = H * 64;
-    const unsigned char* pastK = (const unsigned char*)p.self_cache + ((size_t)(0 * H + h) * p.self_cap * 64) * ES;
-    const unsigned char* pastV = (const unsigned char*)p.self_cache + ((size_t)(1 * H + h) * p.self_cap * 64) * ES;
+    const unsigned char* pastK = (const unsigned char*)la.self_cache + ((size_t)(0 * H + h) * p.self_cap * 64) * ES;
+    const unsigned char* pastV = (const unsigned char*)la.self_cache + ((size_t)(1 * H + h) * p.self_cap * 64) * ES;
     const int vr = lane / NCH, vc = lane % NCH;
     uint4 kpre[KCH], vpre[VPRE];
     if (worker && T > 0) {
@@ -645,25 +648,42 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, unsig
             vpre[n] = *(const uint4*)(pastV + (size_t)row * ROW_B + vc * 16);
         }
     }
-    const float t_dq = p.self_kv_scale;
-    const float inv_t = 1.0f / p.self_kv_scale;
+    const float t_dq = la.self_kv_scale;
+    const float inv_t = 1.0f / la.self_kv_scale;
     if (wid == 0) {                                   // this call's q, k, v of the head (lane = dim): one slab, bias, fp16; the cache append
         float q = 0.f, k = 0.f, v = 0.f;
-        const float* row = p.self_part + h * 64 + lane;
-        q += row[0]; k += row[C]; v += row[2 * C];
-        q = r16(q + (p.self_bias ? (float)p.self_bias[h * 64 + lane] : 0.f));
-        k = r16(k + (p.self_bias ? (float)p.self_bias[C + h * 64 + lane] : 0.f));
-        v = r16(v + (p.self_bias ? (float)p.self_bias[2 * C + h * 64 + lane] : 0.f));
+        if (p.gran_s) {                               // the sums the qkv stage of THIS launch has just published (the whole step in one launch)
+            int first[3] = {h * 64 + 2 * min(lane, 31), C + h * 64 + 2 * min(lane, 31), 2 * C + h * 64 + 2 * min(lane, 31)};
+            u32x4 val[3];
+            float* s_f = s_p;                         // (s_p is not in use yet: 3 x 64 floats)
+            if (sweep_granules16<3>(p.gran_s, first, tag_s, val, p.err, lane) && lane < 32) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    unsigned a0 = val[m].x, a1 = val[m].z;
+                    asm volatile("" : "+v"(a0), "+v"(a1));        // (see chain_cross_stage)
+                    s_f[m * 64 + 2 * lane] = __builtin_bit_cast(float, a0);
+                    s_f[m * 64 + 2 * lane + 1] = __builtin_bit_cast(float, a1);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS writes before its reads
+            q += s_f[lane]; k += s_f[64 + lane]; v += s_f[128 + lane];
+        } else {
+            const float* row = p.self_part + h * 64 + lane;
+            q += row[0]; k += row[C]; v += row[2 * C];
+        }
+        q = r16(q + (la.self_bias ? (float)la.self_bias[h * 64 + lane] : 0.f));
+        k = r16(k + (la.self_bias ? (float)la.self_bias[C + h * 64 + lane] : 0.f));
+        v = r16(v + (la.self_bias ? (float)la.self_bias[2 * C + h * 64 + lane] : 0.f));
         s_knew[lane] = (h16)k;
         s_vnew[lane] = (h16)v;
         const size_t off_k = ((size_t)(0 * H + h) * p.self_cap + T) * 64 + lane;
         const size_t off_v = ((size_t)(1 * H + h) * p.self_cap + T) * 64 + lane;
         if (I8) {
-            ((int8_t*)p.self_cache)[off_k] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(k * inv_t)));
-            ((int8_t*)p.self_cache)[off_v] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(v * inv_t)));
+            ((int8_t*)la.self_cache)[off_k] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(k * inv_t)));
+            ((int8_t*)la.self_cache)[off_v] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(v * inv_t)));
         } else {
-            ((h16*)p.self_cache)[off_k] = (h16)k;
-            ((h16*)p.self_cache)[off_v] = (h16)v;
+            ((h16*)la.self_cache)[off_k] = (h16)k;
+            ((h16*)la.self_cache)[off_v] = (h16)v;
         }
         s_q[lane] = (h16)r16(q * SCALE);
     }
@@ -784,51 +804,75 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     constexpr int TB = WB == 16 ? 10 : 5;
     // epochs never repeat: the generation word counts the decoder calls on this workspace (the embedding kernel that opens a call
     // increments it), the launch id the chains of a call, the low bits the stages of a chain
-    const unsigned epoch0 = (*p.generation << 10) | ((unsigned)p.launch_id << 3);
+    const unsigned gen = *p.generation;
     extern __shared__ __attribute__((aligned(1024))) unsigned char kv_lds[];      // the cross-attention stage's K and V rows (only then)
     __shared__ float s_sc[CHAIN_CROSS_KEYS];
     __shared__ float s_redc[4][2];
     __shared__ float s_o[4][64];
     __shared__ float s_q[64];
-    const int per_split = p.cross_kv ? ((((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7) : 0;
+    // The WHOLE token step in one launch (p.n_layers > 0): the launch walks over the layers itself.  Per-layer pointers come from two
+    // tables (the engine's: biases and the cache scale; the caller's, in the workspace: cross K/V and cache of each layer), the
+    // descriptors are [qkv of layer 0] + 6 per layer, and "layer -1" is that first projection alone (its sums go out as granules,
+    // as every later qkv projection's do, for the self-attention stage behind it).
+    const bool whole = p.n_layers > 0;
+    ChainLayerArgs la{p.cross_kv, p.cross_qbias, p.self_cache, p.self_bias, p.self_kv_scale};
+    const int per_split = (p.cross_kv || whole) ? ((((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7) : 0;
     // Who does what besides the Linears.  The cross-attention's (head, piece) items go to the LAST workgroups of the launch and the
     // self-attention's heads to the ones before them: the first workgroups own the output groups of every n_state-wide Linear (and
     // both slots of the widest), the last ones idle through most stages -- and the four upper waves of a workgroup that carries
     // K / V rows in flight must not meet a stage's "everything of mine has landed" wait before those rows are due.
-    if (p.cross_kv) chain_cross_prefetch(p, kv_lds, per_split);
-    if (p.self_part) {
-        const int n_items = p.cross_kv ? p.cross_heads * p.cross_nsplit : 0;
-        const int base = max((int)gridDim.x - n_items - p.self_heads, 0);
-        const int h = (int)blockIdx.x - base;
-        if (h >= 0 && h < p.self_heads) {             // (workgroup-uniform) LDS: the Linears' buffers, not in use yet
-            float* s_p = &s_red[0][0][0];
-            h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
-            float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
-            float* s_o_flat = (float*)&s_in[0][0];
-            if (p.self_i8) chain_self_stage<true>(p, epoch0, h, s_p, s_new, s_r2, s_o_flat);
-            else chain_self_stage<false>(p, epoch0, h, s_p, s_new, s_r2, s_o_flat);
-        }
-    }
+    if (whole) chain_cross_prefetch(p, p.lio[0].cross_kv, kv_lds, per_split);
+    else if (p.cross_kv) chain_cross_prefetch(p, p.cross_kv, kv_lds, per_split);
     bool own_valid = false, x_in_granules = false;
-    for (int s = 0; s < p.n_stages; ++s) {
-        const ChainStage st = p.st[s];                        // (uniform: scalar loads of a descriptor no kernel writes)
-        const bool wide = (st.K / KT + TB - 1) / TB > 4;
-        const unsigned epoch = epoch0 + (unsigned)s + 1;      // the tag this stage's results carry; its inputs carry epoch - 1
-        int in_kind = CHAIN_IN_GRANULES;
-        const unsigned long long* gran = p.gran_h;
-        unsigned tag = epoch - 1;
-        if (p.merge_ws && s == p.merge_at) in_kind = CHAIN_IN_MERGE;
-        else if (p.gran_p && s == p.merge_at) {               // (only the workgroups that own a group of this stage need the row)
-            if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged(p, epoch0 + (unsigned)p.cross_at + 1, &s_in[0][0]);
-            in_kind = CHAIN_IN_LDS;
+    for (int l = whole ? -1 : 0; l < (whole ? p.n_layers : 1); ++l) {
+        const unsigned epoch0 = (gen << 10) | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);
+        if (whole && l >= 0) {
+            const ChainLayerStatic ls = p.lstat[l];
+            const ChainLayerIo li = p.lio[l];
+            la.cross_kv = (const h16*)li.cross_kv; la.cross_qbias = ls.cq_bias;
+            la.self_cache = li.cache; la.self_bias = ls.qkv_bias; la.self_kv_scale = ls.kv_scale;
         }
-        else if (s == 0 && p.self_part) { gran = p.gran_c; tag = epoch0; }
-        else if (s == 0) in_kind = CHAIN_IN_PLAIN;
-        if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
-        else if (st.ln_g) chain_stage<WB, false, true>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
-        else chain_stage<WB, false, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
-        if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
-        if (p.cross_kv && s == p.cross_at) chain_cross_stage(p, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
+        if ((whole && l >= 0) || (!whole && p.self_part)) {
+            const int n_items = (whole || p.cross_kv) ? p.cross_heads * p.cross_nsplit : 0;
+            const int base = max((int)gridDim.x - n_items - p.self_heads, 0);
+            const int h = (int)blockIdx.x - base;
+            if (h >= 0 && h < p.self_heads) {             // (workgroup-uniform) LDS: the Linears' buffers, not in use now
+                float* s_p = &s_red[0][0][0];
+                h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
+                float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
+                float* s_o_flat = (float*)&s_in[0][0];
+                const unsigned tag_s = ((gen << 10) | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
+                if (p.self_i8) chain_self_stage<true>(p, la, epoch0, tag_s, h, s_p, s_new, s_r2, s_o_flat);
+                else chain_self_stage<false>(p, la, epoch0, tag_s, h, s_p, s_new, s_r2, s_o_flat);
+            }
+        }
+        const int s_first = l < 0 ? 5 : 0;
+        const int s_end = !whole ? p.n_stages : (l < 0 ? 6 : (l + 1 < p.n_layers ? 6 : 5));
+        const bool attn = whole ? l >= 0 : true;
+        for (int s = s_first; s < s_end; ++s) {
+            const ChainStage st = whole ? p.st[1 + 6 * l + s] : p.st[s];      // (uniform: scalar loads of a descriptor no kernel writes)
+            const bool wide = (st.K / KT + TB - 1) / TB > 4;
+            const unsigned epoch = epoch0 + (unsigned)s + 1;      // the tag this stage's results carry; its inputs carry epoch - 1
+            int in_kind = CHAIN_IN_GRANULES;
+            const unsigned long long* gran = p.gran_h;
+            unsigned tag = epoch - 1;
+            if (p.merge_ws && s == p.merge_at) in_kind = CHAIN_IN_MERGE;
+            else if (p.gran_p && s == p.merge_at) {               // (only the workgroups that own a group of this stage need the row)
+                if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged(p, epoch0 + (unsigned)p.cross_at + 1, &s_in[0][0]);
+                in_kind = CHAIN_IN_LDS;
+            }
+            else if (s == 0 && (whole || p.self_part)) { gran = p.gran_c; tag = epoch0; }
+            else if (s == 0) in_kind = CHAIN_IN_PLAIN;
+            if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+            else if (st.ln_g) chain_stage<WB, false, true>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+            else chain_stage<WB, false, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+            if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
+            if (attn && (whole || p.cross_kv) && s == p.cross_at) {
+                chain_cross_stage(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
+                // the NEXT layer's K / V rows set out now: they have the rest of this layer to arrive
+                if (whole && l + 1 < p.n_layers) chain_cross_prefetch(p, p.lio[l + 1].cross_kv, kv_lds, per_split);
+            }
+        }
     }
 }
 
@@ -849,20 +893,42 @@ bool gemv_chain_supports(int C, int w8, int n_cu) {
     return C % KT == 0 && C % 16 == 0 && C <= 1536 && slices_c <= 4 && slices_4c <= 16 && (4 * C / 16 + 1) / 2 <= n_cu && C / 16 <= n_cu;
 }
 
-int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs, int n_wg, hipStream_t stream) {
-    WM_REQUIRE(p.n_stages >= 1 && p.n_stages <= CHAIN_MAX_STAGES, "gemv_chain: %d stages", p.n_stages);
-    WM_REQUIRE(p.x && p.gran_x && p.gran_h && p.err && p.generation && p.st && hs, "gemv_chain: null argument");
+// the caller's per-layer table: 8 entries per launch, by value (a larger argument block is staged through a blit under graph replay)
+struct ChainIoChunk { ChainLayerIo e[8]; };
+__global__ void chain_io_table_kernel(ChainLayerIo* dst, ChainIoChunk c, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = c.e[threadIdx.x];
+}
+int launch_chain_io_table(ChainLayerIo* dst, const ChainLayerIo* host, int n, hipStream_t stream) {
+    for (int i = 0; i < n; i += 8) {
+        ChainIoChunk c{};
+        const int m = n - i < 8 ? n - i : 8;
+        for (int k = 0; k < m; ++k) c.e[k] = host[i + k];
+        hipLaunchKernelGGL(chain_io_table_kernel, dim3(1), dim3(64), 0, stream, dst + i, c, m);
+    }
+    WM_LAUNCH_CHECK(stream, "chain_io_table");
+    return 0;
+}
+
+int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs_all, int n_wg, hipStream_t stream) {
+    const bool whole = p.n_layers > 0;
+    const ChainStage* hs = whole ? hs_all + 1 : hs_all;       // (whole step: the checks look at layer 0's stages; every layer has the same shapes)
+    const int n_stages = whole ? (p.n_layers > 1 ? 6 : 5) : p.n_stages;
+    const bool has_self = whole || p.self_part, has_cross = whole || p.cross_kv;
+    WM_REQUIRE(n_stages >= 1 && n_stages <= CHAIN_MAX_STAGES, "gemv_chain: %d stages", n_stages);
+    WM_REQUIRE(p.x && p.gran_x && p.gran_h && p.err && p.generation && p.st && hs_all, "gemv_chain: null argument");
     WM_REQUIRE(p.launch_id >= 0 && p.launch_id < 128, "gemv_chain: launch_id=%d", p.launch_id);      // (7 bits under the stage index)
+    WM_REQUIRE(!whole || (p.n_layers <= 62 && p.lstat && p.lio && p.gran_s && p.gran_p && p.gran_c && p.gran_q && p.cross_at == 1 && p.merge_at == 2 &&
+                          hs_all[0].ln_g && hs_all[0].mode == 0), "gemv_chain: whole-step launch: bad arguments");
     WM_REQUIRE(p.w8 == 0 || p.w8 == 1 || p.w8 == 4, "gemv_chain: w8=%d", p.w8);
     const int KT = p.w8 == 4 ? 128 : (p.w8 ? 64 : 32);
     int widest = 0;
-    for (int s = 0; s < p.n_stages; ++s) {
+    for (int s = 0; s < n_stages; ++s) {
         const ChainStage& st = hs[s];
         WM_REQUIRE(st.Wt && st.K % KT == 0 && st.K <= CHAIN_MAX_IN && st.n_blocks >= 1, "gemv_chain: stage %d shape", s);
         WM_REQUIRE(st.mode >= 0 && st.mode <= 2 && (st.mode != 0 || p.out32), "gemv_chain: stage %d mode %d", s, st.mode);
         WM_REQUIRE(!st.ln_g || (st.ln_b && st.K <= 1536), "gemv_chain: stage %d LayerNorm needs beta and K <= 1536", s);
         const bool merged_in = (p.merge_ws || p.gran_p) && s == p.merge_at;
-        WM_REQUIRE(s > 0 || st.ln_g || p.in16 || merged_in || p.self_part, "gemv_chain: the first stage needs its input row");
+        WM_REQUIRE(s > 0 || st.ln_g || p.in16 || merged_in || has_self, "gemv_chain: the first stage needs its input row");
         WM_REQUIRE(!merged_in || (p.merge_nsplit >= 1 && p.merge_nsplit <= 16 && p.merge_heads * 64 == st.K && !st.ln_g && st.n_blocks <= n_wg),
                    "gemv_chain: merged input: %d pieces, %d heads for K=%d", p.merge_nsplit, p.merge_heads, st.K);
         WM_REQUIRE(s == 0 || st.ln_g || merged_in || hs[s - 1].mode == 1, "gemv_chain: stage %d reads the hidden row, stage %d must produce it", s, s - 1);
@@ -871,19 +937,19 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs, int n_wg, 
         const int need = slices > 4 ? st.n_blocks : (st.n_blocks + 1) / 2;
         widest = widest > need ? widest : need;
     }
-    WM_REQUIRE(!(p.merge_ws && p.gran_p) && (!(p.merge_ws || p.gran_p) || (p.merge_at >= 0 && p.merge_at < p.n_stages)), "gemv_chain: merge stage %d", p.merge_at);
+    WM_REQUIRE(!(p.merge_ws && p.gran_p) && (!(p.merge_ws || p.gran_p) || (p.merge_at >= 0 && p.merge_at < n_stages)), "gemv_chain: merge stage %d", p.merge_at);
     WM_REQUIRE(!p.merge_ws || p.merge_at == 0, "gemv_chain: partial results in plain memory are the FIRST stage's input");
-    WM_REQUIRE(!p.gran_p || (p.cross_kv && p.merge_at > p.cross_at && p.merge_nsplit == 4 && p.cross_nsplit == 4 && p.merge_heads == p.cross_heads),
+    WM_REQUIRE(!p.gran_p || (has_cross && p.merge_at > p.cross_at && p.merge_nsplit == 4 && p.cross_nsplit == 4 && p.merge_heads == p.cross_heads),
                "gemv_chain: tagged partial results need this launch's cross-attention stage before the merge, 4 pieces");
-    if (p.self_part) {
-        WM_REQUIRE(p.self_cache && p.gran_c && p.self_heads >= 1 && p.self_heads * 64 == hs[0].K && !hs[0].ln_g && !(p.merge_at == 0 && (p.merge_ws || p.gran_p)) &&
-                   (p.self_t_dev || (p.self_T >= 0 && p.self_T < p.self_cap)) && p.self_cap <= 512 && (!p.self_i8 || p.self_kv_scale > 0.f),
+    if (has_self) {
+        WM_REQUIRE((whole || p.self_cache) && p.gran_c && p.self_heads >= 1 && p.self_heads * 64 == hs[0].K && !hs[0].ln_g && !(p.merge_at == 0 && (p.merge_ws || p.gran_p)) &&
+                   (p.self_t_dev || (p.self_T >= 0 && p.self_T < p.self_cap)) && p.self_cap <= 512 && (!p.self_i8 || whole || p.self_kv_scale > 0.f),
                    "gemv_chain: self-attention stage: bad arguments");
-        WM_REQUIRE(n_wg >= p.self_heads + (p.cross_kv ? p.cross_heads * p.cross_nsplit : 0), "gemv_chain: %d workgroups for the attention stages", n_wg);
+        WM_REQUIRE(n_wg >= p.self_heads + (has_cross ? p.cross_heads * p.cross_nsplit : 0), "gemv_chain: %d workgroups for the attention stages", n_wg);
     }
     size_t dyn = 0;
-    if (p.cross_kv) {
-        WM_REQUIRE(p.cross_at >= 0 && p.cross_at < p.n_stages, "gemv_chain: cross-attention behind stage %d", p.cross_at);
+    if (has_cross) {
+        WM_REQUIRE(p.cross_at >= 0 && p.cross_at < n_stages, "gemv_chain: cross-attention behind stage %d", p.cross_at);
         WM_REQUIRE((p.cross_ws || p.gran_p) && p.gran_q && hs[p.cross_at].mode == 0 && p.cross_nsplit > 1 && p.cross_nsplit <= 16 && p.cross_Tk >= 1 &&
                    p.cross_heads * 64 == hs[p.cross_at].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
         const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;

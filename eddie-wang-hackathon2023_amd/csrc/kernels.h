@@ -74,7 +74,7 @@ int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
 // A chain of gemv_small Linears at ONE activation row in one launch (batch 1): stage inputs / outputs between the stages travel
 // as {epoch, value} granules, the first stage reads plain memory, mode-0 results and the residual row go back to plain memory.
 constexpr int CHAIN_MAX_STAGES = 6;
-constexpr int DECODE_CHAIN_DEFAULT = 3;      // 0: off, 1: the Linears chained, 2: + the cross-attention pieces as the first chain's last stage, 3: one launch per layer
+constexpr int DECODE_CHAIN_DEFAULT = 4;      // 0: off, 1: the Linears chained, 2: + the cross-attention pieces as the first chain's last stage, 3: one launch per layer, 4: one per token step
 struct ChainStage {                                           // (an engine keeps its layers' stages in DEVICE memory: a chain's
     const void* Wt; const h16* scale; const h16* bias;         // arguments stay small -- by value they were 330 bytes, and the runtime
     const h16* ln_g; const h16* ln_b;                         // staged such argument blocks with a blit per launch under graph replay)
@@ -82,6 +82,8 @@ struct ChainStage {                                           // (an engine keep
     int mode;                                                 // 0: fp32 sums -> out32   1: gelu -> hidden row   2: residual row += ...
     int pad_;
 };
+struct ChainLayerStatic { const h16* qkv_bias; const h16* cq_bias; float kv_scale; int pad_; };     // per layer, the engine's (device memory)
+struct ChainLayerIo { const void* cross_kv; void* cache; };                                         // per layer, the caller's (in the workspace)
 struct GemvChainParams {
     int n_stages; const ChainStage* st;                       // n_stages consecutive descriptors in device memory
     float* out32;                                             // where a mode-0 stage leaves its sums
@@ -104,12 +106,17 @@ struct GemvChainParams {
     // the launch before left in self_part [3C] -- cache append included (in place) -- its output row on gran_c for stage 0
     const float* self_part; const h16* self_bias; void* self_cache; int self_cap, self_T, self_heads, self_i8; const int32_t* self_t_dev;
     float self_kv_scale; h16* self_out; unsigned long long* gran_c;     // C / 2 entries; self_out: optional plain copy [C]
+    // the whole token step in one launch: n_layers > 0 layers, descriptors st[0] = qkv of layer 0, then 6 per layer (5 for the last);
+    // per-layer pointers from the two tables; qkv sums travel as granules (gran_s, 3 C entries); needs the self- and cross-attention
+    // stages' arguments (heads, pieces, Tk, capacity, T, ...) as for one layer
+    int n_layers; const ChainLayerStatic* lstat; const ChainLayerIo* lio; unsigned long long* gran_s;
     unsigned* err;                                            // set non-zero when a bounded wait gives up
     const unsigned* generation; int launch_id;                // epochs: (*generation << 10) | (launch_id << 3), + stage + 1 (generation: one per decoder call)
 };
 bool gemv_chain_supports(int C, int w8, int n_cu);
 int gemv_chain_err_word(unsigned** out);                      // device address of this device's "a wait was given up" word
-int launch_gemv_chain(const GemvChainParams& p, const ChainStage* host_stages, int n_wg, hipStream_t stream);     // host_stages: the same descriptors, for the argument checks
+int launch_gemv_chain(const GemvChainParams& p, const ChainStage* host_stages, int n_wg, hipStream_t stream);
+int launch_chain_io_table(ChainLayerIo* dst, const ChainLayerIo* host, int n, hipStream_t stream);      // fills the caller's table (small launches, arguments by value)     // host_stages: the same descriptors, for the argument checks
 
 // ---------------------------------------------------------------- gemm_rows.hip
 // The same contract (GemvSmallParams, modes 0-2, optional LayerNorm prologue; ksplit unused) for ANY number of rows: the rows

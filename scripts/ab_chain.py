@@ -14,9 +14,9 @@ import bench
 bench.main()
 """ % (ROOT, os.path.join(ROOT, "eddie-wang-hackathon2023_amd"))
 for r in range(rounds):
-    for on in (0, 1, 2, 3):
+    for on in (0, 1, 2, 3, 4):
         out = subprocess.run([sys.executable, "-c", code, str(on), batch], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
         line = [l for l in out.splitlines() if l.startswith("{")][-1]
         res = json.loads(line)
-        name = ("off", "linears", "linears + cross", "whole layer")[on]
+        name = ("off", "linears", "linears + cross", "whole layer", "whole step")[on]
         print(f"batch {batch} chain {name} round {r}: {res['roofline']['decode_step_ms']} ms per token, {res['value']} tokens/s whole job", flush=True)

@@ -417,7 +417,7 @@ def test_one_row_chain_equals_the_launch_per_linear_path(tmp_path_factory, model
     outs = []
     prev = lib_().wm_set_decode_chain(-1)
     try:
-        for on in (0, 1, 2, 3):                              # off | the Linears chained | + the cross-attention pieces as a chain stage | one launch per layer
+        for on in (0, 1, 2, 3, 4):                           # off | the Linears chained | + the cross-attention pieces as a chain stage | one launch per layer | per token step
             lib_().wm_set_decode_chain(on)
             dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
             dec.detect_language(xa)
