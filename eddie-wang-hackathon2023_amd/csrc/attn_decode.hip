@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
                 for (int i = 0; i < L; ++i) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int e = 0; e < DPL; ++e) acc += qf[i][e] * ks[e];
+                    for (int e = 0; e < DPL; ++e) acc = fmaf(qf[i][e], ks[e], acc);          // (written out: gemv_chain.hip runs a copy of this loop that must round the same way)
                     accs[i] = acc;
                 }
             }
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
                 acc += wave_dpp<0xB1>(acc);                       // lane ^ 1
                 acc += wave_dpp<0x4E>(acc);                       // lane ^ 2
                 if constexpr (LPR == 8) acc += wave_dpp<0x141>(acc);      // the other quad of the 8 (row_half_mirror)
-                const float sc = I8 ? r16(acc * k_scale) : r16(acc);
+                const float sc = I8 ? r16(acc * k_scale) : r16(f32_as_is(acc));
                 if (r < nkeys) {
                     if (sub == 0) s_sc[i][r] = sc;
                     mx[i] = fmaxf(mx[i], sc);
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
             for (int i = 0; i < L; ++i) {
                 const float pr = r < nkeys ? s_sc[i][min(r, nkeys - 1)] : 0.f;
 #pragma unroll
-                for (int e = 0; e < DPL; ++e) o[i][e] += pr * vx[e];
+                for (int e = 0; e < DPL; ++e) o[i][e] = fmaf(pr, vx[e], o[i][e]);
             }
         }
         // pin the accumulators here: pure arithmetic is free to sink below the NEXT prefetch otherwise, which turns the

@@ -112,7 +112,11 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         return;
     }
 
-    // ---- 1. every weight tile of this wave's K slices is requested now, before anything is waited for -------------------
+    // ---- 1. every weight tile of this wave's K slices is requested now, before anything is waited for -- and the epilogue's
+    // per-channel scale and bias with them (requested in the epilogue they were a memory round trip of their own) -------------
+    const int col = nb * 16 + rl;
+    const float sc = (WB != 16 && st.scale) ? (float)CHAIN_GLOBAL(h16, st.scale)[col] : 1.0f;
+    const float bias = (st.mode == 1 || st.mode == 2) && st.bias ? (float)CHAIN_GLOBAL(h16, st.bias)[col] : 0.f;
     u32x4 wreg[NS][TB];
     int t_begin[NS], t_end[NS];
 #pragma unroll
@@ -309,8 +313,6 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     }
 
     // ---- 3. multiply (gemv_small's loop), K slices to LDS scaled, in slice order ------------------------------------------
-    const int col = nb * 16 + rl;
-    const float sc = (WB != 16 && st.scale) ? (float)CHAIN_GLOBAL(h16, st.scale)[col] : 1.0f;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
@@ -367,7 +369,6 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             for (int r = 0; r < 4; ++r) sum[r] += tw[r];
         }
         const float y = sum[0];                               // row 0 (lanes 0-15); the other lanes hold rows that do not exist
-        const float bias = (st.mode == 1 || st.mode == 2) && st.bias ? (float)CHAIN_GLOBAL(h16, st.bias)[col] : 0.f;
         if (st.mode == 0) {
             if (g == 0) {
                 p.out32[col] = y;                             // raw sums for the attention kernel of the next launch
@@ -434,6 +435,7 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
                                                   float* s_sc, float (*s_redc)[2], float (*s_o)[64], float* s_q) {
     constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
     constexpr int STRIDE = 4 * RPI * UNR;
+    constexpr int KB = 3;                          // iterations whose rows are requested together
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_items = p.cross_heads * p.cross_nsplit, item = (int)blockIdx.x - ((int)gridDim.x - n_items);
     const bool has_item = item >= 0;
@@ -485,27 +487,37 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
             const float bs = (float)qb8[e];
             qf[e] = r16(r16(qa + bs) * CHAIN_ATTN_SCALE);
         }
-        // ---- pass 1: scores ------------------------------------------------------------------------------------------------
-        for (int k = 0; k < nb; ++k) {
-            const int r0 = first + k * STRIDE;
+        // ---- pass 1: scores (the rows of three iterations -- all of a <= 384-key piece -- are read from LDS before the first is used:
+        // one LDS round trip instead of twelve dependent ones; per-key arithmetic as ever) ---------------------------------------
+        for (int k0 = 0; k0 < nb; k0 += KB) {
+            half8v hv[KB][UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int r = r0 + u * RPI + rowi;
-                const int rr = min(r, nkeys - 1);
-                const half8v hv = *(const half8v*)(K + (size_t)rr * 128 + sub * 16);
-                float ks[DPL];
+            for (int kk = 0; kk < KB; ++kk)
 #pragma unroll
-                for (int e = 0; e < DPL; ++e) ks[e] = r16((float)hv[e] * CHAIN_ATTN_SCALE);
-                float acc = 0.f;
+                for (int u = 0; u < UNR; ++u) {
+                    const int rr = min(first + (k0 + kk) * STRIDE + u * RPI + rowi, nkeys - 1);
+                    hv[kk][u] = *(const half8v*)(K + (size_t)rr * 128 + sub * 16);
+                }
 #pragma unroll
-                for (int e = 0; e < DPL; ++e) acc += qf[e] * ks[e];
-                acc += wave_dpp<0xB1>(acc);
-                acc += wave_dpp<0x4E>(acc);
-                acc += wave_dpp<0x141>(acc);
-                const float sc = r16(acc);
-                if (r < nkeys) {
-                    if (sub == 0) s_sc[r] = sc;
-                    mx = fmaxf(mx, sc);
+            for (int kk = 0; kk < KB; ++kk) {
+                if (k0 + kk >= nb) break;                                      // wave-uniform
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int r = first + (k0 + kk) * STRIDE + u * RPI + rowi;
+                    float ks[DPL];
+#pragma unroll
+                    for (int e = 0; e < DPL; ++e) ks[e] = r16((float)hv[kk][u][e] * CHAIN_ATTN_SCALE);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int e = 0; e < DPL; ++e) acc = fmaf(qf[e], ks[e], acc);
+                    acc += wave_dpp<0xB1>(acc);
+                    acc += wave_dpp<0x4E>(acc);
+                    acc += wave_dpp<0x141>(acc);
+                    const float sc = r16(f32_as_is(acc));
+                    if (r < nkeys) {
+                        if (sub == 0) s_sc[r] = sc;
+                        mx = fmaxf(mx, sc);
+                    }
                 }
             }
         }
@@ -532,18 +544,28 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
         float o[DPL];
 #pragma unroll
         for (int e = 0; e < DPL; ++e) o[e] = 0.f;
-        for (int k = 0; k < nb; ++k) {
-            const int r0 = first + k * STRIDE;
+        for (int k0 = 0; k0 < nb; k0 += KB) {                              // (rows and weights of three iterations requested together, added in the old order)
+            half8v hv[KB][UNR];
+            float pr[KB][UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int r = r0 + u * RPI + rowi;
-                const half8v hv = *(const half8v*)(V + (size_t)min(r, nkeys - 1) * 128 + sub * 16);
-                const float pr = r < nkeys ? s_sc[min(r, nkeys - 1)] : 0.f;
+            for (int kk = 0; kk < KB; ++kk)
 #pragma unroll
-                for (int e = 0; e < DPL; ++e) o[e] += pr * (float)hv[e];
+                for (int u = 0; u < UNR; ++u) {
+                    const int r = first + (k0 + kk) * STRIDE + u * RPI + rowi;
+                    hv[kk][u] = *(const half8v*)(V + (size_t)min(r, nkeys - 1) * 128 + sub * 16);
+                    pr[kk][u] = r < nkeys ? s_sc[min(r, nkeys - 1)] : 0.f;
+                }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                if (k0 + kk >= nb) break;                                      // wave-uniform
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                    for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr[kk][u], (float)hv[kk][u][e], o[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) asm volatile("" : "+v"(o[e]) : : "memory");
             }
-#pragma unroll
-            for (int e = 0; e < DPL; ++e) asm volatile("" : "+v"(o[e]) : : "memory");
         }
 #pragma unroll
         for (int e = 0; e < DPL; ++e) {
@@ -652,6 +674,9 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     const float inv_t = 1.0f / la.self_kv_scale;
     if (wid == 0) {                                   // this call's q, k, v of the head (lane = dim): one slab, bias, fp16; the cache append
         float q = 0.f, k = 0.f, v = 0.f;
+        const float bq = la.self_bias ? (float)la.self_bias[h * 64 + lane] : 0.f;              // (requested ahead of the wait for the sums)
+        const float bk = la.self_bias ? (float)la.self_bias[C + h * 64 + lane] : 0.f;
+        const float bv = la.self_bias ? (float)la.self_bias[2 * C + h * 64 + lane] : 0.f;
         if (p.gran_s) {                               // the sums the qkv stage of THIS launch has just published (the whole step in one launch)
             int first[3] = {h * 64 + 2 * min(lane, 31), C + h * 64 + 2 * min(lane, 31), 2 * C + h * 64 + 2 * min(lane, 31)};
             u32x4 val[3];
@@ -671,9 +696,9 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
             const float* row = p.self_part + h * 64 + lane;
             q += row[0]; k += row[C]; v += row[2 * C];
         }
-        q = r16(q + (la.self_bias ? (float)la.self_bias[h * 64 + lane] : 0.f));
-        k = r16(k + (la.self_bias ? (float)la.self_bias[C + h * 64 + lane] : 0.f));
-        v = r16(v + (la.self_bias ? (float)la.self_bias[2 * C + h * 64 + lane] : 0.f));
+        q = r16(q + bq);
+        k = r16(k + bk);
+        v = r16(v + bv);
         s_knew[lane] = (h16)k;
         s_vnew[lane] = (h16)v;
         const size_t off_k = ((size_t)(0 * H + h) * p.self_cap + T) * 64 + lane;

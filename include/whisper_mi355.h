@@ -268,20 +268,25 @@ int wm_set_self_attn_waves(int waves);
  * default.  Returns the previous value.  Both forms add an output element's products in the same order and share the
  * epilogue arithmetic: the results are bit-identical, a clip's encoder output does not depend on the batch it is in.     */
 int wm_set_gemm_small_tiles(int tiles);
-/* Batch 1 (one activation row: the reference's own operating point, W/run.py:43-46): the fused Linears of a decoder layer run as
- * two CHAINS inside one launch each -- [out + residual -> LayerNorm + cross-attention q] and [out + residual -> LayerNorm + mlp1 +
- * GELU -> mlp2 + residual -> LayerNorm + qkv of the next layer] (csrc/gemv_chain.hip: the stages hand the activation row over
- * as tagged 8-byte granules, no fences, no barriers; weights of the next stage are requested before its input is waited for); the
- * merge of the cross-attention's key-range pieces is the second chain's prologue.  Mode 2 also runs the cross-attention pieces
- * themselves as the first chain's last stage (their K / V rows are put into LDS by DMA while the chain's Linears run): 3 launches
- * per layer -- self-attention, chain, chain -- instead of 9.  Same arithmetic as the launch-per-Linear form, bit for bit.
- * 0 = off, 1 = the Linears chained, 2 = + the cross-attention stage (default), < 0 = default; returns the previous value.
- * Captured graphs keep the form they were captured with.
+/* Batch 1 (one activation row: the reference's own operating point, W/run.py:43-46): the decoder's kernels run as STAGES of one
+ * launch (csrc/gemv_chain.hip: the stages hand the activation row over as tagged 8-byte granules -- no fences, no flags, no
+ * barriers between workgroups; a stage's weights are requested before its input is waited for).  Same arithmetic as one launch
+ * per kernel, bit for bit.  Modes:
+ *   0  off: a launch per fused Linear and per attention kernel (9 per layer)
+ *   1  the fused Linears of a layer as two chains -- [out + residual -> LayerNorm + cross-attention q] and [merge of the
+ *      cross-attention's key-range pieces + out + residual -> LayerNorm + mlp1 + GELU -> mlp2 + residual -> LayerNorm + qkv of the
+ *      next layer] -- 4 launches per layer
+ *   2  + the cross-attention pieces as the first chain's last stage (K / V rows by DMA into LDS while the Linears run): 3 per layer
+ *   3  + the self-attention (cache append included) as the first stage, the pieces handed to the merge as granules: 1 per layer
+ *   4  the launch walks over the layers itself: ONE launch per token step besides the embedding and the vocabulary
+ *      projection (default).  The per-layer cross K/V and cache pointers reach it through a table in the workspace.
+ * Modes 3 and 4 need the in-place cache (past[i] == present[i], equal capacities <= 512) and fall back to mode 2 otherwise.
+ * < 0 = default; returns the previous value.  Captured graphs keep the form they were captured with.
  * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a (bounded) wait since the last call -- the results of
  * that step are not valid (a chain needs its <= 256 workgroups resident together; the word is cleared by the call; it
  * synchronises with the device).
- * The chain keeps a call counter and its tagged granules in the decoder WORKSPACE: zero the workspace once before its first
- * use and leave it alone between calls (session.py allocates it zeroed).                                                     */
+ * The chain keeps a call counter, its tagged granules and the pointer table in the decoder WORKSPACE: zero the workspace once
+ * before its first use and leave it alone between calls (session.py allocates it zeroed).                                     */
 int wm_set_decode_chain(int on);
 int wm_decode_chain_error(int* out);
 /* Exact V-row skipping in the decode cross-attention (fp16 K/V, single-pass form): a key whose softmax probability rounds to
