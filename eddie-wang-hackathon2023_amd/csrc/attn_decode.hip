@@ -969,7 +969,7 @@ int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t e
         default: hipLaunchKernelGGL(attn_cross_kernel<4>, grid, dim3(256), 0, stream, p); break;
     }
     WM_LAUNCH_CHECK(stream, "attn_cross");
-    if (p.nsplit > 1 && !p.no_combine) {
+    if (p.nsplit > 1) {
         hipLaunchKernelGGL(attn_cross_combine_kernel, dim3(p.H, p.B, p.L), dim3(64), 0, stream, p);
         WM_LAUNCH_CHECK(stream, "attn_cross_combine");
     }

@@ -766,34 +766,43 @@ struct GroupStep {
                 g_chain_cus[slot].store(n_cu, std::memory_order_relaxed);
                 g_chain_err_dev[slot].store(errw, std::memory_order_relaxed);
             }
-            if (gemv_chain_supports(C, e->dec[0].qkv.wcode, n_cu)) { chain = true; chain_wgs = n_cu > 256 ? 256 : n_cu; chain_err = errw; }
+            // one-row groups run a decoder layer (or the whole step) as one launch -- with the in-place cache (past[i] == present[i]), four
+            // key-range pieces, fp16 cross K/V, the four-wave self-attention form; anything else takes the launch-per-kernel path
+            chain_wgs = n_cu > 256 ? 256 : n_cu; chain_err = errw;
+            bool ok = gemv_chain_supports(C, e->dec[0].qkv.wcode, n_cu) && w.nsplit == 4 && !e->i8cross() && self_attn_waves(M) == 4 &&
+                      io->present_capacity <= 512 && H + H * w.nsplit <= chain_wgs;
+            for (int i = 0; ok && i < e->dims.n_text_layer; ++i)
+                ok = io->present[i] && io->cross[i] &&
+                     (T == 0 ? io->n_past_dev == nullptr : (io->past[i] == io->present[i] && io->past_capacity == io->present_capacity));
+            chain = ok;
         }
         return 0;
     }
 
-    // a chain of layer i's Linears in one launch (one row): `first` .. `first + n - 1` of the layer's six stage descriptors.
-    // launch_id: unique per launch of a step (the granules' epochs)
-    int run_chain(int i, int first, int n, const h16* in16, int launch_id, hipStream_t s, bool merge = false, bool cross_stage = false, bool whole_layer = false) {
+    // the arguments every chain launch shares
+    void chain_common(GemvChainParams& p) {
+        const wm_dims& d = e->dims;
+        p.cross_Tk = d.n_audio_ctx; p.cross_heads = H; p.cross_nsplit = w.nsplit; p.gran_q = w.gran_q; p.cross_at = 1;
+        p.gran_p = w.gran_p; p.merge_at = 2; p.merge_nsplit = w.nsplit; p.merge_heads = H;
+        p.self_cap = io->present_capacity; p.self_T = T; p.self_t_dev = io->n_past_dev; p.self_heads = H; p.self_i8 = e->i8kv() ? 1 : 0;
+        p.gran_c = w.gran_c;
+        p.out32 = w.part; p.w8 = e->dec[0].out.wcode; p.gelu_kind = e->gelu();
+        p.x = w.x; p.gran_x = w.gran_x; p.gran_h = w.gran_h; p.err = chain_err;
+        p.generation = w.generation;
+    }
+
+    // decoder layer i of a one-row group as ONE launch (gemv_chain.hip): self-attention, out, cq, cross-attention, merge + cout, mlp1,
+    // mlp2, the qkv sums of the next layer
+    int run_layer(int i, hipStream_t s) {
+        const DecLayer& Lr = e->dec[i];
+        const bool more = i + 1 < e->dims.n_text_layer;
         GemvChainParams p{};
-        if (merge) { p.merge_ws = w.cross_ws; p.merge_nsplit = w.nsplit; p.merge_heads = H; p.merge_at = 0; }
-        if (cross_stage) {           // this layer's cross-attention pieces as the chain's last stage
-            p.cross_kv = (const h16*)io->cross[i]; p.cross_Tk = e->dims.n_audio_ctx; p.cross_heads = H; p.cross_nsplit = w.nsplit;
-            p.cross_ws = w.cross_ws; p.cross_qbias = e->dec[i].cq.b; p.gran_q = w.gran_q; p.cross_at = n - 1;
-        }
-        if (whole_layer) {           // the whole layer: self-attention first, the cross-attention behind stage 1 (cq), its pieces merged by stage 2 (cout)
-            p.cross_at = 1; p.cross_ws = nullptr; p.gran_p = w.gran_p; p.merge_at = 2; p.merge_nsplit = w.nsplit; p.merge_heads = H;
-            const DecLayer& Lr = e->dec[i];
-            p.self_part = w.part; p.self_bias = Lr.qkv.b; p.self_cache = io->present[i]; p.self_cap = io->present_capacity;
-            p.self_T = T; p.self_t_dev = io->n_past_dev; p.self_heads = H; p.self_i8 = e->i8kv() ? 1 : 0; p.self_kv_scale = Lr.kv_scale;
-            p.self_out = nullptr; p.gran_c = w.gran_c;
-        }
-        p.n_stages = n; p.st = e->chain_dev + 1 + (size_t)6 * i + first;
-        p.out32 = w.part;
-        p.w8 = e->dec[i].out.wcode; p.gelu_kind = e->gelu();
-        p.in16 = in16; p.x = w.x; p.hid_out = nullptr;
-        p.gran_x = w.gran_x; p.gran_h = w.gran_h; p.err = chain_err;
-        p.generation = w.generation; p.launch_id = launch_id;
-        return launch_gemv_chain(p, &e->chain_host[1 + (size_t)6 * i + first], chain_wgs, s);
+        chain_common(p);
+        p.n_stages = more ? 6 : 5; p.st = e->chain_dev + 1 + (size_t)6 * i;
+        p.cross_kv = (const h16*)io->cross[i]; p.cross_qbias = Lr.cq.b;
+        p.self_part = w.part; p.self_bias = Lr.qkv.b; p.self_cache = io->present[i]; p.self_kv_scale = Lr.kv_scale;
+        p.launch_id = i;
+        return launch_gemv_chain(p, &e->chain_host[1 + (size_t)6 * i], chain_wgs, s);
     }
 
     int finish(const Lin& l, int ks, int mode, const h16* g, const h16* bta, h16* out, int ldo, int N, hipStream_t s) {
@@ -816,23 +825,15 @@ struct GroupStep {
     }
 
     // self-attention block and the cross-attention query projection of layer i
-    // The whole token step of a one-row group as ONE launch (mode 4): [LayerNorm + qkv of layer 0], then per layer self-attention,
-    // out, cq, cross-attention, merge + cout, mlp1, mlp2, qkv of the next layer -- gemv_chain.hip walks over the layers itself; the
-    // per-layer cross K/V and cache pointers reach it through a table in the workspace, rewritten (small launches on this stream)
-    // only when the caller's pointers differ from the ones last written there.  Same conditions as the one-launch-per-layer form,
-    // for every layer: in-place cache, four key-range pieces, fp16 cross K/V.
+    // The whole token step of a one-row group as ONE launch: [LayerNorm + qkv of layer 0], then per layer self-attention, out, cq,
+    // cross-attention, merge + cout, mlp1, mlp2, qkv of the next layer -- gemv_chain.hip walks over the layers itself; the per-layer
+    // cross K/V and cache pointers reach it through a table in the workspace, rewritten (small launches on this stream) only when
+    // the caller's pointers differ from the ones last written there.
     bool step_done = false;
     int whole_step(hipStream_t s) {
-        const wm_dims& d = e->dims;
-        const int n = d.n_text_layer;
-        if (!(chain && g_decode_chain.load(std::memory_order_relaxed) >= 4 && w.nsplit == 4 && !e->i8cross() && self_attn_waves(M) == 4 &&
-              io->present_capacity <= 512 && H + H * w.nsplit <= chain_wgs && n <= 62 && e->chain_lstat)) return 0;
+        const int n = e->dims.n_text_layer;
         std::vector<ChainLayerIo> tab((size_t)n);
-        for (int i = 0; i < n; ++i) {
-            if (!io->present[i] || !io->cross[i]) return 0;
-            if (T == 0 ? io->n_past_dev != nullptr : !(io->past[i] == io->present[i] && io->past_capacity == io->present_capacity)) return 0;
-            tab[i] = ChainLayerIo{io->cross[i], io->present[i]};
-        }
+        for (int i = 0; i < n; ++i) tab[i] = ChainLayerIo{io->cross[i], io->present[i]};
         {
             std::lock_guard<std::mutex> lk(e->chain_io_mu);
             std::vector<ChainLayerIo>& seen = e->chain_io_seen[w.layer_io];
@@ -843,15 +844,9 @@ struct GroupStep {
             }
         }
         GemvChainParams p{};
+        chain_common(p);
         p.n_layers = n; p.lstat = e->chain_lstat; p.lio = w.layer_io; p.gran_s = w.gran_s;
-        p.st = e->chain_dev; p.n_stages = 0;
-        p.cross_Tk = d.n_audio_ctx; p.cross_heads = H; p.cross_nsplit = w.nsplit; p.gran_q = w.gran_q; p.cross_at = 1;
-        p.gran_p = w.gran_p; p.merge_at = 2; p.merge_nsplit = w.nsplit; p.merge_heads = H;
-        p.self_cap = io->present_capacity; p.self_T = T; p.self_t_dev = io->n_past_dev; p.self_heads = H; p.self_i8 = e->i8kv() ? 1 : 0;
-        p.gran_c = w.gran_c;
-        p.out32 = w.part; p.w8 = e->dec[0].out.wcode; p.gelu_kind = e->gelu();
-        p.x = w.x; p.gran_x = w.gran_x; p.gran_h = w.gran_h; p.err = chain_err;
-        p.generation = w.generation; p.launch_id = 0;
+        p.st = e->chain_dev; p.n_stages = 0; p.launch_id = 0;
         if (launch_gemv_chain(p, e->chain_host.data(), chain_wgs, s)) return 2;
         step_done = true;
         return 0;
@@ -860,7 +855,11 @@ struct GroupStep {
     int pre_cross(int i, hipStream_t s) {
         const DecLayer& Lr = e->dec[i];
         int ks = 0;
-        if (i == 0) { step_done = false; if (int rc = whole_step(s)) return rc; }
+        if (i == 0) {
+            step_done = false;
+            if (chain && g_decode_chain.load(std::memory_order_relaxed) >= 2 && e->dims.n_text_layer <= 62 && e->chain_lstat)
+                if (int rc = whole_step(s)) return rc;
+        }
         if (step_done) return 0;
         mark(i, 0, s);
         if (small) {
@@ -886,32 +885,15 @@ struct GroupStep {
         p.t_dev = io->n_past_dev;
         p.live = io->live_rows;
         p.waves = self_attn_waves(M);
-        // One launch for the WHOLE layer (mode 3): the self-attention as the chain's first stage (the four-wave form's arithmetic: the
-        // form one-row groups take anyway), the cross-attention behind the q projection, its pieces merged -- as tagged granules, inside
-        // the launch -- by the cross-attention output projection.  In-place cache only (past == present), four key-range pieces.
         layer_done = false;
-        if (chain && g_decode_chain.load(std::memory_order_relaxed) >= 3 && w.nsplit == 4 && !e->i8cross() && p.waves == 4 &&
-            p.present_cap <= 512 && (T == 0 ? !io->n_past_dev : (p.past == p.present && p.past_cap == p.present_cap)) &&
-            H + H * w.nsplit <= chain_wgs) {
-            WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
-            const bool more = i + 1 < e->dims.n_text_layer;
-            chain_cross = true; layer_done = true;
-            if (run_chain(i, 0, more ? 6 : 5, nullptr, i, s, false, true, true)) return 2;
+        if (chain) {                   // the whole layer in one launch (a live-row list is not consulted: a one-row group is stepped while its
+            layer_done = true;         // row decodes; the steps between the row's EOT and the host's next poll compute values nobody reads)
+            if (run_layer(i, s)) return 2;
             mark(i, 12, s);
             return 0;
         }
         if (launch_attn_self(p, s)) return 2;
         mark(i, 2, s);
-        if (chain) {                                   // [x += out(ctx)] -> [LN + q sums -> w.part] in one launch
-            WM_REQUIRE(io->cross[i], "wm_decoder_step: cross[%d] is null", i);
-            // (a live-row list is not consulted: a one-row group is stepped while its row decodes; the steps between the row's EOT and
-            // the host's next poll compute values nobody reads)
-            chain_cross = w.nsplit > 1 && !e->i8cross() && g_decode_chain.load(std::memory_order_relaxed) >= 2;
-            if (run_chain(i, 0, 2, w.ctx, 2 * i, s, false, chain_cross)) return 2;
-            mark(i, 5, s);
-            cq_ks = 1;
-            return 0;
-        }
         if (fused()) {
             if (gemv(Lr.out, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;    // x += out(ctx)
             mark(i, 3, s);
@@ -929,12 +911,11 @@ struct GroupStep {
         return 0;
     }
     int cq_ks = 0;
-    bool chain_cross = false;                    // the chain behind the self-attention ran this layer's cross-attention pieces too
-    bool layer_done = false;                     // ... and everything behind them (mode 3: one launch per layer)
+    bool layer_done = false;                     // this layer ran as one chain launch (cross() and post_cross() have nothing left to do)
 
     // the HBM-bound kernel: K and V of every utterance of the group, once
     int cross(int i, hipStream_t s) {
-        if (step_done || (chain && chain_cross)) return 0;           // done by the chain behind the self-attention
+        if (step_done || layer_done) return 0;           // done by the chain launch
         if (!prof->timeline) return cross_launch(i, s);
         hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, prof->timeline, prof->timeline_cap, (long long)(uintptr_t)io->logits, (long long)(2 * i));
         const int rc = cross_launch(i, s);
@@ -954,7 +935,6 @@ struct GroupStep {
         p.out = w.ctx; p.ldo = C; p.nsplit = w.nsplit; p.ws = w.cross_ws;
         p.live = io->live_rows;
         p.skip_zero_rows = g_cross_v_skip.load(std::memory_order_relaxed);
-        p.no_combine = chain && w.nsplit > 1;          // the chain behind this launch merges the pieces in its first stage
         const int slot = (L == 1) ? prof_slot(*prof, i, s) : -1;
         if (launch_attn_cross(p, s, slot >= 0 ? prof->start[slot] : nullptr, slot >= 0 ? prof->stop[slot] : nullptr)) return 2;
         return 0;
@@ -966,13 +946,7 @@ struct GroupStep {
         const wm_dims& d = e->dims;
         int ks = 0;
         mark(i, 6, s);
-        if (step_done || (chain && layer_done)) return 0;
-        if (chain) {             // [x += cout(ctx)] -> [LN + mlp1 + GELU] -> [x += mlp2] -> [LN + qkv sums of the next layer] in one launch
-            const bool more = i + 1 < d.n_text_layer;
-            const int rc = run_chain(i, 2, more ? 4 : 3, w.ctx, 2 * i + 1, s, w.nsplit > 1);
-            mark(i, 12, s);
-            return rc;
-        }
+        if (step_done || layer_done) return 0;
         if (fused()) {
             if (gemv(Lr.cout, w.ctx, C, 2, nullptr, nullptr, nullptr, 0, s)) return 2;
             mark(i, 7, s);
@@ -1302,7 +1276,7 @@ int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void
 
 int wm_set_decode_chain(int on) {
     const int prev = g_decode_chain.load(std::memory_order_relaxed);
-    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on > 4 ? 4 : on), std::memory_order_relaxed);
+    g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on > 2 ? 2 : on), std::memory_order_relaxed);
     return prev;
 }
 

@@ -80,10 +80,8 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
 // residual-stream row in the prologue.
 // Where a stage without LayerNorm takes its input row from (wave-uniform):
 enum ChainIn : int {
-    CHAIN_IN_PLAIN = 0,        // p.in16, plain memory: left by the launch before this one
-    CHAIN_IN_MERGE = 1,        // the cross-attention's partial results in plain memory (p.merge_ws), merged by the stage's own slots
-    CHAIN_IN_LDS = 2,          // the row is in s_in[0] already (chain_merge_tagged has put it there)
-    CHAIN_IN_GRANULES = 3      // an fp16 row published as granules in this launch: `gran`, tagged `tag`
+    CHAIN_IN_LDS = 0,          // the row is in s_in[0] already (chain_merge_tagged has put it there)
+    CHAIN_IN_GRANULES = 1      // an fp16 row published as granules in this launch: `gran`, tagged `tag`
 };
 template <int WB, bool WIDE, bool LN>
 __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const ChainStage& st, int s, unsigned epoch, bool& own_valid,
@@ -106,7 +104,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     // an idle slot (no group of this stage falls to it) only keeps the workgroup's barriers company: it touches no memory, so that
     // waves which carry LDS-DMA requests for a later stage (the cross-attention's K / V rows) are not made to wait for them here
     if (!has_group) {
-        const int nbar = (LN ? 3 : 2) + ((!LN && in_kind == CHAIN_IN_MERGE) ? 1 : 0);
+        const int nbar = LN ? 3 : 2;
         for (int b = 0; b < nbar; ++b) __syncthreads();
         if (st.mode == 2) own_valid = true;
         return;
@@ -202,61 +200,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 #pragma unroll
             for (int m = 0; m < NM; ++m) a[0][i][m] = *(const half8v*)(arow + m * 8);
         }
-    } else if (in_kind == CHAIN_IN_MERGE) {
-        // The launch before this one was the cross-attention over key-range pieces: its partial softmaxes (max, sum, unnormalised
-        // output per piece) are merged HERE instead of by a merge launch of their own -- attn_cross_combine_kernel's arithmetic, a
-        // wave per head (lane = dim), the heads dealt over the workgroup's waves; the merged row goes to LDS.  Every workgroup
-        // repeats the merge (21 KB of L2 reads at large-v2, all in flight at once) and the layer loses a launch.
-        // The partials of ALL of a wave's heads are requested before the first is used (one memory round trip for the prologue, not one
-        // per head: 4.1 -> about 1 us at large-v2, where a wave has five heads): five heads per pass with <= 4 pieces -- the only
-        // count the engine uses below 160 (utterance, head) pairs -- one head per pass otherwise.
-        const int nsp = p.merge_nsplit;
-        auto merge_heads = [&](auto nq_tag, auto mh_tag) {
-            constexpr int NQ = decltype(nq_tag)::value, MH = decltype(mh_tag)::value;
-            for (int h0 = wslot; h0 < p.merge_heads; h0 += 4 * MH) {      // (the slot's four waves; an idle slot only joins the barrier)
-                float ms[MH], ls[MH], ov[MH][NQ];
-#pragma unroll
-                for (int u = 0; u < MH; ++u) {
-                    const float* w = p.merge_ws + (size_t)min(h0 + 4 * u, p.merge_heads - 1) * nsp * 66;
-                    ms[u] = w[min(lane, nsp - 1) * 66]; ls[u] = w[min(lane, nsp - 1) * 66 + 1];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) ov[u][q] = w[min(q, nsp - 1) * 66 + 2 + lane];
-                }
-#pragma unroll
-                for (int u = 0; u < MH; ++u) {
-                    const int h = h0 + 4 * u;
-                    if (h >= p.merge_heads) break;                    // wave-uniform
-                    float m_s = ms[u], l_s = ls[u];
-                    if (lane >= nsp) { m_s = -INFINITY; l_s = 0.f; }
-                    const float m = wave_max_nomfma(m_s);
-                    const float f = lane < nsp ? __expf(m_s - m) : 0.f;
-                    const float lf = l_s * f;
-                    float den = 0.f, num = 0.f;
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        if (q < nsp) {                                // wave-uniform
-                            den += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), q));
-                            num += mul_rn(ov[u][q], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), q)));
-                        }
-                    }
-                    s_in[slot][h * 64 + lane] = (h16)(num / den);
-                }
-            }
-        };
-        if (nsp <= 4) merge_heads(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
-        else merge_heads(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int t_last = max(t_end[j] - 1, t_begin[j]);
-#pragma unroll
-            for (int i = 0; i < TB; ++i) {
-                const h16* arow = &s_in[slot][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
-#pragma unroll
-                for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
-            }
-        }
-    } else if (in_kind == CHAIN_IN_LDS) {
+    } else if (!WIDE && in_kind == CHAIN_IN_LDS) {
         // the merged attention row is in s_in[0] (chain_merge_tagged, all eight waves, ended by a barrier)
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -264,18 +208,6 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 #pragma unroll
             for (int i = 0; i < TB; ++i) {
                 const h16* arow = &s_in[0][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
-#pragma unroll
-                for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
-            }
-        }
-    } else if (in_kind == CHAIN_IN_PLAIN) {
-        // the input row left by the launch before this one (attention context): fragments straight from memory, as gemv_small
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int t_last = max(min(kt_total, t_begin[j] + tps) - 1, 0);
-#pragma unroll
-            for (int i = 0; i < TB; ++i) {
-                const h16* arow = p.in16 + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
 #pragma unroll
                 for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
             }
@@ -387,7 +319,6 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
                 out = (h16)r16((float)xo + y16);
                 if (g == 0) { s_own[slot][rl] = out; p.x[col] = out; }
             }
-            if (st.mode == 1 && p.hid_out && g == 0) p.hid_out[col] = out;
             // two channels per granule: the even lane stores {epoch, own | neighbour << 16}
             const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, out);
             const unsigned nb_bits = __shfl_xor(bits, 1);
@@ -408,6 +339,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 // order, only the rows come from LDS, where waves 4-7 put them by DMA at the START of the launch (K and V do not depend on the
 // activations: their 96 KB fly while the chain's Linears run) instead of from memory through a register pipeline.
 constexpr int CHAIN_CROSS_KEYS = 1536;
+constexpr size_t CHAIN_DYN_LDS = 108 * 1024;      // K and V rows of a piece (beside ~ 49 KB of static LDS, of 160)
 // what the attention stages take per LAYER (kernel arguments for a one-layer launch, the two tables in a whole-step launch)
 struct ChainLayerArgs { const h16* cross_kv; const h16* cross_qbias; void* self_cache; const h16* self_bias; float self_kv_scale; };
 constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
@@ -444,8 +376,6 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     const int sub = lane % LPR, rowi = lane / LPR;
     const int first = (wid & 3) * (RPI * UNR);
     const bool worker = wid < 4 && has_item && nkeys > 0;
-    float* w_out = p.cross_ws + (size_t)(h * p.cross_nsplit + sp) * 66;
-
     half8v qb8 = half8v{0, 0, 0, 0, 0, 0, 0, 0};                              // the lane's 8 q-bias values: requested now, not behind the wait for q
     if (worker && la.cross_qbias) qb8 = *(const half8v*)(la.cross_qbias + h * 64 + sub * DPL);
     if (wid >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's K / V pieces have landed
@@ -460,13 +390,11 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
         }
     }
     __syncthreads();                                                           // (A) rows and q sums are in LDS
-    // the piece's partial result (max, sum, o[64]): plain memory for the NEXT launch to merge, or -- when the merge is a later stage
-    // of this launch -- tagged granules, [head][66][4 pieces] so that a consumer lane finds the four pieces of a value side by side
+    // the piece's partial result (max, sum, o[64]) as tagged granules, [head][66][4 pieces]: a lane of the merge finds the four
+    // pieces of a value side by side
     auto put = [&](int r, float v) {
-        if (p.gran_p)
-            __hip_atomic_store((chain_gu64*)(p.gran_p + ((size_t)h * 66 + r) * 4 + sp), ((unsigned long long)epoch_q << 32) | __builtin_bit_cast(unsigned, v),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else w_out[r] = v;
+        __hip_atomic_store((chain_gu64*)(p.gran_p + ((size_t)h * 66 + r) * 4 + sp), ((unsigned long long)epoch_q << 32) | __builtin_bit_cast(unsigned, v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if (has_item && nkeys == 0) {                                              // an empty piece: the neutral element (attn_cross_kernel)
         if (tid < 66) put(tid, (tid == 0) ? -INFINITY : 0.f);
@@ -640,7 +568,7 @@ __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, uns
 // P.V by wave-wide 16-byte loads of whole V rows, partial sums added in (wave, row, block) order) -- bit for bit.  The head's 64
 // outputs are published as granules (p.gran_c, tagged with the launch's epoch) for the out projection, this launch's next stage.
 template <bool I8>
-__device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const ChainLayerArgs& la, unsigned epoch0, unsigned tag_s, int h, float* s_p, h16 (*s_new)[64],
+__device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const ChainLayerArgs& la, int T, unsigned epoch0, unsigned tag_s, int h, float* s_p, h16 (*s_new)[64],
                                                  float (*s_r2)[4], float* s_o_flat) {
     constexpr float SCALE = 0.35355339059327373f;     // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
     constexpr int ES = I8 ? 1 : 2;
@@ -654,7 +582,6 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool worker = wid < NW;
     h16* s_q = s_new[0]; h16* s_knew = s_new[1]; h16* s_vnew = s_new[2];
-    const int T = p.self_t_dev ? *p.self_t_dev : p.self_T;
     const int H = p.self_heads, C = H * 64;
     const unsigned char* pastK = (const unsigned char*)la.self_cache + ((size_t)(0 * H + h) * p.self_cap * 64) * ES;
     const unsigned char* pastV = (const unsigned char*)la.self_cache + ((size_t)(1 * H + h) * p.self_cap * 64) * ES;
@@ -820,7 +747,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     __syncthreads();
 }
 
-template <int WB>
+template <int WB, bool I8KV>
 __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     __shared__ __attribute__((aligned(16))) float s_red[16][64][4];
     __shared__ __attribute__((aligned(16))) h16 s_in[2][CHAIN_MAX_IN + 8];
@@ -840,25 +767,25 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     // descriptors are [qkv of layer 0] + 6 per layer, and "layer -1" is that first projection alone (its sums go out as granules,
     // as every later qkv projection's do, for the self-attention stage behind it).
     const bool whole = p.n_layers > 0;
+    const int T_now = p.self_t_dev ? *p.self_t_dev : p.self_T;      // cached tokens: one (scalar) load per launch
     ChainLayerArgs la{p.cross_kv, p.cross_qbias, p.self_cache, p.self_bias, p.self_kv_scale};
-    const int per_split = (p.cross_kv || whole) ? ((((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7) : 0;
+    const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
     // Who does what besides the Linears.  The cross-attention's (head, piece) items go to the LAST workgroups of the launch and the
     // self-attention's heads to the ones before them: the first workgroups own the output groups of every n_state-wide Linear (and
     // both slots of the widest), the last ones idle through most stages -- and the four upper waves of a workgroup that carries
     // K / V rows in flight must not meet a stage's "everything of mine has landed" wait before those rows are due.
-    if (whole) chain_cross_prefetch(p, p.lio[0].cross_kv, kv_lds, per_split);
-    else if (p.cross_kv) chain_cross_prefetch(p, p.cross_kv, kv_lds, per_split);
+    chain_cross_prefetch(p, whole ? p.lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
     bool own_valid = false, x_in_granules = false;
+    ChainLayerStatic ls_next{}; ChainLayerIo li_next{};
     for (int l = whole ? -1 : 0; l < (whole ? p.n_layers : 1); ++l) {
         const unsigned epoch0 = (gen << 10) | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);
-        if (whole && l >= 0) {
-            const ChainLayerStatic ls = p.lstat[l];
-            const ChainLayerIo li = p.lio[l];
-            la.cross_kv = (const h16*)li.cross_kv; la.cross_qbias = ls.cq_bias;
-            la.self_cache = li.cache; la.self_bias = ls.qkv_bias; la.self_kv_scale = ls.kv_scale;
+        if (whole && l >= 0) {                        // (the entries were requested a layer ago: scalar loads, nothing waits for them here)
+            la.cross_kv = (const h16*)li_next.cross_kv; la.cross_qbias = ls_next.cq_bias;
+            la.self_cache = li_next.cache; la.self_bias = ls_next.qkv_bias; la.self_kv_scale = ls_next.kv_scale;
         }
-        if ((whole && l >= 0) || (!whole && p.self_part)) {
-            const int n_items = (whole || p.cross_kv) ? p.cross_heads * p.cross_nsplit : 0;
+        if (whole && l + 1 < p.n_layers) { ls_next = p.lstat[l + 1]; li_next = p.lio[l + 1]; }
+        if (l >= 0) {
+            const int n_items = p.cross_heads * p.cross_nsplit;
             const int base = max((int)gridDim.x - n_items - p.self_heads, 0);
             const int h = (int)blockIdx.x - base;
             if (h >= 0 && h < p.self_heads) {             // (workgroup-uniform) LDS: the Linears' buffers, not in use now
@@ -867,13 +794,11 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
                 float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
                 float* s_o_flat = (float*)&s_in[0][0];
                 const unsigned tag_s = ((gen << 10) | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
-                if (p.self_i8) chain_self_stage<true>(p, la, epoch0, tag_s, h, s_p, s_new, s_r2, s_o_flat);
-                else chain_self_stage<false>(p, la, epoch0, tag_s, h, s_p, s_new, s_r2, s_o_flat);
+                chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, h, s_p, s_new, s_r2, s_o_flat);
             }
         }
         const int s_first = l < 0 ? 5 : 0;
         const int s_end = !whole ? p.n_stages : (l < 0 ? 6 : (l + 1 < p.n_layers ? 6 : 5));
-        const bool attn = whole ? l >= 0 : true;
         for (int s = s_first; s < s_end; ++s) {
             const ChainStage st = whole ? p.st[1 + 6 * l + s] : p.st[s];      // (uniform: scalar loads of a descriptor no kernel writes)
             const bool wide = (st.K / KT + TB - 1) / TB > 4;
@@ -881,21 +806,19 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             int in_kind = CHAIN_IN_GRANULES;
             const unsigned long long* gran = p.gran_h;
             unsigned tag = epoch - 1;
-            if (p.merge_ws && s == p.merge_at) in_kind = CHAIN_IN_MERGE;
-            else if (p.gran_p && s == p.merge_at) {               // (only the workgroups that own a group of this stage need the row)
+            if (s == p.merge_at) {                                // (only the workgroups that own a group of this stage need the row)
                 if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged(p, epoch0 + (unsigned)p.cross_at + 1, &s_in[0][0]);
                 in_kind = CHAIN_IN_LDS;
             }
-            else if (s == 0 && (whole || p.self_part)) { gran = p.gran_c; tag = epoch0; }
-            else if (s == 0) in_kind = CHAIN_IN_PLAIN;
+            else if (s == 0) { gran = p.gran_c; tag = epoch0; }
             if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
             else if (st.ln_g) chain_stage<WB, false, true>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
             else chain_stage<WB, false, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
             if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
-            if (attn && (whole || p.cross_kv) && s == p.cross_at) {
+            if (l >= 0 && s == p.cross_at) {
                 chain_cross_stage(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
                 // the NEXT layer's K / V rows set out now: they have the rest of this layer to arrive
-                if (whole && l + 1 < p.n_layers) chain_cross_prefetch(p, p.lio[l + 1].cross_kv, kv_lds, per_split);
+                if (whole && l + 1 < p.n_layers) chain_cross_prefetch(p, li_next.cross_kv, kv_lds, per_split);
             }
         }
     }
@@ -938,65 +861,61 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs_all, int n_
     const bool whole = p.n_layers > 0;
     const ChainStage* hs = whole ? hs_all + 1 : hs_all;       // (whole step: the checks look at layer 0's stages; every layer has the same shapes)
     const int n_stages = whole ? (p.n_layers > 1 ? 6 : 5) : p.n_stages;
-    const bool has_self = whole || p.self_part, has_cross = whole || p.cross_kv;
-    WM_REQUIRE(n_stages >= 1 && n_stages <= CHAIN_MAX_STAGES, "gemv_chain: %d stages", n_stages);
-    WM_REQUIRE(p.x && p.gran_x && p.gran_h && p.err && p.generation && p.st && hs_all, "gemv_chain: null argument");
+    WM_REQUIRE(n_stages >= 5 && n_stages <= CHAIN_MAX_STAGES, "gemv_chain: %d stages (a layer is out, cq, cout, mlp1, mlp2 [, qkv of the next])", n_stages);
+    WM_REQUIRE(p.x && p.out32 && p.gran_x && p.gran_h && p.gran_q && p.gran_p && p.gran_c && p.err && p.generation && p.st && hs_all, "gemv_chain: null argument");
     WM_REQUIRE(p.launch_id >= 0 && p.launch_id < 128, "gemv_chain: launch_id=%d", p.launch_id);      // (7 bits under the stage index)
-    WM_REQUIRE(!whole || (p.n_layers <= 62 && p.lstat && p.lio && p.gran_s && p.gran_p && p.gran_c && p.gran_q && p.cross_at == 1 && p.merge_at == 2 &&
-                          hs_all[0].ln_g && hs_all[0].mode == 0), "gemv_chain: whole-step launch: bad arguments");
+    WM_REQUIRE(p.cross_at == 1 && p.merge_at == 2, "gemv_chain: the cross-attention runs behind stage 1 (cq), stage 2 (cout) merges its pieces");
+    WM_REQUIRE(whole ? (p.n_layers <= 62 && p.lstat && p.lio && p.gran_s && hs_all[0].ln_g && hs_all[0].mode == 0)
+                     : (p.self_part && p.self_cache && p.cross_kv && (!p.self_i8 || p.self_kv_scale > 0.f)),
+               "gemv_chain: %s launch: bad arguments", whole ? "whole-step" : "one-layer");
     WM_REQUIRE(p.w8 == 0 || p.w8 == 1 || p.w8 == 4, "gemv_chain: w8=%d", p.w8);
     const int KT = p.w8 == 4 ? 128 : (p.w8 ? 64 : 32);
     int widest = 0;
     for (int s = 0; s < n_stages; ++s) {
         const ChainStage& st = hs[s];
         WM_REQUIRE(st.Wt && st.K % KT == 0 && st.K <= CHAIN_MAX_IN && st.n_blocks >= 1, "gemv_chain: stage %d shape", s);
-        WM_REQUIRE(st.mode >= 0 && st.mode <= 2 && (st.mode != 0 || p.out32), "gemv_chain: stage %d mode %d", s, st.mode);
+        WM_REQUIRE(st.mode >= 0 && st.mode <= 2, "gemv_chain: stage %d mode %d", s, st.mode);
         WM_REQUIRE(!st.ln_g || (st.ln_b && st.K <= 1536), "gemv_chain: stage %d LayerNorm needs beta and K <= 1536", s);
-        const bool merged_in = (p.merge_ws || p.gran_p) && s == p.merge_at;
-        WM_REQUIRE(s > 0 || st.ln_g || p.in16 || merged_in || has_self, "gemv_chain: the first stage needs its input row");
-        WM_REQUIRE(!merged_in || (p.merge_nsplit >= 1 && p.merge_nsplit <= 16 && p.merge_heads * 64 == st.K && !st.ln_g && st.n_blocks <= n_wg),
-                   "gemv_chain: merged input: %d pieces, %d heads for K=%d", p.merge_nsplit, p.merge_heads, st.K);
+        const bool merged_in = s == p.merge_at;
+        WM_REQUIRE(!merged_in || (p.merge_heads * 64 == st.K && !st.ln_g && st.n_blocks <= n_wg), "gemv_chain: merged input: %d heads for K=%d", p.merge_heads, st.K);
         WM_REQUIRE(s == 0 || st.ln_g || merged_in || hs[s - 1].mode == 1, "gemv_chain: stage %d reads the hidden row, stage %d must produce it", s, s - 1);
         WM_REQUIRE(s == 0 || !st.ln_g || hs[s - 1].mode == 2, "gemv_chain: stage %d normalises the residual row, stage %d must produce it", s, s - 1);
         const int TB = p.w8 ? 5 : 10, slices = (st.K / KT + TB - 1) / TB;
         const int need = slices > 4 ? st.n_blocks : (st.n_blocks + 1) / 2;
         widest = widest > need ? widest : need;
     }
-    WM_REQUIRE(!(p.merge_ws && p.gran_p) && (!(p.merge_ws || p.gran_p) || (p.merge_at >= 0 && p.merge_at < n_stages)), "gemv_chain: merge stage %d", p.merge_at);
-    WM_REQUIRE(!p.merge_ws || p.merge_at == 0, "gemv_chain: partial results in plain memory are the FIRST stage's input");
-    WM_REQUIRE(!p.gran_p || (has_cross && p.merge_at > p.cross_at && p.merge_nsplit == 4 && p.cross_nsplit == 4 && p.merge_heads == p.cross_heads),
-               "gemv_chain: tagged partial results need this launch's cross-attention stage before the merge, 4 pieces");
-    if (has_self) {
-        WM_REQUIRE((whole || p.self_cache) && p.gran_c && p.self_heads >= 1 && p.self_heads * 64 == hs[0].K && !hs[0].ln_g && !(p.merge_at == 0 && (p.merge_ws || p.gran_p)) &&
-                   (p.self_t_dev || (p.self_T >= 0 && p.self_T < p.self_cap)) && p.self_cap <= 512 && (!p.self_i8 || whole || p.self_kv_scale > 0.f),
-                   "gemv_chain: self-attention stage: bad arguments");
-        WM_REQUIRE(n_wg >= p.self_heads + (has_cross ? p.cross_heads * p.cross_nsplit : 0), "gemv_chain: %d workgroups for the attention stages", n_wg);
-    }
-    size_t dyn = 0;
-    if (has_cross) {
-        WM_REQUIRE(p.cross_at >= 0 && p.cross_at < n_stages, "gemv_chain: cross-attention behind stage %d", p.cross_at);
-        WM_REQUIRE((p.cross_ws || p.gran_p) && p.gran_q && hs[p.cross_at].mode == 0 && p.cross_nsplit > 1 && p.cross_nsplit <= 16 && p.cross_Tk >= 1 &&
-                   p.cross_heads * 64 == hs[p.cross_at].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
-        const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
-        WM_REQUIRE(per_split <= CHAIN_CROSS_KEYS, "gemv_chain: %d keys per piece", per_split);
-        dyn = (size_t)2 * per_split * 128 + 1024;
-        WM_REQUIRE(dyn <= 112 * 1024, "gemv_chain: cross-attention pieces of %d keys do not fit LDS", per_split);
-        widest = widest > p.cross_heads * p.cross_nsplit ? widest : p.cross_heads * p.cross_nsplit;
-        static std::atomic<unsigned long long> attr_set{0};       // per device (the dynamic-LDS limit is a per-device attribute of the function)
-        int dev = 0;
-        WM_CHECK_HIP(hipGetDevice(&dev));
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-            WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-            WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-            WM_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-            attr_set.fetch_or(bit, std::memory_order_release);
-        }
-    }
+    WM_REQUIRE(p.merge_nsplit == 4 && p.cross_nsplit == 4 && p.merge_heads == p.cross_heads, "gemv_chain: the attention pieces travel as [head][66][4]: 4 pieces");
+    WM_REQUIRE(p.self_heads >= 1 && p.self_heads * 64 == hs[0].K && !hs[0].ln_g && (p.self_t_dev || (p.self_T >= 0 && p.self_T < p.self_cap)) && p.self_cap <= 512,
+               "gemv_chain: self-attention stage: bad arguments");
+    WM_REQUIRE(n_wg >= p.self_heads + p.cross_heads * p.cross_nsplit, "gemv_chain: %d workgroups for the attention stages", n_wg);
+    WM_REQUIRE(hs[p.cross_at].mode == 0 && p.cross_Tk >= 1 && p.cross_heads * 64 == hs[p.cross_at].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
+    const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
+    WM_REQUIRE(per_split <= CHAIN_CROSS_KEYS, "gemv_chain: %d keys per piece", per_split);
+    const size_t dyn = (size_t)2 * per_split * 128 + 1024;
+    WM_REQUIRE(dyn <= CHAIN_DYN_LDS, "gemv_chain: cross-attention pieces of %d keys do not fit LDS", per_split);
+    widest = widest > p.cross_heads * p.cross_nsplit ? widest : p.cross_heads * p.cross_nsplit;
     WM_REQUIRE(n_wg >= widest, "gemv_chain: %d workgroups for stages that need %d", n_wg, widest);
-    if (p.w8 == 4) hipLaunchKernelGGL(gemv_chain_kernel<4>, dim3(n_wg), dim3(512), dyn, stream, p);
-    else if (p.w8) hipLaunchKernelGGL(gemv_chain_kernel<8>, dim3(n_wg), dim3(512), dyn, stream, p);
-    else hipLaunchKernelGGL(gemv_chain_kernel<16>, dim3(n_wg), dim3(512), dyn, stream, p);
+    static std::atomic<unsigned long long> attr_set{0};       // per device (the dynamic-LDS limit is a per-device attribute of the function)
+    int dev = 0;
+    WM_CHECK_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    auto each_kernel = [&](auto&& f) -> int {
+        if (int rc = f(gemv_chain_kernel<4, false>)) return rc;
+        if (int rc = f(gemv_chain_kernel<4, true>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, false>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, true>)) return rc;
+        if (int rc = f(gemv_chain_kernel<16, false>)) return rc;
+        return f(gemv_chain_kernel<16, true>);
+    };
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        if (each_kernel([&](auto* k) -> int { WM_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_DYN_LDS)); return 0; })) return 2;
+        attr_set.fetch_or(bit, std::memory_order_release);
+    }
+    const bool i8 = p.self_i8 != 0;
+    auto go = [&](auto* k) { hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), dyn, stream, p); };
+    if (p.w8 == 4) { if (i8) go(gemv_chain_kernel<4, true>); else go(gemv_chain_kernel<4, false>); }
+    else if (p.w8) { if (i8) go(gemv_chain_kernel<8, true>); else go(gemv_chain_kernel<8, false>); }
+    else { if (i8) go(gemv_chain_kernel<16, true>); else go(gemv_chain_kernel<16, false>); }
     WM_LAUNCH_CHECK(stream, "gemv_chain");
     return 0;
 }

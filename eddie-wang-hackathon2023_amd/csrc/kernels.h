@@ -74,7 +74,7 @@ int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
 // A chain of gemv_small Linears at ONE activation row in one launch (batch 1): stage inputs / outputs between the stages travel
 // as {epoch, value} granules, the first stage reads plain memory, mode-0 results and the residual row go back to plain memory.
 constexpr int CHAIN_MAX_STAGES = 6;
-constexpr int DECODE_CHAIN_DEFAULT = 4;      // 0: off, 1: the Linears chained, 2: + the cross-attention pieces as the first chain's last stage, 3: one launch per layer, 4: one per token step
+constexpr int DECODE_CHAIN_DEFAULT = 2;      // one-row groups: 0 a launch per kernel, 1 one launch per decoder layer, 2 one per token step
 struct ChainStage {                                           // (an engine keeps its layers' stages in DEVICE memory: a chain's
     const void* Wt; const h16* scale; const h16* bias;         // arguments stay small -- by value they were 330 bytes, and the runtime
     const h16* ln_g; const h16* ln_b;                         // staged such argument blocks with a blit per launch under graph replay)
@@ -85,33 +85,30 @@ struct ChainStage {                                           // (an engine keep
 struct ChainLayerStatic { const h16* qkv_bias; const h16* cq_bias; float kv_scale; int pad_; };     // per layer, the engine's (device memory)
 struct ChainLayerIo { const void* cross_kv; void* cache; };                                         // per layer, the caller's (in the workspace)
 struct GemvChainParams {
-    int n_stages; const ChainStage* st;                       // n_stages consecutive descriptors in device memory
-    float* out32;                                             // where a mode-0 stage leaves its sums
+    // ONE decoder layer of a one-row group (n_layers == 0): n_stages = 5 or 6 consecutive descriptors in device memory -- out, cq,
+    // cout, mlp1, mlp2 [, qkv of the next layer] -- framed by the attention stages:
+    //   first   the self-attention of the row (attn_self_wg_kernel's arithmetic, one head per workgroup) from the qkv sums the launch
+    //           before left in self_part [3C] (cache append included, in place), its output row on gran_c for stage 0
+    //   behind stage cross_at = 1 (cq)   the cross-attention over 4 key-range pieces (attn_cross_kernel<1>'s arithmetic, a (head, piece)
+    //           per workgroup, K / V rows by DMA into LDS from the start of the launch), q from gran_q, the pieces' partial results
+    //           to gran_p as tagged granules [H][66][4]
+    //   stage merge_at = 2 (cout)   merges them (attn_cross_combine_kernel's arithmetic) as its input row
+    // or the WHOLE token step (n_layers > 0): st[0] = qkv of layer 0, then 6 per layer (5 for the last); per-layer pointers from the two
+    // tables; the qkv sums travel as granules too (gran_s, 3 C entries).
+    int n_stages; const ChainStage* st;
+    float* out32;                                             // where a mode-0 stage leaves its sums (plain memory: the next launch's self-attention)
     int w8, gelu_kind;
-    const h16* in16;                                          // the first stage's input row when it has no LayerNorm (attention context)
-    const float* merge_ws; int merge_nsplit, merge_heads;     // instead of in16: the cross-attention's key-range partial results [H][nsplit][66]
-                                                              // of this row, merged by the stage itself (attn_cross_combine_kernel's arithmetic)
     h16* x;                                                   // residual row [C]: read by the first stage that needs it, rewritten by every mode-2 stage
-    h16* hid_out;                                             // optional copy of a mode-1 stage's output in plain memory (tests)
     unsigned long long* gran_x; unsigned long long* gran_h;   // granule edges: C / 2 and 4 C / 2 entries
-    // optional last stage: the decode cross-attention of this row over key-range pieces (attn_cross_kernel<1>'s arithmetic, nsplit > 1),
-    // one (head, piece) per workgroup, its K / V rows prefetched into LDS from the start of the launch; q = the sums the chain's last
-    // Linear (mode 0) has just published on gran_q; the pieces' partial results go to cross_ws for the next launch to merge
-    const h16* cross_kv; int cross_Tk, cross_heads, cross_nsplit; float* cross_ws; const h16* cross_qbias;
+    const h16* cross_kv; int cross_Tk, cross_heads, cross_nsplit; const h16* cross_qbias;
     unsigned long long* gran_q;                               // C entries ({epoch, fp32 bits})
-    int cross_at;                                             // ... which is stage `cross_at` (mode 0); the cross-attention runs behind it
-    int merge_at;                                             // the stage whose input is the merged attention row: merge_ws (plain memory, the launch
-    unsigned long long* gran_p;                               // before) or gran_p (this launch's pieces, tagged: [H][66][4], 4 pieces only)
-    // optional first stage: the self-attention of this row (attn_self_wg_kernel's arithmetic, one head per workgroup) from the qkv sums
-    // the launch before left in self_part [3C] -- cache append included (in place) -- its output row on gran_c for stage 0
+    int cross_at, merge_at, merge_nsplit, merge_heads;
+    unsigned long long* gran_p;
     const float* self_part; const h16* self_bias; void* self_cache; int self_cap, self_T, self_heads, self_i8; const int32_t* self_t_dev;
-    float self_kv_scale; h16* self_out; unsigned long long* gran_c;     // C / 2 entries; self_out: optional plain copy [C]
-    // the whole token step in one launch: n_layers > 0 layers, descriptors st[0] = qkv of layer 0, then 6 per layer (5 for the last);
-    // per-layer pointers from the two tables; qkv sums travel as granules (gran_s, 3 C entries); needs the self- and cross-attention
-    // stages' arguments (heads, pieces, Tk, capacity, T, ...) as for one layer
+    float self_kv_scale; h16* self_out; unsigned long long* gran_c;     // C / 2 entries; self_out: optional plain copy [C] (tests)
     int n_layers; const ChainLayerStatic* lstat; const ChainLayerIo* lio; unsigned long long* gran_s;
     unsigned* err;                                            // set non-zero when a bounded wait gives up
-    const unsigned* generation; int launch_id;                // epochs: (*generation << 10) | (launch_id << 3), + stage + 1 (generation: one per decoder call)
+    const unsigned* generation; int launch_id;                // epochs: (*generation << 10) | (layer or launch_id << 3), + stage + 1 (generation: one per decoder call)
 };
 bool gemv_chain_supports(int C, int w8, int n_cu);
 int gemv_chain_err_word(unsigned** out);                      // device address of this device's "a wait was given up" word
@@ -199,7 +196,6 @@ struct AttnCrossParams {
     float* ws;                               // [B*H*nsplit][L][66] partial (m, l, o[64]) when nsplit > 1
     const int32_t* live;                     // optional [1 + B]: count, then the rows to process (others are skipped)
     int skip_zero_rows;                      // fp16 K/V, nsplit == 1: V rows whose probabilities all round to fp16 zero are not fetched (exact)
-    int no_combine;                          // nsplit > 1: leave the partial results in ws (the consumer merges them: gemv_chain.hip)
 };
 constexpr int CROSS_V_SKIP_DEFAULT = 1;      // measured: profiles/r4e_* (diffuse attention: no slower; peaked: FETCH_SIZE falls with the skipped rows)
 int launch_attn_cross(const AttnCrossParams& p, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

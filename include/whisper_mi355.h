@@ -272,15 +272,14 @@ int wm_set_gemm_small_tiles(int tiles);
  * launch (csrc/gemv_chain.hip: the stages hand the activation row over as tagged 8-byte granules -- no fences, no flags, no
  * barriers between workgroups; a stage's weights are requested before its input is waited for).  Same arithmetic as one launch
  * per kernel, bit for bit.  Modes:
- *   0  off: a launch per fused Linear and per attention kernel (9 per layer)
- *   1  the fused Linears of a layer as two chains -- [out + residual -> LayerNorm + cross-attention q] and [merge of the
- *      cross-attention's key-range pieces + out + residual -> LayerNorm + mlp1 + GELU -> mlp2 + residual -> LayerNorm + qkv of the
- *      next layer] -- 4 launches per layer
- *   2  + the cross-attention pieces as the first chain's last stage (K / V rows by DMA into LDS while the Linears run): 3 per layer
- *   3  + the self-attention (cache append included) as the first stage, the pieces handed to the merge as granules: 1 per layer
- *   4  the launch walks over the layers itself: ONE launch per token step besides the embedding and the vocabulary
+ *   0  a launch per fused Linear and per attention kernel (9 per layer)
+ *   1  a decoder layer as ONE launch: self-attention (cache append included), out + residual, LayerNorm + cross-attention q,
+ *      the cross-attention over four key-range pieces (K / V rows by DMA into LDS while the stages before it run), the merge of
+ *      the pieces + cross-attention out + residual, LayerNorm + mlp1 + GELU, mlp2 + residual, LayerNorm + qkv of the next layer
+ *   2  the launch walks over the layers itself: ONE launch per token step besides the embedding and the vocabulary
  *      projection (default).  The per-layer cross K/V and cache pointers reach it through a table in the workspace.
- * Modes 3 and 4 need the in-place cache (past[i] == present[i], equal capacities <= 512) and fall back to mode 2 otherwise.
+ * Both need the in-place cache (past[i] == present[i], equal capacities <= 512), fp16 cross K/V and <= 62 layers for mode 2; a
+ * call that does not qualify takes the launch-per-kernel path.
  * < 0 = default; returns the previous value.  Captured graphs keep the form they were captured with.
  * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a (bounded) wait since the last call -- the results of
  * that step are not valid (a chain needs its <= 256 workgroups resident together; the word is cleared by the call; it

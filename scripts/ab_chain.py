@@ -1,4 +1,4 @@
-"""A/B of the one-row decode chain (csrc/gemv_chain.hip) on ONE box: bench.py at small batches with wm_set_decode_chain(0 / 1), interleaved.
+"""A/B of the one-row decode chain (csrc/gemv_chain.hip) on ONE box: bench.py at small batches with wm_set_decode_chain(0 / 1 / 2), interleaved.
     python scripts/ab_chain.py [batch=1] [rounds=2]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,9 +14,9 @@ import bench
 bench.main()
 """ % (ROOT, os.path.join(ROOT, "eddie-wang-hackathon2023_amd"))
 for r in range(rounds):
-    for on in (0, 1, 2, 3, 4):
+    for on in (0, 1, 2):
         out = subprocess.run([sys.executable, "-c", code, str(on), batch], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
         line = [l for l in out.splitlines() if l.startswith("{")][-1]
         res = json.loads(line)
-        name = ("off", "linears", "linears + cross", "whole layer", "whole step")[on]
+        name = ("off", "a launch per layer", "one launch per step")[on]
         print(f"batch {batch} chain {name} round {r}: {res['roofline']['decode_step_ms']} ms per token, {res['value']} tokens/s whole job", flush=True)

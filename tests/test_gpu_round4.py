@@ -397,10 +397,11 @@ print(json.dumps({"ms_per_token": best * 1e3 / 96, "runtime": native.runtime_rep
                                                         ("tiny", True, False), ("tiny", "int4", True), ("large-v2-6layer", True, True),
                                                         ("large-v2-6layer", False, False)])
 def test_one_row_chain_equals_the_launch_per_linear_path(tmp_path_factory, model, weight_only, int8_kv):
-    """csrc/gemv_chain.hip: at one activation row the fused Linears of a decoder layer run as two chains inside one launch each
-    (granule hand-offs between the stages).  Same arithmetic as one gemv_small launch per Linear: token ids, log-probabilities
-    and the whole KV cache of a batch-1 decode are IDENTICAL with the chain on and off, eagerly and under graph replay, and no
-    workgroup gave up a wait."""
+    """csrc/gemv_chain.hip: at one activation row a decoder layer -- self-attention with the cache append, the six fused Linears, the
+    cross-attention over key-range pieces and their merge -- runs as the stages of ONE launch (granule hand-offs between the
+    stages), and the whole token step as one launch that walks over the layers.  Same arithmetic as a launch per kernel: token
+    ids, log-probabilities and the whole KV cache of a batch-1 decode are IDENTICAL in the three forms, eagerly and under graph
+    replay, and no workgroup gave up a wait."""
     import synthetic
     from decoding import DecodingOptions, WhisperDecoding
     from encoding import WhisperEncoding
@@ -417,7 +418,7 @@ def test_one_row_chain_equals_the_launch_per_linear_path(tmp_path_factory, model
     outs = []
     prev = lib_().wm_set_decode_chain(-1)
     try:
-        for on in (0, 1, 2, 3, 4):                           # off | the Linears chained | + the cross-attention pieces as a chain stage | one launch per layer | per token step
+        for on in (0, 1, 2):                                 # a launch per kernel | one launch per decoder layer | one per token step
             lib_().wm_set_decode_chain(on)
             dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
             dec.detect_language(xa)
