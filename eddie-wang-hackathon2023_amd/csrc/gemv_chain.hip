@@ -599,7 +599,8 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     }
     const float t_dq = la.self_kv_scale;
     const float inv_t = 1.0f / la.self_kv_scale;
-    if (wid == 0) {                                   // this call's q, k, v of the head (lane = dim): one slab, bias, fp16; the cache append
+    float k_new = 0.f, v_new = 0.f;
+    if (wid == 0) {                                   // this call's q, k, v of the head (lane = dim): one slab, bias, fp16
         float q = 0.f, k = 0.f, v = 0.f;
         const float bq = la.self_bias ? (float)la.self_bias[h * 64 + lane] : 0.f;              // (requested ahead of the wait for the sums)
         const float bk = la.self_bias ? (float)la.self_bias[C + h * 64 + lane] : 0.f;
@@ -628,15 +629,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
         v = r16(v + bv);
         s_knew[lane] = (h16)k;
         s_vnew[lane] = (h16)v;
-        const size_t off_k = ((size_t)(0 * H + h) * p.self_cap + T) * 64 + lane;
-        const size_t off_v = ((size_t)(1 * H + h) * p.self_cap + T) * 64 + lane;
-        if (I8) {
-            ((int8_t*)la.self_cache)[off_k] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(k * inv_t)));
-            ((int8_t*)la.self_cache)[off_v] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(v * inv_t)));
-        } else {
-            ((h16*)la.self_cache)[off_k] = (h16)k;
-            ((h16*)la.self_cache)[off_v] = (h16)v;
-        }
+        k_new = k; v_new = v;                         // (the cache append waits for the end of the stage: see there)
         s_q[lane] = (h16)r16(q * SCALE);
     }
     __syncthreads();
@@ -743,6 +736,17 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
         if ((lane & 1) == 0)
             __hip_atomic_store((chain_gu64*)(p.gran_c + ((h * 64 + lane) >> 1)), ((unsigned long long)epoch0 << 32) | (bits | (nb_bits << 16)),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The cache append, position T: LAST.  A workgroup barrier waits for the wave's stores to be acknowledged by memory (2 us here),
+        // and nothing in this launch reads the new row from memory -- the next token step does.
+        const size_t off_k = ((size_t)(0 * H + h) * p.self_cap + T) * 64 + lane;
+        const size_t off_v = ((size_t)(1 * H + h) * p.self_cap + T) * 64 + lane;
+        if (I8) {
+            ((int8_t*)la.self_cache)[off_k] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(k_new * inv_t)));
+            ((int8_t*)la.self_cache)[off_v] = (int8_t)fminf(127.f, fmaxf(-128.f, rintf(v_new * inv_t)));
+        } else {
+            ((h16*)la.self_cache)[off_k] = (h16)k_new;
+            ((h16*)la.self_cache)[off_v] = (h16)v_new;
+        }
     }
     __syncthreads();
 }
