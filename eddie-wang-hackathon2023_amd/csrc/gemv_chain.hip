@@ -339,7 +339,8 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 // order, only the rows come from LDS, where waves 4-7 put them by DMA at the START of the launch (K and V do not depend on the
 // activations: their 96 KB fly while the chain's Linears run) instead of from memory through a register pipeline.
 constexpr int CHAIN_CROSS_KEYS = 1536;
-constexpr size_t CHAIN_DYN_LDS = 108 * 1024;      // K and V rows of a piece (beside ~ 49 KB of static LDS, of 160)
+constexpr size_t CHAIN_DYN_LDS = 104 * 1024;      // K and V rows of a piece (beside ~ 52 KB of static LDS, of 160)
+constexpr int CHAIN_MAX_LAYERS = 62;               // (layer ids 0 .. 61 under the epoch's stage bits; 63 is "the projection before layer 0")
 // what the attention stages take per LAYER (kernel arguments for a one-layer launch, the two tables in a whole-step launch)
 struct ChainLayerArgs { const h16* cross_kv; const h16* cross_qbias; void* self_cache; const h16* self_bias; float self_kv_scale; };
 constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
@@ -364,10 +365,10 @@ __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, c
 }
 
 __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, const ChainLayerArgs& la, unsigned epoch_q, const unsigned char* kv_lds, int per_split,
-                                                  float* s_sc, float (*s_redc)[2], float (*s_o)[64], float* s_q) {
+                                                  float* s_sc, float (*s_redc)[2] /* [8] */, float (*s_o)[64], float* s_q) {
     constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
     constexpr int STRIDE = 4 * RPI * UNR;
-    constexpr int KB = 3;                          // iterations whose rows are requested together
+    constexpr int KB = 3, KB2 = 2;                 // iterations whose rows are requested together (P.V | scores, a wave's share)
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_items = p.cross_heads * p.cross_nsplit, item = (int)blockIdx.x - ((int)gridDim.x - n_items);
     const bool has_item = item >= 0;
@@ -377,7 +378,7 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     const int first = (wid & 3) * (RPI * UNR);
     const bool worker = wid < 4 && has_item && nkeys > 0;
     half8v qb8 = half8v{0, 0, 0, 0, 0, 0, 0, 0};                              // the lane's 8 q-bias values: requested now, not behind the wait for q
-    if (worker && la.cross_qbias) qb8 = *(const half8v*)(la.cross_qbias + h * 64 + sub * DPL);
+    if (has_item && nkeys > 0 && la.cross_qbias) qb8 = *(const half8v*)(la.cross_qbias + h * 64 + sub * DPL);
     if (wid >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's K / V pieces have landed
     if (wid == 0 && has_item) {                                               // the head's 64 q sums, as the last Linear published them
         int fst[1] = {h * 64 + 2 * min(lane, 31)};
@@ -404,7 +405,7 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     const int nb = (nkeys + STRIDE - 1) / STRIDE;
     float qf[DPL];
     float mx = -INFINITY;
-    if (worker) {
+    if (has_item && nkeys > 0) {
         // q of this lane's 8 dims: one slab, bias, the two roundings (attn_cross_kernel's prologue at ksplit = 1)
 #pragma unroll
         for (int e = 0; e < DPL; ++e) {
@@ -415,23 +416,25 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
             const float bs = (float)qb8[e];
             qf[e] = r16(r16(qa + bs) * CHAIN_ATTN_SCALE);
         }
-        // ---- pass 1: scores (the rows of three iterations -- all of a <= 384-key piece -- are read from LDS before the first is used:
-        // one LDS round trip instead of twelve dependent ones; per-key arithmetic as ever) ---------------------------------------
-        for (int k0 = 0; k0 < nb; k0 += KB) {
-            half8v hv[KB][UNR];
+        // ---- pass 1: scores -- a key's score is its own (no sum across keys), so ALL EIGHT waves take part: wave w scores the rows
+        // attn_cross_kernel's wave w & 3 scores, in the iterations k with k & 1 == w >> 2 (the upper four waves have nothing else to
+        // do once their K / V rows have landed).  The rows of two iterations are read from LDS before the first is used. ----------
+        const int half = wid >> 2;
+        for (int k0 = half; k0 < nb; k0 += 2 * KB2) {
+            half8v hv[KB2][UNR];
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk)
+            for (int kk = 0; kk < KB2; ++kk)
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int rr = min(first + (k0 + kk) * STRIDE + u * RPI + rowi, nkeys - 1);
+                    const int rr = min(first + (k0 + 2 * kk) * STRIDE + u * RPI + rowi, nkeys - 1);
                     hv[kk][u] = *(const half8v*)(K + (size_t)rr * 128 + sub * 16);
                 }
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                if (k0 + kk >= nb) break;                                      // wave-uniform
+            for (int kk = 0; kk < KB2; ++kk) {
+                if (k0 + 2 * kk >= nb) break;                                  // wave-uniform
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int r = first + (k0 + kk) * STRIDE + u * RPI + rowi;
+                    const int r = first + (k0 + 2 * kk) * STRIDE + u * RPI + rowi;
                     float ks[DPL];
 #pragma unroll
                     for (int e = 0; e < DPL; ++e) ks[e] = r16((float)hv[kk][u][e] * CHAIN_ATTN_SCALE);
@@ -455,7 +458,8 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     __syncthreads();                                                           // (B)
     float gmax = 0.f, gsum = 0.f;
     if (worker) {
-        gmax = fmaxf(fmaxf(s_redc[0][0], s_redc[1][0]), fmaxf(s_redc[2][0], s_redc[3][0]));
+        gmax = fmaxf(fmaxf(fmaxf(s_redc[0][0], s_redc[1][0]), fmaxf(s_redc[2][0], s_redc[3][0])),
+                     fmaxf(fmaxf(s_redc[4][0], s_redc[5][0]), fmaxf(s_redc[6][0], s_redc[7][0])));      // (a maximum: whoever found it)
         float sm = 0.f;
         for (int j = tid; j < nkeys; j += 256) {
             const float e = __expf(s_sc[j] - gmax);
@@ -561,6 +565,27 @@ __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, uns
     __syncthreads();
 }
 
+// The cached K and V rows of a self-attention head into LDS, a layer AHEAD of their use (waves 4-7 of the head's workgroup: they idle
+// through every other stage, and the dynamic LDS the cross-attention's workgroups fill with K/V rows is free here).  Rows 0 .. T - 1
+// are contiguous in the cache, so each matrix is copied as 1 KiB pieces, linear: the stage reads them where it read global memory.
+// Returns the bytes per matrix (the V rows start there), or 0 when there is nothing to fetch or the rows do not fit.
+template <bool I8>
+__device__ __forceinline__ int chain_self_prefetch(const GemvChainParams& p, const void* cache, int T, int h, unsigned char* kv_lds, int avail) {
+    constexpr int ROW_B = I8 ? 64 : 128;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_pieces = (T * ROW_B + 1023) >> 10, total = (p.self_cap * ROW_B) >> 10;        // pieces wanted | pieces the head's matrix has
+    if (T <= 0 || 2 * n_pieces * 1024 > avail || n_pieces > total) return 0;
+    if (wid >= 4) {
+        for (int m = 0; m < 2; ++m) {
+            const unsigned char* src = (const unsigned char*)cache + ((size_t)(m * p.self_heads + h) * p.self_cap * 64) * (I8 ? 1 : 2);
+            for (int pc = wid - 4; pc < n_pieces; pc += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pc * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(kv_lds + (m * n_pieces + pc) * 1024), 16, 0, 0);
+        }
+    }
+    return n_pieces * 1024;
+}
+
 // ---- the self-attention of the row as the launch's first stage -----------------------------------------------------------------
 // attn_self_wg_kernel (attn_decode.hip) at one new token of one utterance, for ONE head per workgroup: its four waves are this
 // workgroup's waves 0-3, same expressions in the same order (q / k / v = the qkv sums of the launch before + bias, rounded; the
@@ -569,7 +594,7 @@ __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, uns
 // outputs are published as granules (p.gran_c, tagged with the launch's epoch) for the out projection, this launch's next stage.
 template <bool I8>
 __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const ChainLayerArgs& la, int T, unsigned epoch0, unsigned tag_s, int h, float* s_p, h16 (*s_new)[64],
-                                                 float (*s_r2)[4], float* s_o_flat) {
+                                                 float (*s_r2)[4], float* s_o_flat, const unsigned char* lds_rows, int lds_v_off) {
     constexpr float SCALE = 0.35355339059327373f;     // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
     constexpr int ES = I8 ? 1 : 2;
     constexpr int ROW_B = 64 * ES;
@@ -583,11 +608,13 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     const bool worker = wid < NW;
     h16* s_q = s_new[0]; h16* s_knew = s_new[1]; h16* s_vnew = s_new[2];
     const int H = p.self_heads, C = H * 64;
-    const unsigned char* pastK = (const unsigned char*)la.self_cache + ((size_t)(0 * H + h) * p.self_cap * 64) * ES;
-    const unsigned char* pastV = (const unsigned char*)la.self_cache + ((size_t)(1 * H + h) * p.self_cap * 64) * ES;
+    // the cached rows: in LDS already (chain_self_prefetch, a layer ago; lds_v_off > 0), or from memory, the first blocks requested now
+    const bool in_lds = lds_v_off > 0;                                  // (workgroup-uniform)
+    const unsigned char* pastK = in_lds ? lds_rows : (const unsigned char*)la.self_cache + ((size_t)(0 * H + h) * p.self_cap * 64) * ES;
+    const unsigned char* pastV = in_lds ? lds_rows + lds_v_off : (const unsigned char*)la.self_cache + ((size_t)(1 * H + h) * p.self_cap * 64) * ES;
     const int vr = lane / NCH, vc = lane % NCH;
     uint4 kpre[KCH], vpre[VPRE];
-    if (worker && T > 0) {
+    if (worker && T > 0 && !in_lds) {
         const int kr = min(64 * wid + lane, T - 1);
 #pragma unroll
         for (int c = 0; c < KCH; ++c) kpre[c] = ((const uint4*)(pastK + (size_t)kr * ROW_B))[c];
@@ -645,7 +672,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
                     const uint4* kr = (const uint4*)(pastK + (size_t)j * ROW_B);
 #pragma unroll
                     for (int c = 0; c < KCH; ++c) {
-                        const uint4 w = kb == wid ? kpre[c] : kr[c];
+                        const uint4 w = (kb == wid && !in_lds) ? kpre[c] : kr[c];
                         if (I8) {
                             const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -712,7 +739,10 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
 #pragma unroll
         for (int n = 0; n < VPRE; ++n) {
             const int vb = wid + NW * n;
-            if (vb * VROWS < T) add_block(vb, vpre[n]);
+            if (vb * VROWS < T) {
+                if (in_lds) add_block(vb, *(const uint4*)(pastV + (size_t)min(vb * VROWS + vr, T - 1) * ROW_B + vc * 16));
+                else add_block(vb, vpre[n]);
+            }
         }
         for (int vb = wid + NW * VPRE; vb * VROWS < T; vb += NW) {
             const int row = min(vb * VROWS + vr, T - 1);
@@ -763,7 +793,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     const unsigned gen = *p.generation;
     extern __shared__ __attribute__((aligned(1024))) unsigned char kv_lds[];      // the cross-attention stage's K and V rows (only then)
     __shared__ float s_sc[CHAIN_CROSS_KEYS];
-    __shared__ float s_redc[4][2];
+    __shared__ float s_redc[8][2];
     __shared__ float s_o[4][64];
     __shared__ float s_q[64];
     // The WHOLE token step in one launch (p.n_layers > 0): the launch walks over the layers itself.  Per-layer pointers come from two
@@ -774,32 +804,42 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     const int T_now = p.self_t_dev ? *p.self_t_dev : p.self_T;      // cached tokens: one (scalar) load per launch
     ChainLayerArgs la{p.cross_kv, p.cross_qbias, p.self_cache, p.self_bias, p.self_kv_scale};
     const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
+    // the two per-layer tables, copied to LDS once: read from memory layer by layer they were a cold scalar load (2.3 us) in front of
+    // every layer's first barrier -- on the critical path in the self-attention's workgroups
+    __shared__ ChainLayerStatic s_lst[CHAIN_MAX_LAYERS];
+    __shared__ ChainLayerIo s_lio[CHAIN_MAX_LAYERS];
+    if (whole) {
+        for (int i = threadIdx.x; i < p.n_layers; i += 512) { s_lst[i] = p.lstat[i]; s_lio[i] = p.lio[i]; }
+        __syncthreads();
+    }
     // Who does what besides the Linears.  The cross-attention's (head, piece) items go to the LAST workgroups of the launch and the
     // self-attention's heads to the ones before them: the first workgroups own the output groups of every n_state-wide Linear (and
     // both slots of the widest), the last ones idle through most stages -- and the four upper waves of a workgroup that carries
     // K / V rows in flight must not meet a stage's "everything of mine has landed" wait before those rows are due.
-    chain_cross_prefetch(p, whole ? p.lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
+    chain_cross_prefetch(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
+    const int self_base = max((int)gridDim.x - p.cross_heads * p.cross_nsplit - p.self_heads, 0);
+    const int self_h = (int)blockIdx.x - self_base;                      // this workgroup's self-attention head, if 0 <= self_h < self_heads
+    const bool self_wg = self_h >= 0 && self_h < p.self_heads && self_base >= 0 && (int)blockIdx.x < (int)gridDim.x - p.cross_heads * p.cross_nsplit;
+    int self_v_off = 0;                                                  // > 0: the head's cached rows of the NEXT self-attention stage are (on their way) in LDS
+    if (self_wg) self_v_off = chain_self_prefetch<I8KV>(p, whole ? s_lio[0].cache : p.self_cache, T_now, self_h, kv_lds, 2 * per_split * 128);
     bool own_valid = false, x_in_granules = false;
-    ChainLayerStatic ls_next{}; ChainLayerIo li_next{};
     for (int l = whole ? -1 : 0; l < (whole ? p.n_layers : 1); ++l) {
         const unsigned epoch0 = (gen << 10) | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);
-        if (whole && l >= 0) {                        // (the entries were requested a layer ago: scalar loads, nothing waits for them here)
-            la.cross_kv = (const h16*)li_next.cross_kv; la.cross_qbias = ls_next.cq_bias;
-            la.self_cache = li_next.cache; la.self_bias = ls_next.qkv_bias; la.self_kv_scale = ls_next.kv_scale;
+        if (whole && l >= 0) {
+            const ChainLayerStatic ls = s_lst[l];
+            const ChainLayerIo li = s_lio[l];
+            la.cross_kv = (const h16*)li.cross_kv; la.cross_qbias = ls.cq_bias;
+            la.self_cache = li.cache; la.self_bias = ls.qkv_bias; la.self_kv_scale = ls.kv_scale;
         }
-        if (whole && l + 1 < p.n_layers) { ls_next = p.lstat[l + 1]; li_next = p.lio[l + 1]; }
-        if (l >= 0) {
-            const int n_items = p.cross_heads * p.cross_nsplit;
-            const int base = max((int)gridDim.x - n_items - p.self_heads, 0);
-            const int h = (int)blockIdx.x - base;
-            if (h >= 0 && h < p.self_heads) {             // (workgroup-uniform) LDS: the Linears' buffers, not in use now
-                float* s_p = &s_red[0][0][0];
-                h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
-                float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
-                float* s_o_flat = (float*)&s_in[0][0];
-                const unsigned tag_s = ((gen << 10) | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
-                chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, h, s_p, s_new, s_r2, s_o_flat);
-            }
+        if (l >= 0 && self_wg) {                         // (workgroup-uniform) LDS: the Linears' buffers, not in use now
+            float* s_p = &s_red[0][0][0];
+            h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
+            float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
+            float* s_o_flat = (float*)&s_in[0][0];
+            const unsigned tag_s = ((gen << 10) | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
+            chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, self_h, s_p, s_new, s_r2, s_o_flat, kv_lds, self_v_off);
+            // the NEXT layer's cached rows set out now (the stage's last barrier is behind every read of this layer's)
+            self_v_off = (whole && l + 1 < p.n_layers) ? chain_self_prefetch<I8KV>(p, s_lio[l + 1].cache, T_now, self_h, kv_lds, 2 * per_split * 128) : 0;
         }
         const int s_first = l < 0 ? 5 : 0;
         const int s_end = !whole ? p.n_stages : (l < 0 ? 6 : (l + 1 < p.n_layers ? 6 : 5));
@@ -822,7 +862,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             if (l >= 0 && s == p.cross_at) {
                 chain_cross_stage(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
                 // the NEXT layer's K / V rows set out now: they have the rest of this layer to arrive
-                if (whole && l + 1 < p.n_layers) chain_cross_prefetch(p, li_next.cross_kv, kv_lds, per_split);
+                if (whole && l + 1 < p.n_layers) chain_cross_prefetch(p, s_lio[l + 1].cross_kv, kv_lds, per_split);
             }
         }
     }
@@ -869,7 +909,7 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs_all, int n_
     WM_REQUIRE(p.x && p.out32 && p.gran_x && p.gran_h && p.gran_q && p.gran_p && p.gran_c && p.err && p.generation && p.st && hs_all, "gemv_chain: null argument");
     WM_REQUIRE(p.launch_id >= 0 && p.launch_id < 128, "gemv_chain: launch_id=%d", p.launch_id);      // (7 bits under the stage index)
     WM_REQUIRE(p.cross_at == 1 && p.merge_at == 2, "gemv_chain: the cross-attention runs behind stage 1 (cq), stage 2 (cout) merges its pieces");
-    WM_REQUIRE(whole ? (p.n_layers <= 62 && p.lstat && p.lio && p.gran_s && hs_all[0].ln_g && hs_all[0].mode == 0)
+    WM_REQUIRE(whole ? (p.n_layers <= CHAIN_MAX_LAYERS && p.lstat && p.lio && p.gran_s && hs_all[0].ln_g && hs_all[0].mode == 0)
                      : (p.self_part && p.self_cache && p.cross_kv && (!p.self_i8 || p.self_kv_scale > 0.f)),
                "gemv_chain: %s launch: bad arguments", whole ? "whole-step" : "one-layer");
     WM_REQUIRE(p.w8 == 0 || p.w8 == 1 || p.w8 == 4, "gemv_chain: w8=%d", p.w8);

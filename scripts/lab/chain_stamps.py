@@ -20,12 +20,17 @@ def build():
         return s.replace(marker, marker + text, 1)
     s = s.replace('''// Where a stage without LayerNorm takes its input row from (wave-uniform):''', '''__device__ unsigned long long g_stamps[64 * 32];
 __device__ unsigned long long g_stamps2[64 * 8 * 8];
-__device__ int g_stamp_layer;      // written and read by ONE thread (thread 0 of the stamped workgroup)
+// The stamps of a layer are collected in LDS and written out once, at the start of the next layer: a stamp that went to memory
+// directly would be waited for (its acknowledgement, ~ 2 us) at the next workgroup barrier and measure mostly itself.
+__shared__ unsigned long long s_stamps[32 + 64];
+__shared__ int s_stamp_layer;
 extern "C" int wm_lab_chain_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps2), sizeof(g_stamps2)); }
 #define STAMP_ON (threadIdx.x == 0 && blockIdx.x == WM_STAMP_WG)
-#define STAMP(k) do { if (STAMP_ON && g_stamp_layer >= 0) g_stamps[g_stamp_layer * 32 + (k)] = wall_clock64(); } while (0)
-#define STAMP2(k) do { if (STAMP_ON && g_stamp_layer >= 0) g_stamps2[(g_stamp_layer * 8 + s) * 8 + (k)] = wall_clock64(); } while (0)
+#define STAMP(k) do { if (STAMP_ON) s_stamps[k] = wall_clock64(); } while (0)
+#define STAMP2(k) do { if (STAMP_ON) s_stamps[32 + s * 8 + (k)] = wall_clock64(); } while (0)
+#define STAMP_FLUSH(layer) do { if (STAMP_ON) { const int pl = s_stamp_layer; if (pl >= 0 && pl < 64) { for (int i_ = 0; i_ < 32; ++i_) g_stamps[pl * 32 + i_] = s_stamps[i_]; \\
+    for (int i_ = 0; i_ < 64; ++i_) g_stamps2[pl * 64 + i_] = s_stamps[32 + i_]; } for (int i_ = 0; i_ < 96; ++i_) if (i_ < 24 || i_ >= 32) s_stamps[i_] = 0; s_stamp_layer = (layer); } } while (0)
 // Where a stage without LayerNorm takes its input row from (wave-uniform):''', 1)
     s = ins_before(s, '    // ---- 1. every weight tile', '    STAMP2(0);\n')
     s = ins_after(s, '                ok = sweep_granules16<2 * XP>(p.gran_x, first, epoch - 1, val, p.err, lane);\n', '                STAMP2(1);\n')
@@ -34,8 +39,9 @@ extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipM
     s = ins_before(s, '    // ---- 4. epilogue', '    STAMP2(3);\n')
     s = ins_before(s, '    if (st.mode == 2) own_valid = true;\n    __syncthreads();                                          // s_red / s_in', '    STAMP2(4);\n')
     s = ins_after(s, '        const unsigned epoch0 = (gen << 10) | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);\n',
-                  '        if (STAMP_ON) g_stamp_layer = whole ? l : p.launch_id;\n        STAMP(0);\n')
+                  '        STAMP_FLUSH(whole ? l : p.launch_id);\n        STAMP(0);\n')
     s = ins_before(s, '        const int s_first = l < 0 ? 5 : 0;', '        STAMP(7);\n')
+    s = ins_before(s, '    bool own_valid = false, x_in_granules = false;\n    for (int l = whole ? -1 : 0;', '    if (STAMP_ON) s_stamp_layer = -1;\n')
     s = ins_after(s, '            if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch\'s granules\n', '            STAMP(1 + s);\n')
     s = ins_before(s, '                // the NEXT layer\'s K / V rows set out now', '                STAMP(8);\n')
     s = ins_before(s, '            if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid', '            if (s == p.merge_at) STAMP(9);\n')
@@ -50,7 +56,7 @@ extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipM
     body = s[a:b].replace('        q = r16(q + bq);', '        STAMP(17);\n        q = r16(q + bq);', 1)
     parts = body.split('    __syncthreads();\n')
     assert len(parts) == 7, len(parts)
-    body = (parts[0] + '    STAMP(18);\n    __syncthreads();\n' + parts[1] + '    __syncthreads();\n    STAMP(19);\n' + parts[2] + '    __syncthreads();\n' + parts[3]
+    body = (parts[0] + '    STAMP(18);\n    if (blockIdx.x == WM_STAMP_WG && lane == 0) s_stamps[24 + wid] = wall_clock64();\n    __syncthreads();\n' + parts[1] + '    __syncthreads();\n    STAMP(19);\n' + parts[2] + '    __syncthreads();\n' + parts[3]
             + '    __syncthreads();\n    STAMP(20);\n' + parts[4] + '    __syncthreads();\n    STAMP(21);\n' + parts[5] + '    STAMP(22);\n    __syncthreads();\n' + parts[6])
     body = body.replace('    const float t_dq = la.self_kv_scale;', '    STAMP(16);\n    const float t_dq = la.self_kv_scale;', 1)
     s = s[:a] + body + s[b:]
@@ -94,11 +100,11 @@ def read():
     lib.wm_lab_chain_stamps(st.ctypes.data)
     st = st.reshape(64, 32).astype(np.int64)
     L = dims.n_text_layer
-    x = np.array([st[i] for i in range(1, L - 1)], dtype=np.float64) / 100.0
-    nx = np.array([st[i + 1][0] for i in range(1, L - 1)], dtype=np.float64) / 100.0
+    x = np.array([st[i] for i in range(1, L - 2)], dtype=np.float64) / 100.0
+    nx = np.array([st[i + 1][0] for i in range(1, L - 2)], dtype=np.float64) / 100.0
     cols = [("self-attention (from layer start)", 7, 0), ("out", 1, 7), ("cq", 2, 1), ("cross-attention", 8, 2), ("merge of the pieces", 9, 8), ("cout", 3, 9),
             ("mlp1", 4, 3), ("mlp2", 5, 4), ("qkv of the next layer", 6, 5)]
-    print(f"library {os.environ.get('WM_LIBRARY_PATH')}: one workgroup's view, us per layer (mean over layers 1..{L - 2} of the last step at {dec.sample_len} tokens)")
+    print(f"library {os.environ.get('WM_LIBRARY_PATH')}: one workgroup's view, us per layer (mean over layers 1..{L - 3} of the last step at {dec.sample_len} tokens)")
     tot = 0.0
     for name, hi, lo in cols:
         d = x[:, hi] - x[:, lo]
@@ -112,7 +118,7 @@ def read():
     s2 = s2.reshape(64, 8, 8).astype(np.int64)
     print("  Linear stages (wave 0 of slot 0): wait for the input | LayerNorm / fragments | multiply (weights waited for here) | epilogue + publish")
     for sidx, name in enumerate(["out", "cq", "cout", "mlp1", "mlp2", "qkv"]):
-        y = np.array([s2[i, sidx] for i in range(1, L - 1)], dtype=np.float64) / 100.0
+        y = np.array([s2[i, sidx] for i in range(1, L - 2)], dtype=np.float64) / 100.0
         if y[:, 0].min() <= 0:
             print(f"    {name:6s} (idle in this workgroup)")
             continue
@@ -126,6 +132,7 @@ def read():
         print("  self-attention stage: table / address prologue %.2f | wait for the qkv sums %.2f | q, k, v formed %.2f | cache rows arrive (barrier) %.2f | scores + softmax %.2f | P.V %.2f | sums + publish %.2f" % (
             np.mean(x[:, 16] - x[:, 0]), np.mean(x[:, 17] - x[:, 16]), np.mean(x[:, 18] - x[:, 17]), np.mean(x[:, 19] - x[:, 18]), np.mean(x[:, 20] - x[:, 19]),
             np.mean(x[:, 21] - x[:, 20]), np.mean(x[:, 22] - x[:, 21])))
+        print("    arrival of waves 0..7 at the stage's first barrier, us after (negative: before) wave 0 starts the layer:", " ".join("%.2f" % np.mean(x[:-1, 24 + w] - x[1:, 0]) for w in range(8)), "| released %.2f" % np.mean(x[:, 19] - x[:, 0]))
 
 
 if __name__ == "__main__":
