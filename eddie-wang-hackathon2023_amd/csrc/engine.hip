@@ -857,7 +857,7 @@ struct GroupStep {
         int ks = 0;
         if (i == 0) {
             step_done = false;
-            if (chain && g_decode_chain.load(std::memory_order_relaxed) >= 2 && e->dims.n_text_layer <= 62 && e->chain_lstat)
+            if (chain && g_decode_chain.load(std::memory_order_relaxed) >= 2 && e->dims.n_text_layer <= 32 && e->chain_lstat)
                 if (int rc = whole_step(s)) return rc;
         }
         if (step_done) return 0;

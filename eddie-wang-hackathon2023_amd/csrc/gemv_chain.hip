@@ -339,8 +339,8 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 // order, only the rows come from LDS, where waves 4-7 put them by DMA at the START of the launch (K and V do not depend on the
 // activations: their 96 KB fly while the chain's Linears run) instead of from memory through a register pipeline.
 constexpr int CHAIN_CROSS_KEYS = 1536;
-constexpr size_t CHAIN_DYN_LDS = 104 * 1024;      // K and V rows of a piece (beside ~ 52 KB of static LDS, of 160)
-constexpr int CHAIN_MAX_LAYERS = 62;               // (layer ids 0 .. 61 under the epoch's stage bits; 63 is "the projection before layer 0")
+constexpr size_t CHAIN_DYN_LDS = 100 * 1024;      // K and V rows of a piece (beside ~ 60 KB of static LDS, of 160)
+constexpr int CHAIN_MAX_LAYERS = 32;               // layers of a whole-step launch (their descriptors and tables sit in LDS; Whisper large has 32)
 // what the attention stages take per LAYER (kernel arguments for a one-layer launch, the two tables in a whole-step launch)
 struct ChainLayerArgs { const h16* cross_kv; const h16* cross_qbias; void* self_cache; const h16* self_bias; float self_kv_scale; };
 constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
@@ -808,8 +808,15 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     // every layer's first barrier -- on the critical path in the self-attention's workgroups
     __shared__ ChainLayerStatic s_lst[CHAIN_MAX_LAYERS];
     __shared__ ChainLayerIo s_lio[CHAIN_MAX_LAYERS];
-    if (whole) {
-        for (int i = threadIdx.x; i < p.n_layers; i += 512) { s_lst[i] = p.lstat[i]; s_lio[i] = p.lio[i]; }
+    // ... and so are the stage descriptors: a stage can request nothing before it has its descriptor, and from memory that was a
+    // (vector) load of its own at the head of every stage
+    constexpr int DESC_DW = (int)(sizeof(ChainStage) / 4);
+    __shared__ unsigned s_desc[(1 + 6 * CHAIN_MAX_LAYERS) * DESC_DW];
+    {
+        const int n_desc = whole ? 6 * p.n_layers : p.n_stages;             // (whole step: [qkv of layer 0] + 6 per layer - the last layer's missing sixth)
+        for (int i = threadIdx.x; i < n_desc * DESC_DW; i += 512) s_desc[i] = ((const unsigned*)p.st)[i];
+        if (whole)
+            for (int i = threadIdx.x; i < p.n_layers; i += 512) { s_lst[i] = p.lstat[i]; s_lio[i] = p.lio[i]; }
         __syncthreads();
     }
     // Who does what besides the Linears.  The cross-attention's (head, piece) items go to the LAST workgroups of the launch and the
@@ -844,7 +851,14 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
         const int s_first = l < 0 ? 5 : 0;
         const int s_end = !whole ? p.n_stages : (l < 0 ? 6 : (l + 1 < p.n_layers ? 6 : 5));
         for (int s = s_first; s < s_end; ++s) {
-            const ChainStage st = whole ? p.st[1 + 6 * l + s] : p.st[s];      // (uniform: scalar loads of a descriptor no kernel writes)
+            ChainStage st;                                                     // (uniform: the descriptor's words from LDS, made scalar)
+            {
+                unsigned raw[DESC_DW];
+                const int idx = whole ? 1 + 6 * l + s : s;
+#pragma unroll
+                for (int k = 0; k < DESC_DW; ++k) raw[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)s_desc[idx * DESC_DW + k]);
+                __builtin_memcpy(&st, raw, sizeof(st));
+            }
             const bool wide = (st.K / KT + TB - 1) / TB > 4;
             const unsigned epoch = epoch0 + (unsigned)s + 1;      // the tag this stage's results carry; its inputs carry epoch - 1
             int in_kind = CHAIN_IN_GRANULES;
