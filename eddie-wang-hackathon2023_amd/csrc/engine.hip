@@ -834,7 +834,10 @@ struct GroupStep {
         const int n = e->dims.n_text_layer;
         std::vector<ChainLayerIo> tab((size_t)n);
         for (int i = 0; i < n; ++i) tab[i] = ChainLayerIo{io->cross[i], io->present[i]};
-        {
+        if (io->workspace_id == 0) {                 // the caller vouches for nothing: the table is rewritten on every call
+            if (launch_chain_io_table(w.layer_io, tab.data(), n, s)) return 2;
+        } else {
+            tab.push_back(ChainLayerIo{(const void*)(uintptr_t)io->workspace_id, nullptr});       // (the id is part of what must match)
             std::lock_guard<std::mutex> lk(e->chain_io_mu);
             std::vector<ChainLayerIo>& seen = e->chain_io_seen[w.layer_io];
             const bool same = seen.size() == tab.size() && memcmp(seen.data(), tab.data(), tab.size() * sizeof(ChainLayerIo)) == 0;

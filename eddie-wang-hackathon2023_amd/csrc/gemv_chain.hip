@@ -1,12 +1,16 @@
-// ONE launch for a CHAIN of the small-batch path's fused Linears (gemv_small.hip) at one activation row -- the reference's own
-// operating point, batch 1 (W/run.py:43-46, W/decoding.py:785-821):
+// The decoder of a ONE-ROW group -- the reference's own operating point, batch 1 (W/run.py:43-46, W/decoding.py:785-821) -- as the
+// stages of one launch: a decoder layer is
 //
-//     [out projection + residual] -> [LayerNorm + cross-attention query projection]                      (2 stages)
-//     [out projection + residual] -> [LayerNorm + mlp1 + GELU] -> [mlp2 + residual] -> [LayerNorm + qkv of the next layer]   (4)
+//     self-attention (cache append included)  ->  out projection + residual  ->  LayerNorm + cross-attention query projection  ->
+//     cross-attention over 4 key-range pieces  ->  merge of the pieces + cross-attention out projection + residual  ->
+//     LayerNorm + mlp1 + GELU  ->  mlp2 + residual  ->  LayerNorm + qkv of the next layer
 //
-// so that a decoder layer is 5 launches instead of 9.  Replaces the same reference code as gemv_small.hip (weight_only_gemv_launcher,
-// weightOnlyMatrixVectorMultiplication.cu:136-277; the small-M branch of WeightOnlyQuantMatmulPlugin::enqueue; the element-wise
-// layers around the Linears, whisper/model.py:61-122) -- with gemv_small's arithmetic, bit for bit (tests/test_gpu_round4.py).
+// and the launch walks over the layers itself (or serves one layer per launch): 291 launches per token step become 4.  Replaces
+// the same reference code as gemv_small.hip (weight_only_gemv_launcher, weightOnlyMatrixVectorMultiplication.cu:136-277; the
+// small-M branch of WeightOnlyQuantMatmulPlugin::enqueue; the element-wise layers around the Linears, whisper/model.py:61-122) and
+// as attn_decode.hip's kernels (MaskedMultiheadAttention, decoderMaskedMultiheadAttentionTemplate.h:1195-2188, for the self- and the
+// cross-attention) -- with the arithmetic of gemv_small_kernel, attn_self_wg_kernel, attn_cross_kernel<1> and
+// attn_cross_combine_kernel, bit for bit (tests/test_gpu_round4.py).
 //
 // Why, and why only one row.  At batch 1 a token step is ~ 300 dependent launches of ~ 5.5 us: ~ 2.5 us of kernel boundary and
 // ~ 3 us of body, most of the body the round trip of the weights.  Rounds 2-3 removed launches by REDUNDANT recomputation and
@@ -16,15 +20,20 @@
 // the whole vector with 16-byte sc1 loads (all in flight, one wait) until every tag carries the stage's epoch -- no flag, no
 // fence, no barrier: 1.9 us per all-to-all edge for 2 048 halves, 2.6 us for 5 120, against 2.0-4.2 us for a kernel boundary
 // around a trivial body.  The edge grows with rows x width (4 rows: 3.5 us, 16 rows of 8-byte loads: 25 us) where a boundary
-// does not, so the chain serves ONE row; and a workgroup requests the weights of its next stage BEFORE it waits for that
-// stage's input, so the weights' round trip runs under the wait instead of behind it.
+// does not, so the launch serves ONE row.  What it wins is everything around the edges: a stage's weights (and scale, bias,
+// LayerNorm vectors) are requested BEFORE its input is waited for; the cross-attention's K / V rows and the self-attention's
+// cached rows are in LDS (by DMA, a stage or a layer ahead) before q exists; nothing a stage must have before it can request
+// anything else -- its descriptor, the per-layer pointers -- is read from memory (they are copied to LDS once per launch: each
+// such load was a microsecond in front of EVERY stage).  DESIGN.md section 5 "Batch 1" has the road and the stage timings.
 //
-// Structure.  Workgroups of eight waves, one per CU, alive for the whole chain.  A stage with K <= 4 x 320 inputs is run by
-// "slots" of four waves (a slot = one group of 16 output channels = gemv_small's workgroup: its waves split K as there, meet in
-// LDS in wave order), two slots per workgroup; K = 4 n_state (mlp2) by all eight waves as one slot, two K slices per wave,
-// the sixteen slices added in slice order as gemv_small's sixteen waves are.  The workgroup that owns channels 16 c .. 16 c + 15
-// of the residual stream owns them in every stage (its copy lives in LDS), so the residual adds need no exchange.
-// Every wait is bounded: a wave that gives up sets *err and the rest of the chain falls through (the host checks the word).
+// Structure.  256 workgroups of eight waves, one per CU, alive for the whole launch.  A Linear stage with K <= 4 x 320 inputs is
+// run by "slots" of four waves (a slot = one group of 16 output channels = gemv_small's workgroup: its waves split K as there,
+// meet in LDS in wave order), two slots per workgroup; K = 4 n_state (mlp2) by all eight waves as one slot, two K slices per
+// wave, the sixteen slices added in slice order as gemv_small's sixteen waves are.  The workgroup that owns channels 16 c ..
+// 16 c + 15 of the residual stream owns them in every stage (its copy lives in LDS), so the residual adds need no exchange.
+// The attention stages sit on workgroups that idle through most Linear stages: a self-attention head on each of the 20 before
+// the last 80, a cross-attention (head, piece) on each of the last 80 -- their upper four waves carry the DMA requests.
+// Every wait is bounded: a wave that gives up sets *err and the rest of the launch falls through (the host checks the word).
 #include <atomic>
 
 #include <type_traits>

@@ -82,7 +82,7 @@ EXPORTS = (
 )
 
 
-ABI_VERSION = 5          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
+ABI_VERSION = 6          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
 
 
 class WmError(RuntimeError):
@@ -116,6 +116,7 @@ class WmDecoderIO(C.Structure):
         ("qkv_amax", C.c_void_p),
         ("n_past_dev", C.c_void_p),
         ("live_rows", C.c_void_p),
+        ("workspace_id", C.c_uint64),
     ]
 
 

@@ -17,6 +17,7 @@ Besides the by-name `run` there are typed fast-path methods (`encoder_forward`, 
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import logging
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence
@@ -48,6 +49,9 @@ def str_dtype_to_torch(dtype: str) -> torch.dtype:
 
 def trt_dtype_to_torch(dtype: str) -> torch.dtype:
     return _STR_TO_TORCH[dtype]
+
+
+_WORKSPACE_IDS = itertools.count(1)      # identities of workspace allocations (wm_decoder_io.workspace_id), process-wide
 
 
 @dataclass
@@ -105,6 +109,7 @@ class Session(object):
             # zeroed: the decoder's one-row chain keeps a call counter and tagged granules in its workspace (csrc/gemv_chain.hip);
             # they must not start from whatever the allocator hands back
             ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=f"cuda:{self._device}")
+            ws._wm_id = next(_WORKSPACE_IDS)      # wm_decoder_io.workspace_id: a new identity for every (zeroed) allocation
             self._workspaces[key] = ws
         return ws
 
@@ -226,6 +231,7 @@ class Session(object):
         io.cross = C.cast(cross_arr, C.POINTER(C.c_void_p))
         io.logits = logits.data_ptr()
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+        io.workspace_id = getattr(ws, "_wm_id", 0)
         if qkv_amax is None:
             qkv_amax = self.qkv_amax          # calibration hook set by torch_whisper_convert.py
         io.qkv_amax = qkv_amax.data_ptr() if qkv_amax is not None else None

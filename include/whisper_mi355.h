@@ -51,8 +51,9 @@ typedef struct wm_dims {
  *      wm_gemm_rows, wm_set_rows_path
  *   4  wm_set_self_attn_waves
  *   5  (round 4) wm_set_gemm_small_tiles, wm_lab_knobs; environment knobs are honoured only under WM_LAB=1;
- *      wm_greedy_io gains the sampling fields (temperature, seed) and `without_timestamps` moves into the device rules   */
-#define WM_ABI_VERSION 5
+ *      wm_greedy_io gains the sampling fields (temperature, seed) and `without_timestamps` moves into the device rules
+ *   6  (round 4) wm_set_decode_chain / wm_decode_chain_error; wm_decoder_io gains `workspace_id` (appended)            */
+#define WM_ABI_VERSION 6
 int wm_version(void);
 const char* wm_last_error(void);
 int wm_device_count(int* out);
@@ -130,6 +131,11 @@ typedef struct wm_decoder_io {
      * their KV cache are no longer read, their rows of `logits` are left unspecified (finite) -- wm_greedy_step keeps such a
      * row at EOT whatever its logits.  A live row's result does not depend on which other rows are live. */
     const int32_t* live_rows;
+    /* identity of the workspace's CONTENTS (ABI 6): 0 = unknown.  The one-launch token step of a one-row group (wm_set_decode_chain)
+     * reads the per-layer `cross` / `present` pointers from a table it keeps inside the workspace; with a non-zero id the table is
+     * rewritten only when the pointers or the id differ from what the library last wrote at that address, with 0 on every call
+     * (four small launches).  Give every allocation of a workspace a new id, and a new one whenever it is zeroed or overwritten. */
+    uint64_t workspace_id;
 } wm_decoder_io;
 size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new);
 int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream);

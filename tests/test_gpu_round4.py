@@ -446,3 +446,39 @@ def test_one_row_chain_equals_the_launch_per_linear_path(tmp_path_factory, model
 
 def lib_():
     return native.load_library()
+
+
+def test_one_launch_step_rewrites_its_pointer_table_for_a_new_workspace():
+    """The one-launch token step reads the per-layer cross K/V and cache pointers from a table in the decoder workspace, rewritten only
+    when the pointers or `wm_decoder_io.workspace_id` differ from what the library last wrote at that address.  A second decoder
+    object in the same process is handed the SAME addresses by the caching allocator -- workspace, cross K/V, cache -- with the
+    workspace freshly zeroed: without the id the table would be taken for current and the launch would read null pointers.
+    Three decoders in a row over the same engine, buffers freed in between, must all produce the first one's tokens."""
+    import gc
+    import synthetic
+    from decoding import DecodingOptions, WhisperDecoding
+    from encoding import WhisperEncoding
+    from oracle.whisper_oracle import Dims, synthetic_mel
+    from test_gpu_model import build_engine
+    import tempfile
+    model = "tiny"
+    dims = Dims(**synthetic.DIMS[model])
+    eng = build_engine(tempfile.mkdtemp(), model, 3, True, True, [0.05 + 0.01 * i for i in range(dims.n_text_layer)])
+    enc = WhisperEncoding(eng)
+    mel = synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda()
+    outs, ws_ptrs = [], []
+    for rep in range(3):
+        dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=8))
+        xa = enc.get_audio_features(mel)
+        dec.detect_language(xa)
+        t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+        outs.append((t.cpu(), lp.cpu()))
+        ws_ptrs.append(sorted(w.data_ptr() for w in dec.decoder_session._workspaces.values()))
+        err = C.c_int(0)
+        native.check(lib_().wm_decode_chain_error(C.byref(err)))
+        assert err.value == 0
+        del dec, xa, t, lp
+        gc.collect()
+        torch.cuda.synchronize()
+    for t, lp in outs[1:]:
+        assert torch.equal(t, outs[0][0]) and torch.equal(lp, outs[0][1])
