@@ -14,11 +14,29 @@ struct FusedEpilogue {
     h16* x; int ldx;
 };
 
-// One 16 x 16 accumulator tile (MFMA C/D layout: lane -> channel nb * 16 + (lane & 15), rows mt * 16 + 4 (lane >> 4) + r)
-// whose values y[r] are the Linear's fp32 sums (scaled, K slices already combined).
-__device__ __forceinline__ void fused_epilogue_tile(const FusedEpilogue& e, int M, int nb, int mt, int lane, const float (&y)[4]) {
+// What the epilogue reads from memory besides the sums -- the channel's bias and, in mode 2, the tile's values of the residual
+// stream -- requested by the caller at the START of the kernel (fused_epilogue_prefetch) instead of behind the barrier that joins
+// the K slices: there they were a memory round trip of their own at the end of every launch.
+struct FusedEpiloguePre { float bias; h16 x[4]; };
+__device__ __forceinline__ FusedEpiloguePre fused_epilogue_prefetch(const FusedEpilogue& e, int M, int nb, int mt, int lane) {
     const int g = lane >> 4, col = nb * 16 + (lane & 15);
-    const float bias = (e.mode == 1 || e.mode == 2) && e.bias ? (float)e.bias[col] : 0.f;
+    FusedEpiloguePre pre;
+    pre.bias = (e.mode == 1 || e.mode == 2) && e.bias ? (float)e.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = min(mt * 16 + g * 4 + r, M - 1);                 // (rows past the end re-read the last one; never used)
+        pre.x[r] = e.mode == 2 ? e.x[(size_t)row * e.ldx + col] : (h16)0.f;
+    }
+    return pre;
+}
+
+// One 16 x 16 accumulator tile (MFMA C/D layout: lane -> channel nb * 16 + (lane & 15), rows mt * 16 + 4 (lane >> 4) + r)
+// whose values y[r] are the Linear's fp32 sums (scaled, K slices already combined).  pre: the tile's prefetched bias / residual
+// values, or nullptr (they are read here then).
+__device__ __forceinline__ void fused_epilogue_tile(const FusedEpilogue& e, int M, int nb, int mt, int lane, const float (&y)[4],
+                                                    const FusedEpiloguePre* pre = nullptr) {
+    const int g = lane >> 4, col = nb * 16 + (lane & 15);
+    const float bias = pre ? pre->bias : ((e.mode == 1 || e.mode == 2) && e.bias ? (float)e.bias[col] : 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = mt * 16 + g * 4 + r;
@@ -33,7 +51,8 @@ __device__ __forceinline__ void fused_epilogue_tile(const FusedEpilogue& e, int 
                 e.out16[(size_t)row * e.ld16 + col] = (h16)(e.gelu_kind == 2 ? gelu_tanh(y16) : gelu_erf(y16));
             } else {                                   // mode 2: residual stream, in place
                 h16* xp = e.x + (size_t)row * e.ldx + col;
-                *xp = (h16)r16((float)*xp + y16);
+                const h16 x_old = pre ? pre->x[r] : *xp;
+                *xp = (h16)r16((float)x_old + y16);
             }
         }
     }

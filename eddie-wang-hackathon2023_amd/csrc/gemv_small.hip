@@ -62,6 +62,14 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
     //   3. the wave's activation fragments (L2) -- with LayerNorm requested after the statistics (registers).
     // (No load below sits behind a per-element run-time test: hipcc branches around such a load and waits for each one
     // before the next -- a dependent round trip per element.  Out-of-range elements re-read the last valid one instead.)
+    // (the epilogue's per-channel scale, bias and residual values too: they used to be read behind the barrier that joins the
+    // K slices, a round trip at the end of every launch)
+    const int col = nb * 16 + rl;
+    const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
+    FusedEpilogue ep{p.mode, p.bias, p.gelu_kind, p.out32, p.ld32, p.out16, p.ld16, p.n_valid, p.x, p.ldx};
+    FusedEpiloguePre epre[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) epre[mt] = fused_epilogue_prefetch(ep, p.M, nb, mt, lane);
     const int pieces_per_row = p.K >> 3;
     constexpr int RB = 8, XP = 3;               // rows per wave and sweep (register budget); 16-byte pieces per lane and row (K <= 1536)
     uint4 xv[LN ? RB : 1][LN ? XP : 1];
@@ -201,8 +209,6 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
 
     // ---- K slices meet in LDS (each already multiplied by the per-channel scale, as the big-batch path's slabs are) and
     // are added in wave order by wave 0, which also runs the epilogue -----------------------------------------------------
-    const int col = nb * 16 + rl;
-    const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
     if (nwave > 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -213,7 +219,6 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
         __syncthreads();
         if (wid != 0) return;
     }
-    FusedEpilogue ep{p.mode, p.bias, p.gelu_kind, p.out32, p.ld32, p.out16, p.ld16, p.n_valid, p.x, p.ldx};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         float y[4];
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = acc[mt][r] * sc;
         }
-        fused_epilogue_tile(ep, p.M, nb, mt, lane, y);
+        fused_epilogue_tile(ep, p.M, nb, mt, lane, y, &epre[mt]);
     }
 }
 
