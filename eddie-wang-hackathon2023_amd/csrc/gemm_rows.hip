@@ -201,6 +201,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 5 : 4) void gemm_rows_kernel(Gem
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) xres[mt][r] = xsrc[(size_t)min(row0 + mt * 16 + g * 4 + r, p.M - 1) * xld];
+    // (the channel's scale and bias with them: read behind the K loop they were one more round trip at the end of every launch)
+    const int col = nb * 16 + rl;
+    const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
+    const float bias_pre = (p.mode == 1 || p.mode == 2) && p.bias ? (float)p.bias[col] : 0.f;
 
     // ---- K loop: RING tiles per round, every index a compile-time constant (register arrays indexed at run time live
     // in scratch memory); a tile's slot is refilled as soon as its MFMAs are issued ----------------------------------------
@@ -263,10 +267,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 5 : 4) void gemm_rows_kernel(Gem
     round(t0, std::false_type{});
 
     // ---- epilogue (epilogue.h: the rounding points of the row kernel) -------------------------------------------------------
-    const int col = nb * 16 + rl;
-    const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
     FusedEpilogue ep{p.mode, p.bias, p.gelu_kind, p.out32, p.ld32, p.out16, p.ld16, p.n_valid, p.x, p.ldx};
-    const float bias2 = add_x && p.bias ? (float)p.bias[col] : 0.f;
+    const float bias2 = add_x ? bias_pre : 0.f;
+    FusedEpiloguePre epre{};
+    epre.bias = bias_pre;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         float y[4];
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 5 : 4) void gemm_rows_kernel(Gem
                 if (row < p.M) p.x[(size_t)row * p.ldx + col] = (h16)r16((float)xres[mt][r] + r16(y[r] + bias2));
             }
         } else {
-            fused_epilogue_tile(ep, p.M, nb, ms * MT + mt, lane, y);
+            fused_epilogue_tile(ep, p.M, nb, ms * MT + mt, lane, y, &epre);       // (modes 0 and 1 here: the residual values of `epre` are not read)
         }
     }
 }
