@@ -612,9 +612,9 @@ def main():
                 b = in_situ_probe(dec, lib, last["xa"], B, n_micro, algo_bytes, beside=(enc, mel, args.encoder_cus))
                 roofline["in_situ_beside_encoder"] = {k.replace("in_situ_", ""): v for k, v in b.items() if k != "in_situ_note"}
         else:
-            # one-row utterance groups: the cross-attention is a stage of the in-launch chain (gemv_chain.hip), no launch of the
+            # one-row utterance groups: the cross-attention is a stage of the one-launch token step (gemv_chain.hip), no launch of the
             # K/V kernel exists to sample.  The token step as a whole is the unit then (decode_step_* below): achieved = its bytes / its time
-            roofline = {"kernel": "gemv_chain_kernel (one-row decode step: Linears, cross-attention pieces and merge in two launches per layer)",
+            roofline = {"kernel": "gemv_chain_kernel (one-row decode step: every layer's self-attention, Linears, cross-attention pieces and merge as stages of ONE launch)",
                         "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "note": "batch-1 groups: achieved / frac are the whole token step's (decode_step_bytes.total over decode_step_ms), "
                                 "a latency-bound chain of dependent stages, not a streaming kernel"}
