@@ -244,28 +244,34 @@ int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream) {
     WM_REQUIRE(p.ldc % 8 == 0 && p.ldr % 8 == 0, "gemm_f16: ldc/ldr must be multiples of 8 (16-byte epilogue accesses)");
     WM_REQUIRE(p.M > 0, "gemm_f16: empty M");
     WM_REQUIRE(p.act >= 0 && p.act <= 2, "gemm_f16: act=%d", p.act);
-    const int form = few ? 2 : (p.N % 256 == 0 ? 0 : 1);           // 0: 256 x 256, 1: 256 x 128, 2: 128 x 128 (4 waves, two workgroups per CU)
-    const int bm = form == 2 ? 128 : 256, bn = form == 0 ? 256 : 128;
+    // 0: 256 x 256, 1: 256 x 128, 2: 128 x 128 (4 waves, two workgroups per CU), 3: 64 x 128 (2 waves) when even the 128 x 128 tiles
+    // would leave more than a third of the CUs idle (ONE clip's n_state-wide projections: 120 tiles): a lone tile is bound by what
+    // its CU ingests, so twice the workgroups with three quarters of the bytes each are faster although they read 1.5 x as much in all
+    static const int tiny_max = lab_env_int("WM_GEMM_TINY_TILES", GEMM_TINY_TILES_DEFAULT);
+    const long tiles128 = (long)((p.M + 127) / 128) * (p.N / 128);
+    const int form = few ? (tiles128 <= tiny_max ? 3 : 2) : (p.N % 256 == 0 ? 0 : 1);
+    const int bm = form == 3 ? 64 : (form == 2 ? 128 : 256), bn = form == 0 ? 256 : 128;
     const int grid = ((p.M + bm - 1) / bm) * (p.N / bn);
     static std::atomic<unsigned long long> attr_set{0};             // per device: the dynamic-LDS attribute is a per-device property
     int dev = 0;
     WM_CHECK_HIP(hipGetDevice(&dev));
     const int slot = dev & 63;
     using Kern = void (*)(GemmBigParams);
-    static const Kern kerns[3][3] = {{gemm_f16_kernel<8, 256, 0>, gemm_f16_kernel<8, 256, 1>, gemm_f16_kernel<8, 256, 2>},
+    static const Kern kerns[4][3] = {{gemm_f16_kernel<8, 256, 0>, gemm_f16_kernel<8, 256, 1>, gemm_f16_kernel<8, 256, 2>},
                                      {gemm_f16_kernel<8, 128, 0>, gemm_f16_kernel<8, 128, 1>, gemm_f16_kernel<8, 128, 2>},
-                                     {gemm_f16_kernel<4, 128, 0>, gemm_f16_kernel<4, 128, 1>, gemm_f16_kernel<4, 128, 2>}};
-    static const int rows_of[3] = {256, 256, 128}, cols_of[3] = {256, 128, 128};
+                                     {gemm_f16_kernel<4, 128, 0>, gemm_f16_kernel<4, 128, 1>, gemm_f16_kernel<4, 128, 2>},
+                                     {gemm_f16_kernel<2, 128, 0>, gemm_f16_kernel<2, 128, 1>, gemm_f16_kernel<2, 128, 2>}};
+    static const int rows_of[4] = {256, 256, 128, 64}, cols_of[4] = {256, 128, 128, 128};
     const unsigned long long bit = 1ull << slot;
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        for (int f = 0; f < 3; ++f)
+        for (int f = 0; f < 4; ++f)
             for (int a = 0; a < 3; ++a)
                 WM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[f][a], hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  2 * (rows_of[f] + cols_of[f]) * BK * 2));
         attr_set.fetch_or(bit, std::memory_order_release);
     }
     const size_t lds = (size_t)2 * (bm + bn) * BK * 2;              // the two-stage K-tile ring
-    hipLaunchKernelGGL(kerns[form][p.act], dim3(grid), dim3(form == 2 ? 256 : 512), lds, stream, p);
+    hipLaunchKernelGGL(kerns[form][p.act], dim3(grid), dim3(form == 3 ? 128 : (form == 2 ? 256 : 512)), lds, stream, p);
     WM_LAUNCH_CHECK(stream, "gemm_f16");
     return 0;
 }

@@ -28,7 +28,8 @@ struct GemmBigParams {
 };
 int launch_gemm_f16(const GemmBigParams& p, hipStream_t stream);      // dispatch: gemm_f16p.hip when it supports the shape and the launch has enough tiles, else gemm_f16.hip's kernels
 // launches with fewer 256 x 256 tiles than this run 128 x 128 tiles, two workgroups per CU (gemm_f16.hip; bit-identical results)
-constexpr int GEMM_SMALL_TILES_DEFAULT = 192;
+constexpr int GEMM_SMALL_TILES_DEFAULT = 150;
+constexpr int GEMM_TINY_TILES_DEFAULT = 160;       // at most this many 128 x 128 tiles: 64 x 128 tiles instead (gemm_f16.hip)
 void set_gemm_small_tiles(int tiles);     // 0: never the small form; < 0: the default
 int get_gemm_small_tiles();
 int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream);     // persistent 256x256 tiles, continuous LDS-DMA stream, alternating wave groups

@@ -269,8 +269,9 @@ int wm_set_rows_path(int min_rows);
  * orders; the cache they append is identical.  Captured graphs keep the form they were captured with.                       */
 int wm_set_self_attn_waves(int waves);
 /* The MFMA-bound GEMMs (encoder layers, convolutions, cross-K/V projection; wm_gemm, wm_conv1d_gelu) pick their tile by the
- * size of the launch: with fewer than `tiles` 256 x 256 output tiles (default 192: one to four clips of large-v2, by shape) the launch
- * runs 128 x 128 tiles, two workgroups per CU, else the persistent 256 x 256 kernel.  0 = never the small form, < 0 = the
+ * size of the launch: with fewer than `tiles` 256 x 256 output tiles (default 150: one to four clips of large-v2, by shape) the launch
+ * runs 128 x 128 tiles, two workgroups per CU (64 x 128 when even those would leave a third of the CUs idle: one clip's
+ * n_state-wide projections), else the persistent 256 x 256 kernel.  0 = never the small form, < 0 = the
  * default.  Returns the previous value.  Both forms add an output element's products in the same order and share the
  * epilogue arithmetic: the results are bit-identical, a clip's encoder output does not depend on the batch it is in.     */
 int wm_set_gemm_small_tiles(int tiles);

@@ -62,7 +62,7 @@ def test_gemm_small_tiles_bit_identical(lib, M, N, K, act, resid):
 def test_gemm_tile_switch_default_and_setter(lib):
     prev = lib.wm_set_gemm_small_tiles(7)
     assert lib.wm_set_gemm_small_tiles(-1) == 7
-    assert lib.wm_set_gemm_small_tiles(prev) == 192
+    assert lib.wm_set_gemm_small_tiles(prev) == 150
 
 
 # ------------------------------------------------------------------------------------------ greedy step, without_timestamps
