@@ -24,13 +24,14 @@ __device__ unsigned long long g_stamps2[64 * 8 * 8];
 // directly would be waited for (its acknowledgement, ~ 2 us) at the next workgroup barrier and measure mostly itself.
 __shared__ unsigned long long s_stamps[32 + 64];
 __shared__ int s_stamp_layer;
+__shared__ unsigned long long s_arrive[8];
 extern "C" int wm_lab_chain_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps2), sizeof(g_stamps2)); }
 #define STAMP_ON (threadIdx.x == 0 && blockIdx.x == WM_STAMP_WG)
 #define STAMP(k) do { if (STAMP_ON) s_stamps[k] = wall_clock64(); } while (0)
 #define STAMP2(k) do { if (STAMP_ON) s_stamps[32 + s * 8 + (k)] = wall_clock64(); } while (0)
 #define STAMP_FLUSH(layer) do { if (STAMP_ON) { const int pl = s_stamp_layer; if (pl >= 0 && pl < 64) { for (int i_ = 0; i_ < 32; ++i_) g_stamps[pl * 32 + i_] = s_stamps[i_]; \\
-    for (int i_ = 0; i_ < 64; ++i_) g_stamps2[pl * 64 + i_] = s_stamps[32 + i_]; } for (int i_ = 0; i_ < 96; ++i_) if (i_ < 24 || i_ >= 32) s_stamps[i_] = 0; s_stamp_layer = (layer); } } while (0)
+    for (int i_ = 0; i_ < 64; ++i_) g_stamps2[pl * 64 + i_] = s_stamps[32 + i_]; } for (int i_ = 0; i_ < 96; ++i_) s_stamps[i_] = 0; s_stamp_layer = (layer); } } while (0)
 // Where a stage without LayerNorm takes its input row from (wave-uniform):''', 1)
     s = ins_before(s, '    // ---- 1. every weight tile', '    STAMP2(0);\n')
     s = ins_after(s, '                ok = sweep_granules16<2 * XP>(p.gran_x, first, epoch - 1, val, p.err, lane);\n', '                STAMP2(1);\n')
@@ -56,10 +57,11 @@ extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipM
     body = s[a:b].replace('        q = r16(q + bq);', '        STAMP(17);\n        q = r16(q + bq);', 1)
     parts = body.split('    __syncthreads();\n')
     assert len(parts) == 7, len(parts)
-    body = (parts[0] + '    STAMP(18);\n    if (blockIdx.x == WM_STAMP_WG && lane == 0) s_stamps[24 + wid] = wall_clock64();\n    __syncthreads();\n' + parts[1] + '    __syncthreads();\n    STAMP(19);\n' + parts[2] + '    __syncthreads();\n' + parts[3]
+    body = (parts[0] + '    STAMP(18);\n    if (blockIdx.x == WM_STAMP_WG && lane == 0) s_arrive[wid] = wall_clock64();\n    __syncthreads();\n    STAMP(19);\n    if (STAMP_ON) for (int w_ = 0; w_ < 8; ++w_) s_stamps[24 + w_] = s_arrive[w_];\n' + parts[1] + '    __syncthreads();\n' + parts[2] + '    __syncthreads();\n' + parts[3]
             + '    __syncthreads();\n    STAMP(20);\n' + parts[4] + '    __syncthreads();\n    STAMP(21);\n' + parts[5] + '    STAMP(22);\n    __syncthreads();\n' + parts[6])
     body = body.replace('    const float t_dq = la.self_kv_scale;', '    STAMP(16);\n    const float t_dq = la.self_kv_scale;', 1)
     s = s[:a] + body + s[b:]
+    s = s.replace('constexpr size_t CHAIN_DYN_LDS = 100 * 1024;', 'constexpr size_t CHAIN_DYN_LDS = 97 * 1024;      // (lab: room for the stamps)', 1)
     out = os.path.join(ROOT, "build/lab")
     os.makedirs(out, exist_ok=True)
     open(os.path.join(out, "gemv_chain_stamps.hip"), "w").write(s)
@@ -129,10 +131,10 @@ def read():
         print("  cross-attention stage: cq end -> q swept %.2f | scores %.2f | max / exp / sum %.2f | P.V %.2f | sums + publish %.2f" % (
             np.mean(x[:, 11] - x[:, 2]), np.mean(x[:, 12] - x[:, 11]), np.mean(x[:, 13] - x[:, 12]), np.mean(x[:, 14] - x[:, 13]), np.mean(x[:, 8] - x[:, 14])))
     if st[1, 22] > st[1, 16] > 0:
-        print("  self-attention stage: table / address prologue %.2f | wait for the qkv sums %.2f | q, k, v formed %.2f | cache rows arrive (barrier) %.2f | scores + softmax %.2f | P.V %.2f | sums + publish %.2f" % (
+        print("  self-attention stage: table / address prologue %.2f | wait for the qkv sums %.2f | q, k, v formed %.2f | first barrier %.2f | scores + softmax (2 barriers) %.2f | P.V %.2f | sums + publish %.2f" % (
             np.mean(x[:, 16] - x[:, 0]), np.mean(x[:, 17] - x[:, 16]), np.mean(x[:, 18] - x[:, 17]), np.mean(x[:, 19] - x[:, 18]), np.mean(x[:, 20] - x[:, 19]),
             np.mean(x[:, 21] - x[:, 20]), np.mean(x[:, 22] - x[:, 21])))
-        print("    arrival of waves 0..7 at the stage's first barrier, us after (negative: before) wave 0 starts the layer:", " ".join("%.2f" % np.mean(x[:-1, 24 + w] - x[1:, 0]) for w in range(8)), "| released %.2f" % np.mean(x[:, 19] - x[:, 0]))
+        print("    arrival of waves 0..7 at the stage's first barrier, us after (negative: before) wave 0 starts the layer:", " ".join("%.2f" % np.mean(x[:, 24 + w] - x[:, 0]) for w in range(8)), "| released %.2f" % np.mean(x[:, 19] - x[:, 0]))
 
 
 if __name__ == "__main__":
