@@ -17,15 +17,21 @@ struct FusedEpilogue {
 // What the epilogue reads from memory besides the sums -- the channel's bias and, in mode 2, the tile's values of the residual
 // stream -- requested by the caller at the START of the kernel (fused_epilogue_prefetch) instead of behind the barrier that joins
 // the K slices: there they were a memory round trip of their own at the end of every launch.
-struct FusedEpiloguePre { float bias; h16 x[4]; };
-__device__ __forceinline__ FusedEpiloguePre fused_epilogue_prefetch(const FusedEpilogue& e, int M, int nb, int mt, int lane) {
+// The loads are UNCONDITIONAL (a mode that has no bias / no residual reads a few bytes of `any`, a valid address, and drops them):
+// behind a run-time test hipcc branches around a load and waits for it inside the branch.
+struct FusedEpiloguePre { h16 bias_raw; bool has_bias; h16 x[4]; __device__ float bias() const { return has_bias ? (float)bias_raw : 0.f; } };
+__device__ __forceinline__ FusedEpiloguePre fused_epilogue_prefetch(const FusedEpilogue& e, int M, int nb, int mt, int lane, const void* any) {
     const int g = lane >> 4, col = nb * 16 + (lane & 15);
     FusedEpiloguePre pre;
-    pre.bias = (e.mode == 1 || e.mode == 2) && e.bias ? (float)e.bias[col] : 0.f;
+    pre.has_bias = (e.mode == 1 || e.mode == 2) && e.bias != nullptr;
+    pre.bias_raw = *((pre.has_bias ? e.bias : (const h16*)any) + (pre.has_bias ? col : 0));
+    const bool add_x = e.mode == 2;
+    const h16* xs = add_x ? e.x + col : (const h16*)any;
+    const size_t xld = add_x ? (size_t)e.ldx : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = min(mt * 16 + g * 4 + r, M - 1);                 // (rows past the end re-read the last one; never used)
-        pre.x[r] = e.mode == 2 ? e.x[(size_t)row * e.ldx + col] : (h16)0.f;
+        pre.x[r] = xs[(size_t)row * xld];
     }
     return pre;
 }
@@ -36,7 +42,7 @@ __device__ __forceinline__ FusedEpiloguePre fused_epilogue_prefetch(const FusedE
 __device__ __forceinline__ void fused_epilogue_tile(const FusedEpilogue& e, int M, int nb, int mt, int lane, const float (&y)[4],
                                                     const FusedEpiloguePre* pre = nullptr) {
     const int g = lane >> 4, col = nb * 16 + (lane & 15);
-    const float bias = pre ? pre->bias : ((e.mode == 1 || e.mode == 2) && e.bias ? (float)e.bias[col] : 0.f);
+    const float bias = pre ? pre->bias() : ((e.mode == 1 || e.mode == 2) && e.bias ? (float)e.bias[col] : 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = mt * 16 + g * 4 + r;

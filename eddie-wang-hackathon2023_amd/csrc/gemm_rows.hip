@@ -202,9 +202,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 5 : 4) void gemm_rows_kernel(Gem
 #pragma unroll
         for (int r = 0; r < 4; ++r) xres[mt][r] = xsrc[(size_t)min(row0 + mt * 16 + g * 4 + r, p.M - 1) * xld];
     // (the channel's scale and bias with them: read behind the K loop they were one more round trip at the end of every launch)
+    // (unconditional loads, converted behind the K loop: a load behind a run-time test is waited for inside its branch)
     const int col = nb * 16 + rl;
-    const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
-    const float bias_pre = (p.mode == 1 || p.mode == 2) && p.bias ? (float)p.bias[col] : 0.f;
+    const bool has_scale = WB != 16 && p.scale != nullptr, has_bias = (p.mode == 1 || p.mode == 2) && p.bias != nullptr;
+    const h16 sc_raw = *((has_scale ? p.scale : (const h16*)p.Wt) + (has_scale ? col : 0));
+    const h16 bias_raw = *((has_bias ? p.bias : (const h16*)p.Wt) + (has_bias ? col : 0));
 
     // ---- K loop: RING tiles per round, every index a compile-time constant (register arrays indexed at run time live
     // in scratch memory); a tile's slot is refilled as soon as its MFMAs are issued ----------------------------------------
@@ -267,10 +269,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 5 : 4) void gemm_rows_kernel(Gem
     round(t0, std::false_type{});
 
     // ---- epilogue (epilogue.h: the rounding points of the row kernel) -------------------------------------------------------
+    const float sc = has_scale ? (float)sc_raw : 1.0f;
     FusedEpilogue ep{p.mode, p.bias, p.gelu_kind, p.out32, p.ld32, p.out16, p.ld16, p.n_valid, p.x, p.ldx};
-    const float bias2 = add_x ? bias_pre : 0.f;
+    const float bias2 = add_x && has_bias ? (float)bias_raw : 0.f;
     FusedEpiloguePre epre{};
-    epre.bias = bias_pre;
+    epre.bias_raw = bias_raw; epre.has_bias = has_bias;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         float y[4];

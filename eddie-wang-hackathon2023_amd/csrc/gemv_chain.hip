@@ -121,9 +121,12 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 
     // ---- 1. every weight tile of this wave's K slices is requested now, before anything is waited for -- and the epilogue's
     // per-channel scale and bias with them (requested in the epilogue they were a memory round trip of their own) -------------
+    // (UNCONDITIONAL loads, converted where they are used: behind a run-time test hipcc branches around the load and waits for it
+    // inside the branch -- two round trips in a row at the head of the stage, ahead of the weight requests)
     const int col = nb * 16 + rl;
-    const float sc = (WB != 16 && st.scale) ? (float)CHAIN_GLOBAL(h16, st.scale)[col] : 1.0f;
-    const float bias = (st.mode == 1 || st.mode == 2) && st.bias ? (float)CHAIN_GLOBAL(h16, st.bias)[col] : 0.f;
+    const bool has_scale = WB != 16 && st.scale != nullptr, has_bias = (st.mode == 1 || st.mode == 2) && st.bias != nullptr;
+    const h16 sc_raw = *(CHAIN_GLOBAL(h16, has_scale ? (const void*)st.scale : st.Wt) + (has_scale ? col : 0));
+    const h16 bias_raw = *(CHAIN_GLOBAL(h16, has_bias ? (const void*)st.bias : st.Wt) + (has_bias ? col : 0));
     u32x4 wreg[NS][TB];
     int t_begin[NS], t_end[NS];
 #pragma unroll
@@ -254,6 +257,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     }
 
     // ---- 3. multiply (gemv_small's loop), K slices to LDS scaled, in slice order ------------------------------------------
+    const float sc = has_scale ? (float)sc_raw : 1.0f;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
@@ -310,6 +314,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             for (int r = 0; r < 4; ++r) sum[r] += tw[r];
         }
         const float y = sum[0];                               // row 0 (lanes 0-15); the other lanes hold rows that do not exist
+        const float bias = has_bias ? (float)bias_raw : 0.f;
         if (st.mode == 0) {
             if (g == 0) {
                 p.out32[col] = y;                             // raw sums for the attention kernel of the next launch

@@ -64,12 +64,14 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
     // before the next -- a dependent round trip per element.  Out-of-range elements re-read the last valid one instead.)
     // (the epilogue's per-channel scale, bias and residual values too: they used to be read behind the barrier that joins the
     // K slices, a round trip at the end of every launch)
+    // -- all of them unconditional loads, converted where they are used (a load behind a run-time test is waited for inside its branch)
     const int col = nb * 16 + rl;
-    const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
+    const bool has_scale = WB != 16 && p.scale != nullptr;
+    const h16 sc_raw = *((has_scale ? p.scale : (const h16*)p.Wt) + (has_scale ? col : 0));
     FusedEpilogue ep{p.mode, p.bias, p.gelu_kind, p.out32, p.ld32, p.out16, p.ld16, p.n_valid, p.x, p.ldx};
     FusedEpiloguePre epre[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) epre[mt] = fused_epilogue_prefetch(ep, p.M, nb, mt, lane);
+    for (int mt = 0; mt < MT; ++mt) epre[mt] = fused_epilogue_prefetch(ep, p.M, nb, mt, lane, p.Wt);
     const int pieces_per_row = p.K >> 3;
     constexpr int RB = 8, XP = 3;               // rows per wave and sweep (register budget); 16-byte pieces per lane and row (K <= 1536)
     uint4 xv[LN ? RB : 1][LN ? XP : 1];
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
 
     // ---- K slices meet in LDS (each already multiplied by the per-channel scale, as the big-batch path's slabs are) and
     // are added in wave order by wave 0, which also runs the epilogue -----------------------------------------------------
+    const float sc = has_scale ? (float)sc_raw : 1.0f;
     if (nwave > 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
