@@ -86,6 +86,11 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
     for (int i = 0; i < p.L; ++i) {
         const int m = b * p.L + i;
         float q = 0.f, k = 0.f, v = 0.f;
+        // (the three biases: unconditional loads in flight with the slabs -- behind `p.bias ? ... : 0` each was waited for inside its
+        // branch, three round trips in a row; without a bias a few bytes of the slab are read and dropped)
+        const h16* bsrc = p.bias ? p.bias + h * 64 + lane : (const h16*)p.part;
+        const int bstep = p.bias ? C : 0;
+        const h16 bq_raw = bsrc[0], bk_raw = bsrc[bstep], bv_raw = bsrc[2 * bstep];
         {
             const float* row = p.part + (size_t)m * p.ldp + h * 64 + lane;
             int s = 0;
@@ -102,9 +107,9 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
                 q += r0[0]; k += r0[C]; v += r0[2 * C];
             }
         }
-        q = r16(q + (p.bias ? (float)p.bias[h * 64 + lane] : 0.f));
-        k = r16(k + (p.bias ? (float)p.bias[C + h * 64 + lane] : 0.f));
-        v = r16(v + (p.bias ? (float)p.bias[2 * C + h * 64 + lane] : 0.f));
+        q = r16(q + (p.bias ? (float)bq_raw : 0.f));
+        k = r16(k + (p.bias ? (float)bk_raw : 0.f));
+        v = r16(v + (p.bias ? (float)bv_raw : 0.f));
         if (p.amax) {     // calibration hook: max |q|,|k|,|v| of this layer (smoothquant.py:117-175, F8)
             const float a = wave_max_nomfma(fmaxf(fabsf(q), fmaxf(fabsf(k), fabsf(v))));
             if (lane == 0) atomicMax((unsigned int*)p.amax, __float_as_uint(a));   // a >= 0: bit order = value order
@@ -311,6 +316,9 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
         for (int i = 0; i < p.L; ++i) {
             const int m = b * p.L + i;
             float q = 0.f, k = 0.f, v = 0.f;
+            const h16* bsrc = p.bias ? p.bias + h * 64 + lane : (const h16*)p.part;      // (unconditional bias loads: see attn_self_kernel)
+            const int bstep = p.bias ? C : 0;
+            const h16 bq_raw = bsrc[0], bk_raw = bsrc[bstep], bv_raw = bsrc[2 * bstep];
             const float* row = p.part + (size_t)m * p.ldp + h * 64 + lane;
             int s = 0;
             for (; s + 4 <= p.ksplit; s += 4) {    // the one-wave form's order of additions
@@ -325,9 +333,9 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
                 const float* r0 = row + (size_t)s * sstride;
                 q += r0[0]; k += r0[C]; v += r0[2 * C];
             }
-            q = r16(q + (p.bias ? (float)p.bias[h * 64 + lane] : 0.f));
-            k = r16(k + (p.bias ? (float)p.bias[C + h * 64 + lane] : 0.f));
-            v = r16(v + (p.bias ? (float)p.bias[2 * C + h * 64 + lane] : 0.f));
+            q = r16(q + (p.bias ? (float)bq_raw : 0.f));
+            k = r16(k + (p.bias ? (float)bk_raw : 0.f));
+            v = r16(v + (p.bias ? (float)bv_raw : 0.f));
             if (p.amax) {     // calibration hook (see attn_self_kernel)
                 const float a = wave_max_nomfma(fmaxf(fabsf(q), fmaxf(fabsf(k), fabsf(v))));
                 if (lane == 0) atomicMax((unsigned int*)p.amax, __float_as_uint(a));

@@ -392,7 +392,12 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     const int first = (wid & 3) * (RPI * UNR);
     const bool worker = wid < 4 && has_item && nkeys > 0;
     half8v qb8 = half8v{0, 0, 0, 0, 0, 0, 0, 0};                              // the lane's 8 q-bias values: requested now, not behind the wait for q
-    if (has_item && nkeys > 0 && la.cross_qbias) qb8 = *(const half8v*)(la.cross_qbias + h * 64 + sub * DPL);
+    {                                                                      // (unconditional: no wait inside a branch)
+        const bool hb = has_item && nkeys > 0 && la.cross_qbias != nullptr;
+        const half8v raw = *(const half8v*)(hb ? la.cross_qbias + h * 64 + sub * DPL : (const h16*)p.st);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) qb8[e] = hb ? raw[e] : (h16)0.f;
+    }
     if (wid >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's K / V pieces have landed
     if (wid == 0 && has_item) {                                               // the head's 64 q sums, as the last Linear published them
         int fst[1] = {h * 64 + 2 * min(lane, 31)};
@@ -643,9 +648,10 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     float k_new = 0.f, v_new = 0.f;
     if (wid == 0) {                                   // this call's q, k, v of the head (lane = dim): one slab, bias, fp16
         float q = 0.f, k = 0.f, v = 0.f;
-        const float bq = la.self_bias ? (float)la.self_bias[h * 64 + lane] : 0.f;              // (requested ahead of the wait for the sums)
-        const float bk = la.self_bias ? (float)la.self_bias[C + h * 64 + lane] : 0.f;
-        const float bv = la.self_bias ? (float)la.self_bias[2 * C + h * 64 + lane] : 0.f;
+        // (requested ahead of the wait for the sums, as UNCONDITIONAL loads: behind `bias ? ... : 0` each is waited for in its branch)
+        const h16* bsrc = la.self_bias ? la.self_bias + h * 64 + lane : (const h16*)p.st;
+        const int bstep = la.self_bias ? C : 0;
+        const h16 bq_raw = bsrc[0], bk_raw = bsrc[bstep], bv_raw = bsrc[2 * bstep];
         if (p.gran_s) {                               // the sums the qkv stage of THIS launch has just published (the whole step in one launch)
             int first[3] = {h * 64 + 2 * min(lane, 31), C + h * 64 + 2 * min(lane, 31), 2 * C + h * 64 + 2 * min(lane, 31)};
             u32x4 val[3];
@@ -665,9 +671,9 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
             const float* row = p.self_part + h * 64 + lane;
             q += row[0]; k += row[C]; v += row[2 * C];
         }
-        q = r16(q + bq);
-        k = r16(k + bk);
-        v = r16(v + bv);
+        q = r16(q + (la.self_bias ? (float)bq_raw : 0.f));
+        k = r16(k + (la.self_bias ? (float)bk_raw : 0.f));
+        v = r16(v + (la.self_bias ? (float)bv_raw : 0.f));
         s_knew[lane] = (h16)k;
         s_vnew[lane] = (h16)v;
         k_new = k; v_new = v;                         // (the cache append waits for the end of the stage: see there)
