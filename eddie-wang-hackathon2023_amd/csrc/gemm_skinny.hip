@@ -62,6 +62,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
     const int bn = blockIdx.x % nwg_n, ks = blockIdx.x / nwg_n;
     const int nb = bn * NW + wid;                          // this wave's 16-channel block
     const bool wave_active = nb < p.n_blocks;
+    // the per-channel scale of the epilogue: an unconditional load, requested now (read behind the K loop -- and behind a test, which
+    // makes hipcc wait for it inside the branch -- it was a round trip of its own at the end of every launch)
+    const bool has_scale = WB != 16 && p.scale != nullptr;
+    const h16 sc_raw = *((has_scale ? p.scale : (const h16*)p.Wt) + (has_scale && wave_active ? nb * 16 + (lane & 15) : 0));
 
     const int kt_total = p.K / KT;
     const int tps = (kt_total + p.ksplit - 1) / p.ksplit;  // tiles per split
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmSkinnyParams p
 
     if (!wave_active) return;
     const int col = nb * 16 + (lane & 15);
-    const float sc = (WB != 16 && p.scale) ? (float)p.scale[col] : 1.0f;
+    const float sc = has_scale ? (float)sc_raw : 1.0f;
     const int ldp = p.n_blocks * 16;
     const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.M * ldp;
 #pragma unroll
