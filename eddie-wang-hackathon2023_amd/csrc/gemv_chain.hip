@@ -632,8 +632,10 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     const unsigned char* pastK = in_lds ? lds_rows : (const unsigned char*)la.self_cache + ((size_t)(0 * H + h) * p.self_cap * 64) * ES;
     const unsigned char* pastV = in_lds ? lds_rows + lds_v_off : (const unsigned char*)la.self_cache + ((size_t)(1 * H + h) * p.self_cap * 64) * ES;
     const int vr = lane / NCH, vc = lane % NCH;
+    // the first K block and the first four V blocks of this wave into registers, all requests in flight together: from memory at the
+    // stage's start, or -- rows that chain_self_prefetch has put into LDS -- behind the stage's first barrier, when they have landed
     uint4 kpre[KCH], vpre[VPRE];
-    if (worker && T > 0 && !in_lds) {
+    auto rows_to_registers = [&]() {
         const int kr = min(64 * wid + lane, T - 1);
 #pragma unroll
         for (int c = 0; c < KCH; ++c) kpre[c] = ((const uint4*)(pastK + (size_t)kr * ROW_B))[c];
@@ -642,7 +644,8 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
             const int row = min((wid + NW * n) * VROWS + vr, T - 1);
             vpre[n] = *(const uint4*)(pastV + (size_t)row * ROW_B + vc * 16);
         }
-    }
+    };
+    if (worker && T > 0 && !in_lds) rows_to_registers();
     const float t_dq = la.self_kv_scale;
     const float inv_t = 1.0f / la.self_kv_scale;
     float k_new = 0.f, v_new = 0.f;
@@ -680,6 +683,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
         s_q[lane] = (h16)r16(q * SCALE);
     }
     __syncthreads();
+    if (worker && T > 0 && in_lds) rows_to_registers();
     const int nk = T + 1;
     float mx = -INFINITY;
     if (worker) {
@@ -692,7 +696,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
                     const uint4* kr = (const uint4*)(pastK + (size_t)j * ROW_B);
 #pragma unroll
                     for (int c = 0; c < KCH; ++c) {
-                        const uint4 w = (kb == wid && !in_lds) ? kpre[c] : kr[c];
+                        const uint4 w = kb == wid ? kpre[c] : kr[c];
                         if (I8) {
                             const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -759,10 +763,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
 #pragma unroll
         for (int n = 0; n < VPRE; ++n) {
             const int vb = wid + NW * n;
-            if (vb * VROWS < T) {
-                if (in_lds) add_block(vb, *(const uint4*)(pastV + (size_t)min(vb * VROWS + vr, T - 1) * ROW_B + vc * 16));
-                else add_block(vb, vpre[n]);
-            }
+            if (vb * VROWS < T) add_block(vb, vpre[n]);
         }
         for (int vb = wid + NW * VPRE; vb * VROWS < T; vb += NW) {
             const int row = min(vb * VROWS + vr, T - 1);

@@ -1,0 +1,66 @@
+"""Build-time lint of the decode path's kernels (no GPU needed): a memory load whose NEXT instruction is a full `s_waitcnt vmcnt(0)`.
+hipcc compiles `p ? p[i] : 0` (and any load behind a run-time test) to a branch with the load AND its wait inside: the wave stops
+for a memory round trip right there, and for everything it requested before -- two such "prefetches" in a row are two round
+trips in a row.  Round 4 found the pattern in front of every stage of the one-launch decoder, every gemv_small / gemm_rows /
+gemm_skinny launch and every self-attention launch (bias and scale loads): batch 1 1.145 -> 1.075 ms per token, batch 8 2.20 ->
+2.07.  Waits written by hand (inline assembly: the granule sweeps) are not counted.  Known, accepted
+sites are listed with their reason; anything above them fails.
+    python scripts/check_late_loads.py            # prints the sites per kernel"""
+import os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "eddie-wang-hackathon2023_amd", "csrc")
+# kernel-name pattern -> allowed sites, why
+ALLOWED = [
+    (r"gemv_chain_kernelILi(4|8|16)ELb[01]E", 12, "seven polls of the error word inside bounded waits (every 64th spin), the first residual read of a launch (p.x: twice, once per stage form), the self-attention's K block beyond 64 cached keys, the qkv sums read back from LDS through a flat pointer"),
+    (r"gemv_small_kernelILi(4|8|16)ELi1E", 1, "M <= 16 forms: the fp16 logits form's single fragment load"),
+    (r"gemv_small_kernelILi(4|8|16)ELi2E", 16, "17-32-row forms (not used: the small path serves <= 16 rows)"),
+    (r"gemm_rows_kernel", 0, ""),
+    (r"gemm_skinny_kernel", 0, ""),
+    (r"attn_self(_wg)?_kernel", 2, "the live-row entry and the device-resident token count, which everything else depends on"),
+    (r"attn_cross_kernel", 2, "live-row entry and q bias per item: removing them shortens the launch in situ and LENGTHENS the token step (profiles/r4u_*)"),
+    (r"attn_cross_combine_kernel", 1, ""),
+]
+FILES = ["gemv_chain.hip", "gemv_small.hip", "gemm_rows.hip", "gemm_skinny.hip", "attn_decode.hip"]
+
+
+def sites(path):
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                        "-S", "--cuda-device-only", "-o", asm, path], check=True, stderr=subprocess.DEVNULL)
+        fn, last_load, in_asm = None, -9, False
+        for n, line in enumerate(open(asm)):
+            t = line.strip()
+            if re.match(r"^_ZN[\w]+:", t):
+                fn, last_load = t.split(":")[0], -9
+            elif t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif re.match(r"(global|flat)_load", t):
+                last_load = -9 if in_asm else n
+            elif t.startswith("s_waitcnt vmcnt(0)") and not in_asm and n - last_load == 1 and fn:
+                out[fn] = out.get(fn, 0) + 1
+            elif t and not t.startswith(";") and not t.startswith("."):
+                pass
+    return out
+
+
+def check():
+    bad, report = [], []
+    for f in FILES:
+        for fn, cnt in sorted(sites(os.path.join(CSRC, f)).items()):
+            allowed = next((a for pat, a, _ in ALLOWED if re.search(pat, fn)), 0)
+            report.append((f, fn, cnt, allowed))
+            if cnt > allowed:
+                bad.append((f, fn, cnt, allowed))
+    return bad, report
+
+
+if __name__ == "__main__":
+    bad, report = check()
+    for f, fn, cnt, allowed in report:
+        print(f"{f:18s} {cnt:3d} (allowed {allowed:2d})  {fn[:100]}")
+    print("FAIL" if bad else "ok")
+    sys.exit(1 if bad else 0)

@@ -393,3 +393,16 @@ def test_encoder_attention_main_loop_stays_at_its_instruction_floor():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_attn_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert r.stdout.count("ok ") == 2
+
+
+def test_no_prefetch_load_is_waited_for_where_it_is_issued():
+    """scripts/check_late_loads.py: in the generated code of the decode path's kernels no memory load is followed directly by a full
+    `s_waitcnt vmcnt(0)` beyond the listed, explained sites -- the shape hipcc gives `p ? p[i] : 0` (a branch with the load and its
+    wait inside), which cost the one-launch decoder 6 % and every small-batch launch a round trip before round 4 removed it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_late_loads", os.path.join(ROOT, "scripts", "check_late_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, report = mod.check()
+    assert report, "no kernel found"
+    assert not bad, bad
