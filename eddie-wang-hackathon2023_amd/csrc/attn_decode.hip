@@ -51,11 +51,17 @@ __global__ __launch_bounds__(64) void attn_self_kernel(AttnSelfParams p) {
 
     const int h = blockIdx.x, lane = threadIdx.x;
     int b = blockIdx.y;
+    // the live-row count, this row's entry of the list and the device-resident step counter: three UNCONDITIONAL loads in flight
+    // together (each behind its own test they were three round trips in a row in front of the cache prefetch); an absent list /
+    // counter reads a word of the qkv sums instead and drops it
+    const int32_t* lsrc = p.live ? p.live : (const int32_t*)p.part;
+    const int32_t live_n = lsrc[0], live_b = lsrc[p.live ? 1 + b : 0];
+    const int32_t t_now = (p.t_dev ? p.t_dev : (const int32_t*)p.part)[0];
     if (p.live) {                                // rows still decoding (wave-uniform): the others' caches are not touched
-        if (b >= p.live[0]) return;
-        b = p.live[1 + b];
+        if (b >= live_n) return;
+        b = live_b;
     }
-    const int T = p.t_dev ? *p.t_dev : p.T;      // device-resident step counter (graph replay) or host value
+    const int T = p.t_dev ? t_now : p.T;         // device-resident step counter (graph replay) or host value
     const int C = p.H * 64;
     // The kernel is a chain of dependent memory round trips (this call's q / k / v sums, the cached K rows, the cached V rows)
     // and at small batches nothing else: the first 64 K rows (one per lane) and the first 32 V rows (lane = dim) do not depend on
@@ -286,11 +292,14 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
 
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int b = blockIdx.y;
+    const int32_t* lsrc = p.live ? p.live : (const int32_t*)p.part;      // (three unconditional loads in flight together: see attn_self_kernel)
+    const int32_t live_n = lsrc[0], live_b = lsrc[p.live ? 1 + b : 0];
+    const int32_t t_now = (p.t_dev ? p.t_dev : (const int32_t*)p.part)[0];
     if (p.live) {                                 // rows still decoding (workgroup-uniform)
-        if (b >= p.live[0]) return;
-        b = p.live[1 + b];
+        if (b >= live_n) return;
+        b = live_b;
     }
-    const int T = p.t_dev ? *p.t_dev : p.T;
+    const int T = p.t_dev ? t_now : p.T;
     const int C = p.H * 64;
     const unsigned char* pastK = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(0 * p.H + h) * p.past_cap * 64) * ES;
     const unsigned char* pastV = (const unsigned char*)p.past + ((size_t)b * p.past_bstride + (size_t)(1 * p.H + h) * p.past_cap * 64) * ES;
