@@ -16,7 +16,7 @@ ALLOWED = [
     (r"gemv_small_kernelILi(4|8|16)ELi2E", 16, "17-32-row forms (not used: the small path serves <= 16 rows)"),
     (r"gemm_rows_kernel", 0, ""),
     (r"gemm_skinny_kernel", 0, ""),
-    (r"attn_self(_wg)?_kernel", 2, "the live-row entry and the device-resident token count, which everything else depends on"),
+    (r"attn_self(_wg)?_kernel", 0, ""),
     (r"attn_cross_kernel", 2, "live-row entry and q bias per item: removing them shortens the launch in situ and LENGTHENS the token step (profiles/r4u_*)"),
     (r"attn_cross_combine_kernel", 1, ""),
 ]
