@@ -735,7 +735,10 @@ struct GroupStep {
             hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, s, prof->timeline, prof->timeline_cap, (long long)(uintptr_t)io->logits, (long long)(1000 + 32 * layer + pos));
     }
 
-    int init(const wm_engine* e_, const wm_decoder_io* io_) {
+    // alone: no other group's step is issued beside this one.  The one-launch forms need their 256 workgroups resident TOGETHER (one
+    // fills a CU's LDS); two such launches dispatched side by side on two streams could each get half of the chip and wait for the
+    // other half until the bounded waits give up -- so only a step that runs alone takes them.
+    int init(const wm_engine* e_, const wm_decoder_io* io_, bool alone = true) {
         e = e_; io = io_;
         prof = &g_prof_dev[e->device >= 0 && e->device < MAX_DEVICES ? e->device : 0];
         WM_REQUIRE(io && io->tokens && io->positional_embedding && io->present && io->cross && io->logits && io->workspace,
@@ -754,7 +757,7 @@ struct GroupStep {
         small = M <= small_path_max_rows();
         rows = !small && rows_path_min_rows() > 0 && M >= rows_path_min_rows() && !e->dec.empty() && gemm_rows_supports(C, e->dec[0].qkv.wcode);
         chain = false;
-        if (small && M == 1 && !e->dec.empty() && e->chain_dev && g_decode_chain.load(std::memory_order_relaxed) && !io->qkv_amax) {
+        if (alone && small && M == 1 && !e->dec.empty() && e->chain_dev && g_decode_chain.load(std::memory_order_relaxed) && !io->qkv_amax) {
             const int slot = e->device >= 0 && e->device < 64 ? e->device : 0;
             int n_cu = g_chain_cus[slot].load(std::memory_order_relaxed);
             unsigned* errw = g_chain_err_dev[slot].load(std::memory_order_relaxed);
@@ -1053,7 +1056,7 @@ int wm_decoder_step_multi(const wm_engine* e, int n_groups, const wm_decoder_io*
     GroupStep g[8];
     for (int k = 0; k < n_groups; ++k) {
         WM_REQUIRE(light_streams[k] && light_streams[k] != heavy_stream, "wm_decoder_step_multi: group %d needs its own stream", k);
-        if (g[k].init(e, ios[k])) return 1;
+        if (g[k].init(e, ios[k], n_groups == 1)) return 1;
     }
     const int n_layer = e->dims.n_text_layer;
     for (int k = 0; k < n_groups; ++k)

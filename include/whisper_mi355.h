@@ -285,8 +285,9 @@ int wm_set_gemm_small_tiles(int tiles);
  *      the pieces + cross-attention out + residual, LayerNorm + mlp1 + GELU, mlp2 + residual, LayerNorm + qkv of the next layer
  *   2  the launch walks over the layers itself: ONE launch per token step besides the embedding and the vocabulary
  *      projection (default).  The per-layer cross K/V and cache pointers reach it through a table in the workspace.
- * Both need the in-place cache (past[i] == present[i], equal capacities <= 512), fp16 cross K/V and <= 32 layers for mode 2; a
- * call that does not qualify takes the launch-per-kernel path.
+ * Both need the in-place cache (past[i] == present[i], equal capacities <= 512), fp16 cross K/V and <= 32 layers for mode 2, and
+ * a step that runs alone (wm_decoder_step, or wm_decoder_step_multi with one group: the launch needs all of its workgroups
+ * resident together); a call that does not qualify takes the launch-per-kernel path.
  * < 0 = default; returns the previous value.  Captured graphs keep the form they were captured with.
  * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a (bounded) wait since the last call -- the results of
  * that step are not valid (a chain needs its <= 256 workgroups resident together; the word is cleared by the call; it
