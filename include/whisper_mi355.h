@@ -287,7 +287,8 @@ int wm_set_gemm_small_tiles(int tiles);
  *      projection (default).  The per-layer cross K/V and cache pointers reach it through a table in the workspace.
  * Both need the in-place cache (past[i] == present[i], equal capacities <= 512), fp16 cross K/V and <= 32 layers for mode 2, and
  * a step that runs alone (wm_decoder_step, or wm_decoder_step_multi with one group: the launch needs all of its workgroups
- * resident together); a call that does not qualify takes the launch-per-kernel path.
+ * resident together -- one per CU: do not issue such a step on a stream whose CU mask leaves it fewer CUs than the device has,
+ * use mode 0 there); a call that does not qualify takes the launch-per-kernel path.
  * < 0 = default; returns the previous value.  Captured graphs keep the form they were captured with.
  * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a (bounded) wait since the last call -- the results of
  * that step are not valid (a chain needs its <= 256 workgroups resident together; the word is cleared by the call; it
