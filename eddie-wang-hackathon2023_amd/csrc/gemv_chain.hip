@@ -682,6 +682,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
         k_new = k; v_new = v;                         // (the cache append waits for the end of the stage: see there)
         s_q[lane] = (h16)r16(q * SCALE);
     }
+    if (wid >= 4 && in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the waves that requested the rows: they have landed
     __syncthreads();
     if (worker && T > 0 && in_lds) rows_to_registers();
     const int nk = T + 1;
