@@ -614,8 +614,18 @@ def main():
         else:
             # one-row utterance groups: the cross-attention is a stage of the one-launch token step (gemv_chain.hip), no launch of the
             # K/V kernel exists to sample.  The token step as a whole is the unit then (decode_step_* below): achieved = its bytes / its time
+            chain_traffic, chain_src = None, None        # HBM bytes per launch from the committed PMC pass of the same command (profiles/r4w_*)
+            try:
+                import re as _re
+                txt = (Path(__file__).resolve().parent / "profiles" / "r4w_pmc_b1_chain_fetch.txt").read_text()
+                m = _re.search(r"streaming reads\): ([0-9.]+) MB", txt)
+                if m and B == 1 and args.model == "large-v2" and args.config == "int8":
+                    chain_traffic = int(float(m.group(1)) * 1e6)
+                    chain_src = "profiles/r4w_pmc_b1_chain_fetch.txt (committed rocprofv3 --pmc FETCH_SIZE pass of bench.py --batch 1, not measured in this run; FETCH_SIZE KB x 1024 x 2)"
+            except OSError:
+                pass
             roofline = {"kernel": "gemv_chain_kernel (one-row decode step: every layer's self-attention, Linears, cross-attention pieces and merge as stages of ONE launch)",
-                        "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": chain_traffic, "traffic_source": chain_src,
                         "note": "batch-1 groups: achieved / frac are the whole token step's (decode_step_bytes.total over decode_step_ms), "
                                 "a latency-bound chain of dependent stages, not a streaming kernel"}
         if roofline is not None:
