@@ -245,6 +245,8 @@ class WhisperDecoding:
         self.micro_batches = None         # stream-parallel utterance groups: None = by batch size (_groups), or a fixed count
         self.lang_id_sequential = False   # bench.py: run the language pass group by group (0.2 % of a step) so that its
                                           # HIP-event kernel timings are not inflated by the other group's HBM share
+        self.groups_sequential = False    # bench.py's roofline probe: main_loop steps the utterance groups one AFTER the other (each group's
+                                          # step waits for the previous group's), so that a launch is timed with the chip to itself
         # experimental schedule (off by default): cross-attention on its own CU set
         # (wm_decoder_step_multi).  Steady state 12.9 ms/step vs 13.9 for the captured graphs at B = 256, but the
         # cross-queue event hand-offs cost 12 us each and only resolve quickly while the host is busy issuing.
@@ -812,11 +814,16 @@ class WhisperDecoding:
             elif counter is not None:
                 native.check(lib.wm_step_advance(counter.data_ptr(), gr['stream']), "wm_step_advance")
 
+        last_issued = None
         for i in range(self.sample_len):
             for gr in groups:
                 if not gr['active']:
                     continue
                 lo, hi, sm, slot = gr['lo'], gr['hi'], gr['stream'], gr['slot']
+                if self.groups_sequential and n_micro > 1:
+                    if last_issued is not None:
+                        streams[slot].wait_stream(streams[last_issued])
+                    last_issued = slot
                 gkey = (n_micro, slot, use_live)
                 if i == 0:
                     sess.decoder_step(gr['tokens'][:, :L0], pos[0:L0], gr['cross'], None, cap, gr['kv'], cap,

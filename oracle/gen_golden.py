@@ -22,7 +22,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 W = "/root/reference/tensorrt_llm_july-release-v1/examples/whisper"
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("WM_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")      # WM_GOLDEN_OUT: a scratch tree, to check that the fixtures regenerate
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "eddie-wang-hackathon2023_amd"))
 
@@ -163,6 +163,12 @@ def gen_op_fixtures(tm):
                    ln_out=lnm(x).numpy(), ln_out_f16=lnm(x.half()).float().numpy())
         c1 = tm.Conv1d(8, 16, kernel_size=3, padding=1)
         c2 = tm.Conv1d(16, 16, kernel_size=3, stride=2, padding=1)
+        # the layers' parameters from THIS function's generator (torch's default init draws from the global generator, whose state
+        # here depends on everything constructed before: the fixture would not regenerate), in the default init's range 1 / sqrt(fan_in)
+        for c in (c1, c2):
+            bound = 1.0 / np.sqrt(c.in_channels * c.kernel_size[0])
+            c.weight.data = torch.from_numpy(rng.uniform(-bound, bound, tuple(c.weight.shape)).astype(np.float32))
+            c.bias.data = torch.from_numpy(rng.uniform(-bound, bound, tuple(c.bias.shape)).astype(np.float32))
         xin = torch.from_numpy(rng.standard_normal((2, 8, 20)).astype(np.float32))
         y1 = torch.nn.functional.gelu(c1(xin))
         y2 = torch.nn.functional.gelu(c2(y1))
@@ -374,6 +380,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-rules-nots" in sys.argv:
         gen_rules_nots_fixture(import_reference_decoding())
+        sys.exit(0)
+    if "--only-ops" in sys.argv:
+        gen_op_fixtures(tm)
         sys.exit(0)
     if "--only-sampling" in sys.argv:
         gen_sampling_fixture(import_reference_decoding())
