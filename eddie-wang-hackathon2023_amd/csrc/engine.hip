@@ -151,9 +151,12 @@ struct wm_engine {
     // next layer -- on the device (the kernels read them there) and on the host (the launcher's checks)
     wm::ChainStage* chain_dev = nullptr; std::vector<wm::ChainStage> chain_host;      // [qkv of layer 0] + 6 per layer (gemv_chain.hip)
     wm::ChainLayerStatic* chain_lstat = nullptr;                                       // per layer: biases of the attention stages, cache scale
-    // the caller's per-layer pointers (cross K/V, cache) as last written to a workspace's table (whole-step launch): keyed by the table's address
+    // what the library knows about the chain state it keeps in a caller's workspace (granules, call counter, pointer table), keyed by the
+    // table's address: the workspace_id under which the state was initialised, and the per-layer pointers last written to the table.
+    // Dies with the engine; capped (a caller that hands a new workspace to every call must not grow it without bound).
+    struct ChainWsSeen { uint64_t id = 0; std::vector<wm::ChainLayerIo> tab; };
     mutable std::mutex chain_io_mu;
-    mutable std::unordered_map<const void*, std::vector<wm::ChainLayerIo>> chain_io_seen;
+    mutable std::unordered_map<const void*, ChainWsSeen> chain_io_seen;
     bool w8() const { return flags & WM_FLAG_WEIGHT_ONLY_INT8; }
     bool i8kv() const { return flags & WM_FLAG_INT8_KV; }
     bool i8cross() const { return flags & WM_FLAG_INT8_CROSS_KV; }
@@ -659,8 +662,49 @@ constexpr int SMALL_PATH_DEFAULT_ROWS = 16;
 std::atomic<int> g_cross_v_skip{CROSS_V_SKIP_DEFAULT};
 // the one-row chain (gemv_chain.hip): a decoder layer at batch 1 in 5 launches instead of 9 (wm_set_decode_chain)
 std::atomic<int> g_decode_chain{DECODE_CHAIN_DEFAULT};
-std::atomic<int> g_chain_cus[64];
-std::atomic<unsigned*> g_chain_err_dev[64];
+// What the one-launch forms need to know about a DEVICE.  `err` is the word a wave of a chain sets when it gives up a bounded wait (a
+// workgroup of the launch was not running): it lives in pinned host memory that the device reaches directly, so the host reads it
+// without a copy or a synchronisation -- every decoder call looks at it.  `declined` is sticky: once a launch has given up, the device
+// is not trusted to hold a chain's workgroups together any more and every later call takes the launch-per-kernel path
+// (wm_set_decode_chain re-arms).  `resident` caches the occupancy verdict per kernel variant and LDS footprint.
+struct ChainDev {
+    std::mutex mu;
+    int n_cu = 0;
+    unsigned* err_host = nullptr; unsigned* err_dev = nullptr;
+    bool declined = false; std::string reason;
+    std::map<long long, bool> resident;
+    std::atomic<long long> launches{0};
+    std::atomic<long long> declined_calls{0};
+};
+ChainDev g_chain_dev[64];
+static ChainDev& chain_dev_slot(int device) { return g_chain_dev[device >= 0 && device < 64 ? device : 0]; }
+// first use on a device: the CU count and the error word (the calling thread's current device is the engine's)
+int chain_dev_init(ChainDev& cd, int device) {
+    std::lock_guard<std::mutex> lk(cd.mu);
+    if (cd.n_cu > 0 && cd.err_host) return 0;
+    int v = 0;
+    WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device));
+    void* host = nullptr; void* dev = nullptr;
+    WM_CHECK_HIP(hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(host, 0, 64);
+    WM_CHECK_HIP(hipHostGetDevicePointer(&dev, host, 0));
+    cd.err_host = (unsigned*)host; cd.err_dev = (unsigned*)dev;
+    cd.n_cu = v > 0 ? v : 1;
+    return 0;
+}
+inline unsigned chain_err_peek(const ChainDev& cd) {
+    return cd.err_host ? __atomic_load_n(cd.err_host, __ATOMIC_RELAXED) : 0u;
+}
+// a stream created with a CU mask (wm_stream_create_cu_mask, hipExtStreamCreateWithCUMask) that leaves it fewer CUs than the device
+// has cannot hold a chain's workgroups together.  A query that fails says nothing: the stream is taken for an ordinary one.
+bool stream_has_all_cus(hipStream_t s, int n_cu) {
+    uint32_t mask[32];
+    memset(mask, 0, sizeof(mask));
+    if (hipExtStreamGetCUMask(s, 32, mask) != hipSuccess) { (void)hipGetLastError(); return true; }
+    int bits = 0;
+    for (uint32_t m : mask) bits += __builtin_popcount(m);
+    return bits == 0 || bits >= n_cu;        // (no bit at all: the runtime reports no mask)
+}
 std::atomic<int> g_small_rows{-1};        // -1: not yet read from the environment
 int small_path_max_rows() {               // WM_SMALL_PATH=<rows> / wm_set_small_batch_rows: the fused path serves M <= rows (0: never)
     int r = g_small_rows.load(std::memory_order_relaxed);
@@ -708,7 +752,7 @@ struct GroupStep {
     int B, L, T, C, H, M;
     bool small = false;                          // the fused small-batch path (gemv_small.hip)
     bool chain = false;                          // ... with its Linears chained inside one launch (one row: gemv_chain.hip)
-    int chain_wgs = 0; unsigned* chain_err = nullptr;
+    int chain_wgs = 0; unsigned* chain_err = nullptr; ChainDev* chain_cd = nullptr;
     bool rows = false;                           // the fused row-split path (gemm_rows.hip)
     bool fused() const { return small || rows; }
 
@@ -738,7 +782,7 @@ struct GroupStep {
     // alone: no other group's step is issued beside this one.  The one-launch forms need their 256 workgroups resident TOGETHER (one
     // fills a CU's LDS); two such launches dispatched side by side on two streams could each get half of the chip and wait for the
     // other half until the bounded waits give up -- so only a step that runs alone takes them.
-    int init(const wm_engine* e_, const wm_decoder_io* io_, bool alone = true) {
+    int init(const wm_engine* e_, const wm_decoder_io* io_, hipStream_t stream, bool alone = true) {
         e = e_; io = io_;
         prof = &g_prof_dev[e->device >= 0 && e->device < MAX_DEVICES ? e->device : 0];
         WM_REQUIRE(io && io->tokens && io->positional_embedding && io->present && io->cross && io->logits && io->workspace,
@@ -757,26 +801,48 @@ struct GroupStep {
         small = M <= small_path_max_rows();
         rows = !small && rows_path_min_rows() > 0 && M >= rows_path_min_rows() && !e->dec.empty() && gemm_rows_supports(C, e->dec[0].qkv.wcode);
         chain = false;
+        hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(stream, &cap_st) == hipSuccess && cap_st != hipStreamCaptureStatusNone;
+        ChainDev& cd = chain_dev_slot(e->device);
+        // A chain launch on this device has given up a wait and nobody has acknowledged it (wm_decode_chain_error): the results of that
+        // step -- and of everything decoded from it -- are invalid.  Every decoder call fails loudly until the caller has looked.
+        // (Not while a stream is being captured: the call issues no work then, and failing it would abort the caller's capture.)
+        if (!capturing && chain_err_peek(cd) != 0) {
+            set_error("wm_decoder_step: a one-launch decode step on device %d gave up waiting for its workgroups (they were not resident "
+                      "together): the results since then are invalid.  Call wm_decode_chain_error() to acknowledge and decode again -- the device "
+                      "takes the launch-per-kernel path from then on (wm_set_decode_chain re-arms the one-launch forms)", e->device);
+            return 1;
+        }
         if (alone && small && M == 1 && !e->dec.empty() && e->chain_dev && g_decode_chain.load(std::memory_order_relaxed) && !io->qkv_amax) {
-            const int slot = e->device >= 0 && e->device < 64 ? e->device : 0;
-            int n_cu = g_chain_cus[slot].load(std::memory_order_relaxed);
-            unsigned* errw = g_chain_err_dev[slot].load(std::memory_order_relaxed);
-            if (n_cu == 0 || !errw) {
-                int v = 0;
-                WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, e->device));
-                n_cu = v > 0 ? v : 1;
-                if (gemv_chain_err_word(&errw)) return 2;
-                g_chain_cus[slot].store(n_cu, std::memory_order_relaxed);
-                g_chain_err_dev[slot].store(errw, std::memory_order_relaxed);
-            }
+            if (chain_dev_init(cd, e->device)) return 2;
+            const int n_cu = cd.n_cu;
             // one-row groups run a decoder layer (or the whole step) as one launch -- with the in-place cache (past[i] == present[i]), four
             // key-range pieces, fp16 cross K/V, the four-wave self-attention form; anything else takes the launch-per-kernel path
-            chain_wgs = n_cu > 256 ? 256 : n_cu; chain_err = errw;
+            chain_wgs = n_cu > 256 ? 256 : n_cu; chain_err = cd.err_dev; chain_cd = &cd;
             bool ok = gemv_chain_supports(C, e->dec[0].qkv.wcode, n_cu) && w.nsplit == 4 && !e->i8cross() && self_attn_waves(M) == 4 &&
                       io->present_capacity <= 512 && H + H * w.nsplit <= chain_wgs;
             for (int i = 0; ok && i < e->dims.n_text_layer; ++i)
                 ok = io->present[i] && io->cross[i] &&
                      (T == 0 ? io->n_past_dev == nullptr : (io->past[i] == io->present[i] && io->past_capacity == io->present_capacity));
+            // ... and only where the launch's workgroups can be resident TOGETHER (they wait for each other): a device that has let a chain
+            // down before is not asked again, the runtime's occupancy figure must cover the grid, and the stream must own every CU
+            if (ok) {
+                std::lock_guard<std::mutex> lk(cd.mu);
+                ok = !cd.declined;
+                if (ok) {
+                    const long long key = ((long long)e->dec[0].qkv.wcode << 40) | ((long long)(e->i8kv() ? 1 : 0) << 32) | ((long long)e->dims.n_audio_ctx << 8) | w.nsplit;
+                    auto it = cd.resident.find(key);
+                    if (it == cd.resident.end()) {
+                        bool fits = false;
+                        if (gemv_chain_resident(e->dec[0].qkv.wcode, e->i8kv() ? 1 : 0, e->dims.n_audio_ctx, w.nsplit, chain_wgs, n_cu, &fits)) return 2;
+                        it = cd.resident.emplace(key, fits).first;
+                        if (!fits) cd.reason = "the runtime's occupancy figure says the device cannot hold the launch's workgroups together";
+                    }
+                    ok = it->second;
+                }
+            }
+            if (ok && !stream_has_all_cus(stream, n_cu)) ok = false;
+            if (!ok) cd.declined_calls.fetch_add(1, std::memory_order_relaxed);
             chain = ok;
         }
         return 0;
@@ -805,6 +871,7 @@ struct GroupStep {
         p.cross_kv = (const h16*)io->cross[i]; p.cross_qbias = Lr.cq.b;
         p.self_part = w.part; p.self_bias = Lr.qkv.b; p.self_cache = io->present[i]; p.self_kv_scale = Lr.kv_scale;
         p.launch_id = i;
+        chain_cd->launches.fetch_add(1, std::memory_order_relaxed);
         return launch_gemv_chain(p, &e->chain_host[1 + (size_t)6 * i], chain_wgs, s);
     }
 
@@ -822,6 +889,7 @@ struct GroupStep {
         EmbedParams ep{io->tokens, io->tokens_ld > 0 ? io->tokens_ld : L, M, L, e->emb_t, C,
                        (const h16*)io->positional_embedding, w.x, C, d.n_vocab, io->n_past_dev, nullptr};
         ep.generation = chain ? w.generation : nullptr;      // the chain's granule epochs count the calls on this workspace
+        if (chain) if (int rc = chain_prepare_workspace(s)) return rc;
         if (launch_embed(ep, s)) return 2;
         if (small) return 0;                         // the first LayerNorm happens inside the qkv projection
         return launch_layernorm(w.x, C, M, C, e->dec[0].ln1g, e->dec[0].ln1b, w.xn, C, s);
@@ -832,21 +900,50 @@ struct GroupStep {
     // cross-attention, merge + cout, mlp1, mlp2, qkv of the next layer -- gemv_chain.hip walks over the layers itself; the per-layer
     // cross K/V and cache pointers reach it through a table in the workspace, rewritten (small launches on this stream) only when
     // the caller's pointers differ from the ones last written there.
+    // The chain's state in the caller's workspace -- tagged granules, the call counter, the per-layer pointer table -- is the LIBRARY's to
+    // initialise: the workspace arrives as the allocator left it (the reference's plugins get theirs the same way; INTEGRATION.md's stub
+    // uses torch.empty).  A state the library has not initialised under this (address, workspace_id) is cleared by a memset ON THE
+    // STREAM OF THE CALL, ahead of the embedding kernel that opens the call (which counts the cleared call counter up to 1: tag 0 is
+    // never valid, and bit 31 of every epoch is set besides).  workspace_id == 0 vouches for nothing: cleared on every call.  Under
+    // stream capture the nodes are recorded but not run, so nothing is remembered: a captured call always carries its own initialisation.
+    bool ws_fresh = false, ws_capturing = false;
+    int chain_prepare_workspace(hipStream_t s) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        ws_capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        ws_fresh = io->workspace_id == 0 || ws_capturing;
+        if (!ws_fresh) {
+            std::lock_guard<std::mutex> lk(e->chain_io_mu);
+            auto it = e->chain_io_seen.find(w.layer_io);
+            ws_fresh = it == e->chain_io_seen.end() || it->second.id != io->workspace_id;
+            if (ws_fresh) {
+                if (e->chain_io_seen.size() > 4096) e->chain_io_seen.clear();
+                wm_engine::ChainWsSeen& seen = e->chain_io_seen[w.layer_io];
+                seen.id = io->workspace_id; seen.tab.clear();
+            }
+        }
+        if (ws_fresh) {
+            unsigned char* lo = (unsigned char*)w.gran_x;
+            unsigned char* hi = (unsigned char*)(w.generation + 4);
+            WM_CHECK_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo), s));
+        }
+        return 0;
+    }
+
     bool step_done = false;
     int whole_step(hipStream_t s) {
         const int n = e->dims.n_text_layer;
         std::vector<ChainLayerIo> tab((size_t)n);
         for (int i = 0; i < n; ++i) tab[i] = ChainLayerIo{io->cross[i], io->present[i]};
-        if (io->workspace_id == 0) {                 // the caller vouches for nothing: the table is rewritten on every call
+        if (io->workspace_id == 0 || ws_capturing) {     // nothing is vouched for (or remembered): the table is rewritten on every call
             if (launch_chain_io_table(w.layer_io, tab.data(), n, s)) return 2;
         } else {
-            tab.push_back(ChainLayerIo{(const void*)(uintptr_t)io->workspace_id, nullptr});       // (the id is part of what must match)
             std::lock_guard<std::mutex> lk(e->chain_io_mu);
-            std::vector<ChainLayerIo>& seen = e->chain_io_seen[w.layer_io];
-            const bool same = seen.size() == tab.size() && memcmp(seen.data(), tab.data(), tab.size() * sizeof(ChainLayerIo)) == 0;
+            wm_engine::ChainWsSeen& seen = e->chain_io_seen[w.layer_io];
+            const bool same = !ws_fresh && seen.id == io->workspace_id && seen.tab.size() == tab.size() &&
+                              memcmp(seen.tab.data(), tab.data(), tab.size() * sizeof(ChainLayerIo)) == 0;
             if (!same) {
                 if (launch_chain_io_table(w.layer_io, tab.data(), n, s)) return 2;
-                seen = tab;
+                seen.id = io->workspace_id; seen.tab = tab;
             }
         }
         GemvChainParams p{};
@@ -854,6 +951,7 @@ struct GroupStep {
         p.n_layers = n; p.lstat = e->chain_lstat; p.lio = w.layer_io; p.gran_s = w.gran_s;
         p.st = e->chain_dev; p.n_stages = 0; p.launch_id = 0;
         if (launch_gemv_chain(p, e->chain_host.data(), chain_wgs, s)) return 2;
+        chain_cd->launches.fetch_add(1, std::memory_order_relaxed);
         step_done = true;
         return 0;
     }
@@ -1038,7 +1136,7 @@ int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t str
         return 0;
     }
     GroupStep g;
-    if (g.init(e, io)) return 1;
+    if (int rc = g.init(e, io, s)) return rc;
     if (g.begin(s)) return 2;
     for (int i = 0; i < e->dims.n_text_layer; ++i) {
         if (g.pre_cross(i, s)) return 2;
@@ -1056,7 +1154,7 @@ int wm_decoder_step_multi(const wm_engine* e, int n_groups, const wm_decoder_io*
     GroupStep g[8];
     for (int k = 0; k < n_groups; ++k) {
         WM_REQUIRE(light_streams[k] && light_streams[k] != heavy_stream, "wm_decoder_step_multi: group %d needs its own stream", k);
-        if (g[k].init(e, ios[k], n_groups == 1)) return 1;
+        if (int rc = g[k].init(e, ios[k], (hipStream_t)light_streams[k], n_groups == 1)) return rc;
     }
     const int n_layer = e->dims.n_text_layer;
     for (int k = 0; k < n_groups; ++k)
@@ -1283,18 +1381,44 @@ int wm_attn_decode_cross(const float* q, int B, int L, int H, int Tk, const void
 int wm_set_decode_chain(int on) {
     const int prev = g_decode_chain.load(std::memory_order_relaxed);
     g_decode_chain.store(on < 0 ? DECODE_CHAIN_DEFAULT : (on > 2 ? 2 : on), std::memory_order_relaxed);
+    for (ChainDev& cd : g_chain_dev) {               // an explicit choice re-arms devices that had let a chain down
+        std::lock_guard<std::mutex> lk(cd.mu);
+        if (cd.declined) { cd.declined = false; cd.reason.clear(); }
+    }
     return prev;
 }
 
 int wm_decode_chain_error(int* out) {
     WM_REQUIRE(out, "wm_decode_chain_error: null argument");
-    unsigned* errw = nullptr;
-    if (gemv_chain_err_word(&errw)) return 2;
-    unsigned v[4] = {0, 0, 0, 0};
-    WM_CHECK_HIP(hipMemcpy(v, errw, sizeof(v), hipMemcpyDeviceToHost));
-    *out = (int)v[0];
-    if (v[0]) { const unsigned z[4] = {0, 0, 0, 0}; WM_CHECK_HIP(hipMemcpy(errw, z, sizeof(z), hipMemcpyHostToDevice)); }
+    ChainDev& cd = chain_dev_slot(current_device_index());
+    WM_CHECK_HIP(hipDeviceSynchronize());            // the word is current for everything the caller has enqueued so far
+    const unsigned v = chain_err_peek(cd);
+    *out = (int)v;
+    if (v) {
+        std::lock_guard<std::mutex> lk(cd.mu);
+        __atomic_store_n(cd.err_host, 0u, __ATOMIC_RELAXED);
+        cd.declined = true;
+        cd.reason = "a one-launch decode step gave up waiting for its workgroups (they were not resident together)";
+    }
     return 0;
+}
+
+int wm_decode_chain_status(wm_chain_status* out) {
+    WM_REQUIRE(out, "wm_decode_chain_status: null argument");
+    ChainDev& cd = chain_dev_slot(current_device_index());
+    std::lock_guard<std::mutex> lk(cd.mu);
+    memset(out, 0, sizeof(*out));
+    out->mode = g_decode_chain.load(std::memory_order_relaxed);
+    out->launches = cd.launches.load(std::memory_order_relaxed);
+    out->declined_calls = cd.declined_calls.load(std::memory_order_relaxed);
+    out->declined = cd.declined ? 1 : 0;
+    out->error_pending = chain_err_peek(cd) ? 1 : 0;
+    snprintf(out->reason, sizeof(out->reason), "%s", cd.reason.c_str());
+    return 0;
+}
+
+int wm_debug_occupy(int n_workgroups, size_t lds_bytes, int64_t microseconds, wm_stream_t stream) {
+    return launch_occupy(n_workgroups, lds_bytes, (long long)microseconds, (hipStream_t)stream);
 }
 
 int wm_set_cross_v_skip(int on) {

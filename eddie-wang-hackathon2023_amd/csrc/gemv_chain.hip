@@ -50,8 +50,10 @@ typedef __attribute__((address_space(1))) unsigned long long chain_gu64;
 
 constexpr int CHAIN_MAX_IN = 4 * 1536;     // widest stage input (halves): mlp2's K = 4 n_state
 
+// (the error word lives in pinned host memory the device reaches directly: the host reads it without a copy or a synchronisation --
+// engine.hip: ChainDev -- so it is read and written at system scope; it is looked at once per 64 polls only)
 __device__ __forceinline__ bool chain_failed(const unsigned* err) {
-    return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
 }
 
 // NL 16-byte sc1 loads per lane (two granules each) from granule indices first[k] (even), repeated until every tag is `epoch`.
@@ -78,7 +80,7 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
         if (__all(ok)) return true;
         if ((spins & 63) == 63 && chain_failed(err)) return false;
         if (spins > (1u << 20)) {                     // ~ a second: a workgroup of the chain is not running
-            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -358,6 +360,7 @@ constexpr int CHAIN_MAX_LAYERS = 32;               // layers of a whole-step lau
 // what the attention stages take per LAYER (kernel arguments for a one-layer launch, the two tables in a whole-step launch)
 struct ChainLayerArgs { const h16* cross_kv; const h16* cross_qbias; void* self_cache; const h16* self_bias; float self_kv_scale; };
 constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
+constexpr unsigned CHAIN_EPOCH_LIVE = 0x80000000u;
 
 __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, const void* cross_kv, unsigned char* kv_lds, int per_split) {
     // waves 4-7: this workgroup's piece of K, then of V, as 1 KiB pieces (8 rows of 128 B) into LDS, linear
@@ -811,8 +814,9 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);
     constexpr int TB = WB == 16 ? 10 : 5;
     // epochs never repeat: the generation word counts the decoder calls on this workspace (the embedding kernel that opens a call
-    // increments it), the launch id the chains of a call, the low bits the stages of a chain
-    const unsigned gen = *p.generation;
+    // increments it), the launch id the chains of a call, the low bits the stages of a chain.  Bit 31 is always set: the tag of a
+    // zero-initialised granule (the library clears the granules of a workspace it has not seen, engine.hip) is never a valid epoch.
+    const unsigned gen = CHAIN_EPOCH_LIVE | ((*p.generation & 0x1fffffu) << 10);
     extern __shared__ __attribute__((aligned(1024))) unsigned char kv_lds[];      // the cross-attention stage's K and V rows (only then)
     __shared__ float s_sc[CHAIN_CROSS_KEYS];
     __shared__ float s_redc[8][2];
@@ -853,7 +857,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     if (self_wg) self_v_off = chain_self_prefetch<I8KV>(p, whole ? s_lio[0].cache : p.self_cache, T_now, self_h, kv_lds, 2 * per_split * 128);
     bool own_valid = false, x_in_granules = false;
     for (int l = whole ? -1 : 0; l < (whole ? p.n_layers : 1); ++l) {
-        const unsigned epoch0 = (gen << 10) | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);
+        const unsigned epoch0 = gen | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);
         if (whole && l >= 0) {
             const ChainLayerStatic ls = s_lst[l];
             const ChainLayerIo li = s_lio[l];
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
             float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
             float* s_o_flat = (float*)&s_in[0][0];
-            const unsigned tag_s = ((gen << 10) | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
+            const unsigned tag_s = (gen | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
             chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, self_h, s_p, s_new, s_r2, s_o_flat, kv_lds, self_v_off);
             // the NEXT layer's cached rows set out now (the stage's last barrier is behind every read of this layer's)
             self_v_off = (whole && l + 1 < p.n_layers) ? chain_self_prefetch<I8KV>(p, s_lio[l + 1].cache, T_now, self_h, kv_lds, 2 * per_split * 128) : 0;
@@ -904,12 +908,44 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     }
 }
 
-// the word a wave sets when it gives up a bounded wait: one per device (the kernels get its address, wm_decode_chain_error reads it)
-__device__ unsigned g_chain_err[4];
-int gemv_chain_err_word(unsigned** out) {
-    void* ptr = nullptr;
-    WM_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_chain_err)));
-    *out = (unsigned*)ptr;
+// the dynamic-LDS limit is a per-device attribute of each instantiation: raised once per device
+static int chain_set_lds_attribute() {
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    WM_CHECK_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (attr_set.load(std::memory_order_acquire) & bit) return 0;
+    auto each_kernel = [&](auto&& f) -> int {
+        if (int rc = f(gemv_chain_kernel<4, false>)) return rc;
+        if (int rc = f(gemv_chain_kernel<4, true>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, false>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, true>)) return rc;
+        if (int rc = f(gemv_chain_kernel<16, false>)) return rc;
+        return f(gemv_chain_kernel<16, true>);
+    };
+    if (each_kernel([&](auto* k) -> int { WM_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_DYN_LDS)); return 0; })) return 2;
+    attr_set.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
+// Can the CURRENT device hold the launch's n_wg workgroups TOGETHER?  They wait for each other, so one that is never scheduled makes the
+// others spin until their bounded waits give up: the runtime's occupancy figure for this instantiation at its LDS footprint (static +
+// the K / V pieces) times the CUs must cover the grid.  *ok = false is an answer, not an error.
+int gemv_chain_resident(int w8, int self_i8, int cross_Tk, int cross_nsplit, int n_wg, int n_cu, bool* ok) {
+    *ok = false;
+    WM_REQUIRE(cross_nsplit >= 1 && cross_Tk >= 1 && n_wg >= 1 && n_cu >= 1, "gemv_chain_resident: bad arguments");
+    const int per_split = (((cross_Tk + cross_nsplit - 1) / cross_nsplit) + 7) & ~7;
+    const size_t dyn = (size_t)2 * per_split * 128 + 1024;
+    if (dyn > CHAIN_DYN_LDS) return 0;
+    if (chain_set_lds_attribute()) return 2;
+    int per_cu = 0;
+    auto ask = [&](auto* k) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, 512, dyn); };
+    hipError_t rc;
+    if (w8 == 4) rc = self_i8 ? ask(gemv_chain_kernel<4, true>) : ask(gemv_chain_kernel<4, false>);
+    else if (w8) rc = self_i8 ? ask(gemv_chain_kernel<8, true>) : ask(gemv_chain_kernel<8, false>);
+    else rc = self_i8 ? ask(gemv_chain_kernel<16, true>) : ask(gemv_chain_kernel<16, false>);
+    WM_CHECK_HIP(rc);
+    *ok = per_cu >= 1 && (long)per_cu * n_cu >= n_wg;
     return 0;
 }
 
@@ -975,28 +1011,30 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs_all, int n_
     WM_REQUIRE(dyn <= CHAIN_DYN_LDS, "gemv_chain: cross-attention pieces of %d keys do not fit LDS", per_split);
     widest = widest > p.cross_heads * p.cross_nsplit ? widest : p.cross_heads * p.cross_nsplit;
     WM_REQUIRE(n_wg >= widest, "gemv_chain: %d workgroups for stages that need %d", n_wg, widest);
-    static std::atomic<unsigned long long> attr_set{0};       // per device (the dynamic-LDS limit is a per-device attribute of the function)
-    int dev = 0;
-    WM_CHECK_HIP(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << (dev & 63);
-    auto each_kernel = [&](auto&& f) -> int {
-        if (int rc = f(gemv_chain_kernel<4, false>)) return rc;
-        if (int rc = f(gemv_chain_kernel<4, true>)) return rc;
-        if (int rc = f(gemv_chain_kernel<8, false>)) return rc;
-        if (int rc = f(gemv_chain_kernel<8, true>)) return rc;
-        if (int rc = f(gemv_chain_kernel<16, false>)) return rc;
-        return f(gemv_chain_kernel<16, true>);
-    };
-    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        if (each_kernel([&](auto* k) -> int { WM_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_DYN_LDS)); return 0; })) return 2;
-        attr_set.fetch_or(bit, std::memory_order_release);
-    }
+    if (chain_set_lds_attribute()) return 2;
     const bool i8 = p.self_i8 != 0;
     auto go = [&](auto* k) { hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), dyn, stream, p); };
     if (p.w8 == 4) { if (i8) go(gemv_chain_kernel<4, true>); else go(gemv_chain_kernel<4, false>); }
     else if (p.w8) { if (i8) go(gemv_chain_kernel<8, true>); else go(gemv_chain_kernel<8, false>); }
     else { if (i8) go(gemv_chain_kernel<16, true>); else go(gemv_chain_kernel<16, false>); }
     WM_LAUNCH_CHECK(stream, "gemv_chain");
+    return 0;
+}
+
+// Diagnostic: n_wg workgroups that each hold `lds_bytes` of LDS and sleep for `usec` microseconds (wm_debug_occupy: the GPU test of the
+// chain's give-up path keeps half of the CUs' LDS busy with it, so that a chain launch cannot get its workgroups resident together).
+__global__ __launch_bounds__(64) void occupy_kernel(long long ticks, int* sink) {
+    extern __shared__ unsigned char hold[];
+    hold[threadIdx.x] = (unsigned char)threadIdx.x;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (sink && hold[(threadIdx.x + 1) & 63] == 255 && ticks < 0) *sink = 1;
+}
+int launch_occupy(int n_wg, size_t lds_bytes, long long usec, hipStream_t stream) {
+    WM_REQUIRE(n_wg >= 1 && n_wg <= 4096 && lds_bytes <= 160 * 1024 && usec >= 0 && usec <= 20000000, "wm_debug_occupy: bad arguments");
+    WM_CHECK_HIP(hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(64), lds_bytes, stream, usec * 100, (int*)nullptr);       // wall_clock64: 100 MHz
+    WM_LAUNCH_CHECK(stream, "occupy");
     return 0;
 }
 

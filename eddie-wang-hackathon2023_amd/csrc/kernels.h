@@ -112,7 +112,8 @@ struct GemvChainParams {
     const unsigned* generation; int launch_id;                // epochs: (*generation << 10) | (layer or launch_id << 3), + stage + 1 (generation: one per decoder call)
 };
 bool gemv_chain_supports(int C, int w8, int n_cu);
-int gemv_chain_err_word(unsigned** out);                      // device address of this device's "a wait was given up" word
+int gemv_chain_resident(int w8, int self_i8, int cross_Tk, int cross_nsplit, int n_wg, int n_cu, bool* ok);      // can the current device hold the launch's workgroups together?
+int launch_occupy(int n_wg, size_t lds_bytes, long long usec, hipStream_t stream);      // diagnostic: workgroups that hold LDS and sleep
 int launch_gemv_chain(const GemvChainParams& p, const ChainStage* host_stages, int n_wg, hipStream_t stream);
 int launch_chain_io_table(ChainLayerIo* dst, const ChainLayerIo* host, int n, hipStream_t stream);      // fills the caller's table (small launches, arguments by value)     // host_stages: the same descriptors, for the argument checks
 

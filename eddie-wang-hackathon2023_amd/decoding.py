@@ -453,7 +453,7 @@ class WhisperDecoding:
                 self.tokens[:, self.sot_index + 1] = language_tokens.cpu()        # write language tokens
         return languages, language_probs
 
-    def detect_language(self, audio_features):
+    def detect_language(self, audio_features, _retry: bool = False):
         """Language-ID pass, fast path: same arithmetic as detect_language_reference, but the cross
         K/V land in the persistent buffers main_loop re-uses (the reference computes them twice,
         SURVEY F6) and the one-token decoder call runs per utterance group on its stream."""
@@ -468,6 +468,9 @@ class WhisperDecoding:
             n_audio, dev = audio_features.shape[0], audio_features.device
             cfg = self.decoder_config
             st = self._fast_state(n_audio, dev)
+            one_row = any(hi - lo == 1 for lo, hi in self._groups(n_audio)[1])      # groups that may run as one launch per step
+            if one_row and native.chain_status()["error_pending"]:                  # (a peek at a host word: no synchronisation)
+                self._chain_gave_up("found before the language pass")               # somebody else's give-up: acknowledged, not ours to repeat
             cross = self._cross_persistent(audio_features, st)
             if 'lang_logits' not in st:
                 st['lang_logits'] = torch.empty((n_audio, 1, cfg['vocab_size']), dtype=torch.float16, device=dev)
@@ -484,6 +487,8 @@ class WhisperDecoding:
                                                   [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
                                                   st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g)
                 main.wait_stream(streams[g])
+            if one_row and not _retry and self._chain_gave_up("language pass"):
+                return self.detect_language(audio_features[0] if single else audio_features, _retry=True)
             language_tokens, language_probs, languages = self._language_from_logits(
                 st['lang_logits'][:, 0].float(), n_audio, single)
             if self.options.language is None:
@@ -709,6 +714,27 @@ class WhisperDecoding:
             st['cross_key'], st['cross_xa'] = key, xa
         return st['cross']
 
+    def _chain_gave_up(self, where: str) -> bool:
+        """Did a one-launch decode step (csrc/gemv_chain.hip: batch-1 groups) give up waiting for its workgroups since the last look?
+        The launch needs its workgroups resident together; another tenant holding CUs or LDS while it is dispatched makes its bounded
+        waits expire, and everything decoded from that step is invalid.  The library then stops using the one-launch forms on this
+        device (wm_decode_chain_error: acknowledged, the device takes a launch per kernel from now on); graphs captured with chain
+        launches are dropped.  Returns True when the caller has to decode again."""
+        err = C.c_int(0)
+        native.check(native.load_library().wm_decode_chain_error(C.byref(err)), "wm_decode_chain_error")
+        if not err.value:
+            return False
+        for st in self._state.values():
+            st['graphs'].clear()
+        if not WhisperDecoding._chain_warned:
+            WhisperDecoding._chain_warned = True
+            logger.warning("whisper_mi355: a one-launch decode step gave up waiting for its workgroups (%s; the GPU was not free to hold them "
+                           "together): decoding again with a launch per kernel, which this device uses from now on "
+                           "(wm_set_decode_chain re-arms the one-launch step)", where)
+        return True
+
+    _chain_warned = False
+
     def _live_list(self, st, n_micro, slot, lo, hi):
         """The group's list of rows still decoding (int32 [1 + n]: count, indices relative to the group), reset to
         "all of them"; wm_step_finish rebuilds it after every step from the `done` flags."""
@@ -744,7 +770,7 @@ class WhisperDecoding:
         io.temperature, io.row0, io.seed_dev = float(self.options.temperature), lo, st['seed'].data_ptr()
         native.check(native.load_library().wm_greedy_step(C.byref(io), stream), "wm_greedy_step")
 
-    def main_loop(self, audio_features, ignore_eot: bool = False, row_limit=None):
+    def main_loop(self, audio_features, ignore_eot: bool = False, row_limit=None, _retry: bool = False):
         """Greedy decoding, fast path.  Same return values as the reference's main_loop
         (tokens int64 [n, <=n_text_ctx+1], sum_logprobs fp32 [n], no_speech_probs list).
         `ignore_eot` (benchmarks with random weights) decodes `sample_len` tokens regardless.
@@ -771,8 +797,12 @@ class WhisperDecoding:
         cfg = self.decoder_config
         V, cap = cfg['vocab_size'], cfg['num_text_ctx']
         st = self._fast_state(n_batch, dev)
+        one_row = any(hi - lo == 1 for lo, hi in self._groups(n_batch)[1])      # groups that may run as one launch per token step
+        if one_row and not _retry and native.chain_status()["error_pending"]:   # (a peek at a host word: no synchronisation)
+            self._chain_gave_up("found before the decode loop")                 # somebody else's give-up: acknowledged, not ours to repeat
         if self.options.temperature != 0:     # a fresh seed per call from torch's generator: torch.manual_seed makes a run repeatable
-            st['seed'].copy_(torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32))
+            if not _retry:
+                st['seed'].copy_(torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32))
         cross = self._cross_persistent(audio_features, st)
         st['tokens'].zero_()
         st['tokens'][:, :L0] = tokens0.to(torch.int32)
@@ -885,14 +915,12 @@ class WhisperDecoding:
             main.wait_stream(s_)
         out = self._finish_main_loop(st, cur, L0, n_batch, ignore_eot,
                                      nsp_dev if self.tokenizer.no_speech is not None else None)
-        if any(hi - lo == 1 for lo, hi in bounds):
-            # one-row groups run their Linears as in-launch chains (csrc/gemv_chain.hip) whose workgroups wait for each other with
-            # bounded spins: a wait that was given up (the chain's workgroups were not resident together) invalidates the step
-            err = C.c_int(0)
-            native.check(lib.wm_decode_chain_error(C.byref(err)), "wm_decode_chain_error")
-            if err.value:
-                raise RuntimeError("whisper_mi355: a decode-chain workgroup gave up waiting for its input (the GPU was not free to hold the "
-                                   "chain's workgroups together); rerun with wm_set_decode_chain(0)")
+        if one_row and not _retry and self._chain_gave_up("decode loop"):
+            # one-row groups run the token step as ONE launch whose workgroups wait for each other with bounded spins; a wait that was
+            # given up invalidates the step and every token after it.  The utterance is decoded again, in this process, on the
+            # launch-per-kernel path (the library has taken the device off the one-launch forms; the captured graphs are gone).
+            return self.main_loop(audio_features[:: self.n_group] if self.n_group > 1 and audio_features.shape[0] == n_batch else audio_features,
+                                  ignore_eot=ignore_eot, row_limit=row_limit, _retry=True)
         return out
 
     def _main_loop_partitioned(self, audio_features, st, cross, L0, n_micro, bounds, ignore_eot):

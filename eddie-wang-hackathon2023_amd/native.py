@@ -77,12 +77,12 @@ EXPORTS = (
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
     "wm_profile_configure", "wm_profile_read", "wm_step_advance", "wm_log_mel_workspace_bytes", "wm_log_mel",
-    "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_gemv_fused", "wm_gemm_rows", "wm_set_rows_path", "wm_set_small_batch_rows", "wm_set_self_attn_waves", "wm_set_gemm_small_tiles", "wm_lab_knobs", "wm_set_cross_v_skip", "wm_set_decode_chain", "wm_decode_chain_error", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
+    "wm_flac_info", "wm_flac_decode", "wm_conv1d_gelu", "wm_argmax", "wm_gemv_fused", "wm_gemm_rows", "wm_set_rows_path", "wm_set_small_batch_rows", "wm_set_self_attn_waves", "wm_set_gemm_small_tiles", "wm_lab_knobs", "wm_set_cross_v_skip", "wm_set_decode_chain", "wm_decode_chain_error", "wm_decode_chain_status", "wm_debug_occupy", "wm_decoder_step_multi", "wm_stream_create_cu_mask", "wm_stream_destroy", "wm_attn_decode_cross_i8", "wm_debug_timeline",
     "wm_step_finish",
 )
 
 
-ABI_VERSION = 6          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
+ABI_VERSION = 7          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
 
 
 class WmError(RuntimeError):
@@ -93,6 +93,20 @@ class WmFlacStreamInfo(C.Structure):
     """wm_flac_streaminfo (include/whisper_mi355.h)."""
     _fields_ = [("sample_rate", C.c_int32), ("channels", C.c_int32), ("bits_per_sample", C.c_int32),
                 ("max_block_size", C.c_int32), ("total_samples", C.c_int64), ("md5", C.c_uint8 * 16)]
+
+
+class WmChainStatus(C.Structure):
+    """wm_chain_status (include/whisper_mi355.h)."""
+    _fields_ = [("mode", C.c_int32), ("declined", C.c_int32), ("error_pending", C.c_int32), ("pad_", C.c_int32),
+                ("launches", C.c_int64), ("declined_calls", C.c_int64), ("reason", C.c_char * 160)]
+
+
+def chain_status() -> dict:
+    """wm_decode_chain_status of the current device as a dict (tests, diagnostics)."""
+    st = WmChainStatus()
+    check(load_library().wm_decode_chain_status(C.byref(st)), "wm_decode_chain_status")
+    return {"mode": st.mode, "declined": bool(st.declined), "error_pending": bool(st.error_pending), "launches": int(st.launches),
+            "declined_calls": int(st.declined_calls), "reason": st.reason.decode()}
 
 
 class WmDims(C.Structure):
@@ -206,6 +220,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_set_cross_v_skip.argtypes = [i32]
     lib.wm_set_decode_chain.argtypes = [i32]
     lib.wm_decode_chain_error.argtypes = [C.POINTER(C.c_int)]
+    lib.wm_decode_chain_status.argtypes = [C.POINTER(WmChainStatus)]
+    lib.wm_debug_occupy.argtypes = [i32, sz, C.c_int64, vp]
     lib.wm_gemm_skinny.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.wm_gemm_skinny_default_ksplit.argtypes = [i32, i32, i32, i32]
     lib.wm_layernorm.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp]

@@ -106,10 +106,12 @@ class Session(object):
     def _workspace(self, key: tuple, nbytes: int) -> torch.Tensor:
         ws = self._workspaces.get(key)
         if ws is None or ws.numel() < nbytes:
-            # zeroed: the decoder's one-row chain keeps a call counter and tagged granules in its workspace (csrc/gemv_chain.hip);
-            # they must not start from whatever the allocator hands back
-            ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=f"cuda:{self._device}")
-            ws._wm_id = next(_WORKSPACE_IDS)      # wm_decoder_io.workspace_id: a new identity for every (zeroed) allocation
+            # as the allocator hands it back, like the buffers the reference's session gets (torch.empty): the decoder's one-launch step
+            # keeps a call counter and tagged granules in its workspace (csrc/gemv_chain.hip), and the LIBRARY initialises them, on the
+            # stream of the first call that carries this allocation's id (a zero-fill here ran on torch's current stream, un-ordered
+            # with the side stream the first call ran on)
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=f"cuda:{self._device}")
+            ws._wm_id = next(_WORKSPACE_IDS)      # wm_decoder_io.workspace_id: a new identity for every allocation
             self._workspaces[key] = ws
         return ws
 

@@ -52,8 +52,11 @@ typedef struct wm_dims {
  *   4  wm_set_self_attn_waves
  *   5  (round 4) wm_set_gemm_small_tiles, wm_lab_knobs; environment knobs are honoured only under WM_LAB=1;
  *      wm_greedy_io gains the sampling fields (temperature, seed) and `without_timestamps` moves into the device rules
- *   6  (round 4) wm_set_decode_chain / wm_decode_chain_error; wm_decoder_io gains `workspace_id` (appended)            */
-#define WM_ABI_VERSION 6
+ *   6  (round 4) wm_set_decode_chain / wm_decode_chain_error; wm_decoder_io gains `workspace_id` (appended)
+ *   7  (round 5) the decoder workspace needs NO initialisation by the caller any more (the library clears the state it keeps there,
+ *      on the stream of the call); a one-launch step that gave up makes the NEXT wm_decoder_step fail (rc 1) until
+ *      wm_decode_chain_error has been called; wm_decode_chain_status, wm_debug_occupy                                            */
+#define WM_ABI_VERSION 7
 int wm_version(void);
 const char* wm_last_error(void);
 int wm_device_count(int* out);
@@ -132,9 +135,13 @@ typedef struct wm_decoder_io {
      * row at EOT whatever its logits.  A live row's result does not depend on which other rows are live. */
     const int32_t* live_rows;
     /* identity of the workspace's CONTENTS (ABI 6): 0 = unknown.  The one-launch token step of a one-row group (wm_set_decode_chain)
-     * reads the per-layer `cross` / `present` pointers from a table it keeps inside the workspace; with a non-zero id the table is
-     * rewritten only when the pointers or the id differ from what the library last wrote at that address, with 0 on every call
-     * (four small launches).  Give every allocation of a workspace a new id, and a new one whenever it is zeroed or overwritten. */
+     * keeps state inside the workspace: tagged granules, a call counter, a table of the per-layer `cross` / `present` pointers.  The
+     * workspace itself needs no preparation (ABI 7: hipMalloc / torch.empty memory is fine) -- the library initialises that state, on
+     * the stream of the call: with 0 on EVERY call (a 120 KB memset node and four small launches: correct, a few microseconds slower),
+     * with a non-zero id once per (address, id), and the table is rewritten only when the pointers differ from what the library last
+     * wrote there.  A non-zero id is the caller's promise that since the id was first passed nothing but wm_decoder_step calls of this
+     * engine with the same (batch, n_new) have written to the workspace: give every allocation a new id, and a new one whenever the
+     * memory is reused for anything else.  Calls that are being captured into a graph always carry their own initialisation. */
     uint64_t workspace_id;
 } wm_decoder_io;
 size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new);
@@ -290,13 +297,34 @@ int wm_set_gemm_small_tiles(int tiles);
  * resident together -- one per CU: do not issue such a step on a stream whose CU mask leaves it fewer CUs than the device has,
  * use mode 0 there); a call that does not qualify takes the launch-per-kernel path.
  * < 0 = default; returns the previous value.  Captured graphs keep the form they were captured with.
- * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a (bounded) wait since the last call -- the results of
- * that step are not valid (a chain needs its <= 256 workgroups resident together; the word is cleared by the call; it
- * synchronises with the device).
- * The chain keeps a call counter, its tagged granules and the pointer table in the decoder WORKSPACE: zero the workspace once
- * before its first use and leave it alone between calls (session.py allocates it zeroed).                                     */
+ * Robustness.  The launch's workgroups wait for each other, so they must be resident together.  The library therefore takes the
+ * one-launch forms only when (a) the runtime's occupancy figure for the kernel at its LDS footprint times the device's CUs covers the
+ * grid (asked once per device and kernel variant), (b) the stream of the call owns every CU (a stream created with a CU mask that
+ * leaves it fewer -- wm_stream_create_cu_mask, hipExtStreamCreateWithCUMask -- takes the launch-per-kernel path) and (c) no earlier
+ * launch on the device has given up.  Every wait inside the launch is bounded (about a second): a wave that gives up sets a word in
+ * pinned host memory and the rest of the launch falls through.
+ * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a wait since the last call -- the results of that step and of
+ * everything decoded from it are NOT valid (another tenant held CUs or LDS while the launch was dispatched).  The call synchronises
+ * with the device, clears the word and takes the device off the one-launch forms (wm_set_decode_chain re-arms it): decode the
+ * utterance again, it now runs a launch per kernel (WhisperDecoding.main_loop / detect_language do exactly that, with one warning).
+ * Until it has been called, every wm_decoder_step / wm_decoder_step_multi on that device returns 1 (wm_last_error says why) -- a
+ * caller that never looks cannot go on decoding from garbage.  (Calls under stream capture are exempt: they enqueue nothing.)
+ * wm_decode_chain_status: what the calling thread's device has done so far (tests, diagnostics).                               */
+typedef struct wm_chain_status {
+    int32_t mode;               /* wm_set_decode_chain's current value */
+    int32_t declined;           /* 1: the device is off the one-launch forms (a launch gave up, or the occupancy check said no) */
+    int32_t error_pending;      /* 1: a give-up nobody has acknowledged yet */
+    int32_t pad_;
+    int64_t launches;           /* one-launch steps / layers issued (or captured) on this device */
+    int64_t declined_calls;     /* decoder calls that qualified by shape but took the launch-per-kernel path for reasons (a)-(c) */
+    char reason[160];           /* why the device is declined ("" if it is not) */
+} wm_chain_status;
 int wm_set_decode_chain(int on);
 int wm_decode_chain_error(int* out);
+int wm_decode_chain_status(wm_chain_status* out);
+/* Diagnostic: `n_workgroups` one-wave workgroups that each hold `lds_bytes` of LDS and sleep for `microseconds` on `stream` (a tenant
+ * that keeps CUs' LDS busy: tests/test_gpu_round5.py provokes the give-up path of the one-launch step with it).                 */
+int wm_debug_occupy(int n_workgroups, size_t lds_bytes, int64_t microseconds, wm_stream_t stream);
 /* Exact V-row skipping in the decode cross-attention (fp16 K/V, single-pass form): a key whose softmax probability rounds to
  * fp16 zero contributes exactly nothing to P.V, so the wave instructions whose 8 rows all weigh zero do not fetch them from
  * HBM (they re-read 8 rows the workgroup has just used).  Outputs are bit-identical with it on or off for finite V.  1 = on

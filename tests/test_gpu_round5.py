@@ -1,0 +1,362 @@
+"""Round 5 GPU tests (through the C ABI, on a real MI355X): the one-launch decode step at its product shape and under stress."""
+import ctypes as C
+import logging
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import build as B  # noqa: E402
+import native  # noqa: E402
+import synthetic  # noqa: E402
+from decoding import DecodingOptions, WhisperDecoding  # noqa: E402
+from encoding import WhisperEncoding  # noqa: E402
+from oracle.whisper_oracle import Dims, OracleConfig, OracleModel, greedy_reference_run, synthetic_mel  # noqa: E402
+
+LOGIT_TOL = 3e-2             # tests/test_gpu_model.py: fp16 activations, fp32 accumulate
+LOGIT_TOL_INT8_KV = 6e-2     # ... plus one LSB of the int8 cache
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return native.load_library()
+
+
+@pytest.fixture(scope="module")
+def tmpdir_module(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("engines5"))
+
+
+@pytest.fixture()
+def chain_rearmed(lib):
+    """Every test here starts with the one-launch forms armed at the default mode and leaves them so."""
+    lib.wm_set_decode_chain(-1)
+    err = C.c_int(0)
+    native.check(lib.wm_decode_chain_error(C.byref(err)))
+    lib.wm_set_decode_chain(-1)
+    yield
+    native.check(lib.wm_decode_chain_error(C.byref(err)))
+    lib.wm_set_decode_chain(-1)
+
+
+def _write_kv_scales(qdir, scales):
+    os.makedirs(qdir, exist_ok=True)
+    for i, s in enumerate(scales):
+        np.array([s], dtype=np.float32).tofile(os.path.join(qdir, f"model.decoder.blocks.{i}.attn.query_key_value.scale_y_quant_orig.bin"))
+
+
+def _small_engine(tmp, model="large-v2-6layer", weight_only=True, int8_kv=True):
+    from test_gpu_model import build_engine
+    dims = Dims(**synthetic.DIMS[model])
+    scales = [0.05 + 0.01 * i for i in range(dims.n_text_layer)] if int8_kv else None
+    return build_engine(tmp, model, 3, weight_only, int8_kv, scales), dims
+
+
+# ------------------------------------------------------------------------------------------ the default batch-1 path at FULL depth
+@pytest.mark.parametrize("quantised", [True, False])
+def test_full_depth_batch1_one_launch_step_matches_oracle_and_the_launch_per_kernel_path(lib, tmpdir_module, chain_rearmed, quantised):
+    """The reference's operating point (W/run.py:43-61, W/decoding.py:785-821: ONE utterance) on the product's default path at the
+    product's shape: large-v2, 32 + 32 layers -- exactly CHAIN_MAX_LAYERS of csrc/gemv_chain.hip -- weight-only int8 + int8 KV
+    (BASELINE.json configs[3]) and fp16 (configs[1]).
+      (a) batch-1 `main_loop` with the decode step as a launch per kernel / one launch per layer / ONE launch per token step, eagerly
+          and replayed from the captured graph: token ids, log-probabilities and every byte of the KV cache identical;
+      (b) the one-launch step teacher-forced with the GPU-resident oracle's ids through the in-place-cache call `main_loop` makes:
+          logits within the tolerance of the small models at every step, and bit-identical to the launch-per-kernel path's;
+      (c) the launches really were the one-launch form (wm_decode_chain_status counts them) and none gave up."""
+    dims = Dims(**synthetic.DIMS["large-v2"])
+    assert dims.n_text_layer == 32
+    ck = synthetic.synthetic_checkpoint("large-v2", 9, device="cuda")
+    sd = {k: v.cpu() for k, v in ck["model_state_dict"].items()}
+    mel = synthetic_mel(1, 3000, 80, 4242).cuda()
+    scales = None
+    if quantised:
+        cal = OracleModel(dims, sd, OracleConfig(act="float16", weight_only=True)).to("cuda")
+        scales = cal.calibrate_kv_scales(mel, 3)
+        del cal
+    oracle = OracleModel(dims, sd, OracleConfig(act="float16", weight_only=quantised, int8_kv=quantised, kv_scales=scales)).to("cuda")
+    del sd
+    prompt = [dims.n_vocab - 1607, dims.n_vocab - 1606, dims.n_vocab - 1506]
+    n_steps = 6
+    ref = greedy_reference_run(oracle, mel, prompt, n_steps)
+    del oracle
+    out = os.path.join(tmpdir_module, f"eng_large-v2_b1_{int(quantised)}")
+    argv = ["--output_dir", out, "--use_gpt_attention_plugin", "--use_gemm_plugin", "--use_layernorm_plugin", "--log_level", "error"]
+    if quantised:
+        qdir = os.path.join(tmpdir_module, "quantize_large-v2_b1", "1-gpu")
+        _write_kv_scales(qdir, scales)
+        argv += ["--use_weight_only", "--int8_kv_cache", "--quantize_dir", qdir]
+    B.build_from_checkpoint(ck, B.parse_arguments(argv))
+    del ck
+    torch.cuda.empty_cache()
+    tol = LOGIT_TOL_INT8_KV if quantised else LOGIT_TOL
+    enc = WhisperEncoding(Path(out))
+    xa = enc.get_audio_features(mel)
+
+    # ---- (b) teacher-forced, through Session.decoder_step with the in-place cache (what main_loop issues per token) ------------
+    def teacher_forced(mode):
+        lib.wm_set_decode_chain(mode)
+        dec = WhisperDecoding(Path(out))
+        cfg = dec.decoder_config
+        cap, V = cfg['num_text_ctx'], cfg['vocab_size']
+        st = dec._fast_state(1, xa.device)
+        cross = dec._cross_persistent(xa, st)
+        tokens = torch.zeros((1, cap + 1), dtype=torch.int32, device="cuda")
+        tokens[0, :3] = torch.tensor(prompt, dtype=torch.int32)
+        tokens[0, 3:3 + n_steps - 1] = ref["ids"][0, :n_steps - 1].to(torch.int32)
+        s = torch.cuda.current_stream().cuda_stream
+        sess, pos = dec.decoder_session, dec.positional_embedding
+        before = native.chain_status()["launches"]
+        logits3 = torch.empty((1, 3, V), dtype=torch.float16, device="cuda")
+        sess.decoder_step(tokens[:, :3], pos[0:3], cross, None, cap, st['kv'], cap, logits3, 0, s)
+        got = [logits3.clone()]
+        logits1 = torch.empty((1, 1, V), dtype=torch.float16, device="cuda")
+        for k in range(n_steps - 1):
+            cur = 3 + k + 1
+            sess.decoder_step(tokens[:, cur - 1:cur], pos[cur - 1:cur], cross, st['kv'], cap, st['kv'], cap, logits1, cur - 1, s)
+            got.append(logits1.clone())
+        torch.cuda.synchronize()
+        launches = native.chain_status()["launches"] - before
+        kv = [c[:, :, :, :3 + n_steps - 1].clone() for c in st['kv']]
+        del dec, st
+        return got, kv, launches
+
+    got2, kv2, n2 = teacher_forced(2)
+    got0, kv0, n0 = teacher_forced(0)
+    assert n2 == n_steps - 1 and n0 == 0, (n2, n0)              # (c) one launch per token step | none
+    worst = float((got2[0].float() - ref["logits"][0]).abs().max())
+    n_safe = n_ok = 0
+    for k in range(n_steps - 1):
+        worst = max(worst, float((got2[k + 1][:, 0].float() - ref["logits"][k + 1][:, 0]).abs().max()))
+        safe = bool(ref["margins"][0, k + 1] > 2 * tol)
+        n_safe += int(safe)
+        n_ok += int(safe and int(got2[k + 1][0, 0].float().argmax()) == int(ref["ids"][0, k + 1]))
+    print(f"full depth, batch 1, one launch per token step, quantised={quantised}: max|logits - oracle| = {worst:.4f}, ids {n_ok}/{n_safe}")
+    assert worst < tol, worst
+    assert n_ok == n_safe and n_safe > 0
+    for a, b in zip(got2, got0):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    for a, b in zip(kv2, kv0):
+        assert torch.equal(a, b)
+
+    # ---- (a) the loop itself, three forms x eager / replayed --------------------------------------------------------------------
+    outs = []
+    for mode in (0, 1, 2):
+        lib.wm_set_decode_chain(mode)
+        dec = WhisperDecoding(Path(out), options=DecodingOptions(sample_len=10))
+        dec.detect_language(xa)
+        for use_graphs in (False, True):
+            dec.use_graphs = use_graphs
+            for st in dec._state.values():
+                st['graphs'].clear()
+            before = native.chain_status()["launches"]
+            t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+            n_l = native.chain_status()["launches"] - before
+            assert (n_l > 0) == (mode > 0), (mode, use_graphs, n_l)
+            outs.append((mode, use_graphs, t.cpu(), lp.cpu(), [c.clone() for c in dec._state[1]['kv']]))
+        del dec
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"], st_
+    r = outs[0]
+    for mode, use_graphs, t, lp, kv in outs[1:]:
+        assert torch.equal(t, r[2]) and torch.equal(lp, r[3]), (mode, use_graphs)
+        for a, b in zip(kv, r[4]):
+            assert torch.equal(a, b), (mode, use_graphs)
+    assert len(set(r[2][0, 3:].tolist())) > 3                      # a real decode, not one token repeated
+
+
+# ------------------------------------------------------------------------------------------ hardening
+def test_one_launch_step_is_declined_on_a_cu_masked_stream(lib, tmpdir_module, chain_rearmed):
+    """A stream whose CU mask leaves it fewer CUs than the device has cannot hold the step's workgroups together: the library looks
+    at the mask of the stream of the call and takes the launch-per-kernel path there (no give-up, no second of spinning) -- same
+    bits as on an ordinary stream."""
+    eng, dims = _small_engine(tmpdir_module)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    masked = native.create_masked_stream([i < n_cu - 64 for i in range(n_cu)], 0)
+    full = native.create_masked_stream([True] * n_cu, 0)
+    res = {}
+    for name, strm in (("full", full), ("masked", masked), ("ordinary", torch.cuda.Stream())):
+        dec = WhisperDecoding(eng)
+        cfg = dec.decoder_config
+        cap, V = cfg['num_text_ctx'], cfg['vocab_size']
+        st = dec._fast_state(1, xa.device)
+        cross = dec._cross_persistent(xa, st)
+        tokens = torch.tensor([[50258, 50259, 50359, 1000, 2000]], dtype=torch.int32, device="cuda")
+        logits = torch.empty((1, 3, V), dtype=torch.float16, device="cuda")
+        torch.cuda.synchronize()
+        before = native.chain_status()
+        with torch.cuda.stream(strm):
+            dec.decoder_session.decoder_step(tokens[:, :3], dec.positional_embedding[0:3], cross, None, cap, st['kv'], cap, logits, 0, strm.cuda_stream)
+            l1 = torch.empty((1, 1, V), dtype=torch.float16, device="cuda")
+            dec.decoder_session.decoder_step(tokens[:, 3:4], dec.positional_embedding[3:4], cross, st['kv'], cap, st['kv'], cap, l1, 3, strm.cuda_stream)
+        torch.cuda.synchronize()
+        after = native.chain_status()
+        res[name] = (l1.clone(), after["launches"] - before["launches"], after["declined_calls"] - before["declined_calls"])
+        del dec, st
+    assert res["full"][1] == 1 and res["ordinary"][1] == 1 and res["masked"][1] == 0, {k: v[1:] for k, v in res.items()}
+    assert res["masked"][2] == 1
+    assert torch.equal(res["full"][0].view(torch.int16), res["masked"][0].view(torch.int16))
+    assert torch.equal(res["full"][0].view(torch.int16), res["ordinary"][0].view(torch.int16))
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"]
+
+
+def test_a_step_that_gives_up_is_decoded_again_on_the_launch_per_kernel_path(lib, tmpdir_module, chain_rearmed, caplog):
+    """Another tenant holds the LDS of half the CUs while the one-launch step is dispatched (wm_debug_occupy: 128 workgroups of 100 KB
+    that sleep for four seconds): the step's workgroups are not resident together, the ones that run give up after their bounded
+    waits (about a second) and set the error word.  `main_loop` notices, warns ONCE, and decodes the utterance again in the same
+    process on the launch-per-kernel path -- the tokens, log-probabilities and cache of an undisturbed run -- and the device stays
+    off the one-launch forms until wm_set_decode_chain re-arms it.  A caller of the C ABI that does not look gets rc != 0 from its
+    next wm_decoder_step."""
+    eng, dims = _small_engine(tmpdir_module)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=10))
+    dec.detect_language(xa)
+    t_ref, lp_ref, _ = dec.main_loop(xa, ignore_eot=True)
+    kv_ref = [c.clone() for c in dec._state[1]['kv']]
+    assert native.chain_status()["launches"] > 0 and not native.chain_status()["declined"]
+    del dec
+
+    # (1) through the product loop
+    WhisperDecoding._chain_warned = False
+    dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=10))
+    dec.detect_language(xa)
+    torch.cuda.synchronize()
+    hog = torch.cuda.Stream()
+    native.check(lib.wm_debug_occupy(128, 100 * 1024, 4_000_000, hog.cuda_stream))
+    with caplog.at_level(logging.WARNING, logger="whisper_mi355"):
+        t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), t_ref.cpu()) and torch.equal(lp.cpu(), lp_ref.cpu())
+    for a, b in zip(dec._state[1]['kv'], kv_ref):
+        assert torch.equal(a, b)
+    st_ = native.chain_status()
+    assert st_["declined"] and not st_["error_pending"] and "gave up" in st_["reason"], st_
+    assert sum("one-launch decode step gave up" in r.getMessage() for r in caplog.records) == 1
+    before = st_["launches"]
+    t2, _, _ = dec.main_loop(xa, ignore_eot=True)                   # declined: a launch per kernel, no chain launch any more
+    assert torch.equal(t2.cpu(), t_ref.cpu()) and native.chain_status()["launches"] == before
+    del dec
+
+    # (2) a C-ABI caller that never asks: the next call fails loudly until the give-up has been acknowledged
+    lib.wm_set_decode_chain(-1)                                    # re-armed
+    assert not native.chain_status()["declined"]
+    dec = WhisperDecoding(eng)
+    cfg = dec.decoder_config
+    cap, V = cfg['num_text_ctx'], cfg['vocab_size']
+    st = dec._fast_state(1, xa.device)
+    cross = dec._cross_persistent(xa, st)
+    tokens = torch.tensor([[50258, 50259, 50359, 1000, 2000]], dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    l3, l1 = torch.empty((1, 3, V), dtype=torch.float16, device="cuda"), torch.empty((1, 1, V), dtype=torch.float16, device="cuda")
+    dec.decoder_session.decoder_step(tokens[:, :3], dec.positional_embedding[0:3], cross, None, cap, st['kv'], cap, l3, 0, s)
+    torch.cuda.synchronize()
+    native.check(lib.wm_debug_occupy(128, 100 * 1024, 4_000_000, hog.cuda_stream))
+    dec.decoder_session.decoder_step(tokens[:, 3:4], dec.positional_embedding[3:4], cross, st['kv'], cap, st['kv'], cap, l1, 3, s)
+    torch.cuda.synchronize()
+    assert native.chain_status()["error_pending"]
+    with pytest.raises(native.WmError, match="gave up"):
+        dec.decoder_session.decoder_step(tokens[:, 4:5], dec.positional_embedding[4:5], cross, st['kv'], cap, st['kv'], cap, l1, 4, s)
+    err = C.c_int(0)
+    native.check(lib.wm_decode_chain_error(C.byref(err)))
+    assert err.value != 0
+    dec.decoder_session.decoder_step(tokens[:, 3:4], dec.positional_embedding[3:4], cross, st['kv'], cap, st['kv'], cap, l1, 3, s)      # acknowledged: works, a launch per kernel
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(l1.float()).all())
+
+
+@pytest.mark.parametrize("vouched", [True, False])
+def test_the_decoder_workspace_needs_no_initialisation(lib, tmpdir_module, chain_rearmed, vouched):
+    """The one-launch step keeps a call counter, tagged granules and a pointer table in the caller's workspace.  The caller hands the
+    workspace over as the allocator left it (INTEGRATION.md's stub: torch.empty); here it is filled with the worst garbage there is
+    -- the bytes a previous life of the SAME state left behind, at a later generation, and 0xFF / 0x00 patterns -- and given a new
+    identity (`vouched`) or none (workspace_id 0: the library re-initialises on every call).  Tokens, log-probabilities and cache of
+    the first, clean run come out every time, eagerly and replayed."""
+    eng, dims = _small_engine(tmpdir_module)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=10))
+    dec.detect_language(xa)
+    t_ref, lp_ref, _ = dec.main_loop(xa, ignore_eot=True)
+    kv_ref = [c.clone() for c in dec._state[1]['kv']]
+    import session as S
+    stale = {k: w.clone() for k, w in dec.decoder_session._workspaces.items()}          # the state as 10 + calls have left it
+    for fill in ("stale", 0xFF, 0x00, "random"):
+        for k, w in dec.decoder_session._workspaces.items():
+            if fill == "stale":
+                w.copy_(stale[k])
+            elif fill == "random":
+                w.copy_(torch.randint(0, 256, (w.numel(),), dtype=torch.uint8, device=w.device))
+            else:
+                w.fill_(fill)
+            w._wm_id = next(S._WORKSPACE_IDS) if vouched else 0
+        torch.cuda.synchronize()
+        for use_graphs in (False, True):
+            dec.use_graphs = use_graphs
+            for st in dec._state.values():
+                st['graphs'].clear()
+            dec.detect_language(xa)
+            t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+            assert torch.equal(t.cpu(), t_ref.cpu()) and torch.equal(lp.cpu(), lp_ref.cpu()), (fill, use_graphs)
+            for a, b in zip(dec._state[1]['kv'], kv_ref):
+                assert torch.equal(a, b), (fill, use_graphs)
+    st_ = native.chain_status()
+    assert st_["launches"] > 0 and not st_["error_pending"] and not st_["declined"], st_
+
+
+def test_a_first_call_under_stream_capture_carries_its_own_initialisation(lib, tmpdir_module, chain_rearmed):
+    """The library remembers which workspaces it has initialised -- but a call that is being CAPTURED enqueues nothing, so it must not
+    be remembered: a decoder step captured as the very first call on a workspace, replayed, then followed by an eager call with the
+    same pointers and workspace id, reads a table and granules that exist (before: the eager call skipped the table write and the
+    launch read null pointers)."""
+    eng, dims = _small_engine(tmpdir_module)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    outs = []
+    for captured_first in (False, True):
+        dec = WhisperDecoding(eng)
+        cfg = dec.decoder_config
+        cap, V = cfg['num_text_ctx'], cfg['vocab_size']
+        st = dec._fast_state(1, xa.device)
+        cross = dec._cross_persistent(xa, st)
+        tokens = torch.zeros((1, cap + 1), dtype=torch.int32, device="cuda")
+        tokens[0, :6] = torch.tensor([50258, 50259, 50359, 1000, 2000, 3000], dtype=torch.int32)
+        l3, l1 = torch.empty((1, 3, V), dtype=torch.float16, device="cuda"), torch.empty((1, 1, V), dtype=torch.float16, device="cuda")
+        side = torch.cuda.Stream()
+        sess, pos = dec.decoder_session, dec.positional_embedding
+        with torch.cuda.stream(side):
+            sess.decoder_step(tokens[:, :3], pos[0:3], cross, None, cap, st['kv'], cap, l3, 0, side.cuda_stream)       # (L = 3: another workspace)
+            counter = torch.full((1,), 3, dtype=torch.int32, device="cuda")
+            got = []
+            if captured_first:
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    sess.decoder_step(tokens, pos, cross, st['kv'], cap, st['kv'], cap, l1, 1, side.cuda_stream, n_past_dev=counter, n_new=1)
+                    native.check(lib.wm_step_advance(counter.data_ptr(), side.cuda_stream))
+                graph.replay()
+                got.append(l1.clone())
+                graph.replay()
+                got.append(l1.clone())
+            else:
+                for cur in (4, 5):
+                    sess.decoder_step(tokens[:, cur - 1:cur], pos[cur - 1:cur], cross, st['kv'], cap, st['kv'], cap, l1, cur - 1, side.cuda_stream)
+                    got.append(l1.clone())
+            # ... and an eager call on the SAME workspace (same shapes, same id) behind the replays
+            sess.decoder_step(tokens, pos, cross, st['kv'], cap, st['kv'], cap, l1, 1, side.cuda_stream,
+                              n_past_dev=torch.full((1,), 5, dtype=torch.int32, device="cuda"), n_new=1)
+            got.append(l1.clone())
+        torch.cuda.synchronize()
+        outs.append(got)
+        del dec, st
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"], st_

@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/whisper_mi355.h but not exported"
     assert declared == set(native.EXPORTS)
-    assert lib.wm_version() == native.ABI_VERSION == 6
+    assert lib.wm_version() == native.ABI_VERSION == 7
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -40,7 +40,8 @@ def test_struct_layouts_match_header(tmp_path):
     fields = {"wm_dims": [n for n, _ in native.WmDims._fields_],
               "wm_decoder_io": [n for n, _ in native.WmDecoderIO._fields_],
               "wm_greedy_io": [n for n, _ in native.WmGreedyIO._fields_],
-              "wm_gemv_io": [n for n, _ in native.WmGemvIO._fields_]}
+              "wm_gemv_io": [n for n, _ in native.WmGemvIO._fields_],
+              "wm_chain_status": [n for n, _ in native.WmChainStatus._fields_]}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "whisper_mi355.h"', 'int main(void){']
     for s, fs in fields.items():
         src.append(f'printf("{s} %zu\\n", sizeof({s}));')
@@ -51,7 +52,7 @@ def test_struct_layouts_match_header(tmp_path):
                            str(tmp_path / "l.c"), "-o", str(tmp_path / "l")])
     got = dict(line.split() for line in subprocess.check_output([str(tmp_path / "l")]).decode().splitlines())
     for s, cls in (("wm_dims", native.WmDims), ("wm_decoder_io", native.WmDecoderIO), ("wm_greedy_io", native.WmGreedyIO),
-                   ("wm_gemv_io", native.WmGemvIO)):
+                   ("wm_gemv_io", native.WmGemvIO), ("wm_chain_status", native.WmChainStatus)):
         assert int(got[s]) == C.sizeof(cls), s
         for f in fields[s]:
             assert int(got[f"{s}.{f}"]) == getattr(cls, f).offset, f"{s}.{f}"
