@@ -118,42 +118,70 @@ def cpu_baseline(args, decode_steps: int, time_cap_s: float = 150.0):
     mode (fp32-stored parameters, fp16 activations, W/torch_model.py:25-45 -- how W/summarize.py:81-84,121 runs it) --
     encoder, cross K/V, language-ID pass, 3-token prefill and the greedy steps.  The decode loop is timed for as many
     of the `decode_steps` tokens as fit in the time cap (every step costs the same: the per-token time of the measured
-    steps is applied to the rest, and `sample` says how many were measured)."""
+    steps is applied to the rest, and `sample` says how many were measured).
+    Threads: a short sweep first (encoder once + 3 greedy steps at 16 / 32 / 64 / 128 threads, as far as the box has cores) picks
+    the count with the fastest whole clip (127 steps + encoder); the sweep is reported (`thread_sweep`), `cores` is what the timed
+    clip used.  `tiny_en`: the same path for tiny.en's shape (BASELINE.json configs[0]), every step measured."""
     from oracle.whisper_oracle import Dims, OracleConfig, OracleModel
     import synthetic
-    d = dict(synthetic.DIMS[args.model])
-    cores = min(os.cpu_count() or 1, 32)      # torch's CPU kernels stop scaling (and regress) far below 256 threads
+    n_cpu = os.cpu_count() or 1
+
+    def build(model_name):
+        d = dict(synthetic.DIMS[model_name])
+        # same distributions as the engines' weights, drawn on the GPU (seconds instead of minutes for 1.5e9 values), moved to the host
+        sd = synthetic.synthetic_state_dict(d, args.seed, device="cuda" if torch.cuda.is_available() else None)
+        dims = Dims(**d)
+        model = OracleModel(dims, {k: v.cpu() for k, v in sd.items()}, OracleConfig(act="float16"))
+        return dims, model, synthetic.synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 1234)
+
+    def clip(dims, model, mel, steps, cap_s):
+        t_start = time.perf_counter()
+        with torch.no_grad():
+            t = time.perf_counter(); xa = model.encoder(mel); t_enc = time.perf_counter() - t
+            t = time.perf_counter(); ckv = model.cross_kv(xa); t_ckv = time.perf_counter() - t
+            sot = dims.n_vocab - 1607                          # <|startoftranscript|> of either vocabulary
+            t = time.perf_counter(); model.decoder(torch.tensor([[sot]]), ckv, None); t_lang = time.perf_counter() - t
+            t = time.perf_counter(); logits, kv = model.decoder(torch.tensor([[sot, sot + 1, sot + 101]]), ckv, None); t_pre = time.perf_counter() - t
+            n_meas, t_loop = 0, 0.0
+            while n_meas < steps - 1 and (n_meas < 3 or time.perf_counter() - t_start < cap_s):
+                t = time.perf_counter()
+                logits, kv = model.decoder(logits[:, -1:].argmax(-1), ckv, kv)
+                t_loop += time.perf_counter() - t
+                n_meas += 1
+        return dict(enc=t_enc, ckv=t_ckv, lang=t_lang, pre=t_pre, step=t_loop / max(n_meas, 1), n=n_meas)
+
+    dims, model, mel = build(args.model)
+    sweep = {}
+    for n in (16, 32, 64, 128):
+        if n <= n_cpu:
+            torch.set_num_threads(n)
+            r = clip(dims, model, mel, 4, 0.0)
+            sweep[str(n)] = {"encoder_s": round(r["enc"], 3), "step_s": round(r["step"], 4),
+                             "clip_estimate_s": round(r["enc"] + r["ckv"] + r["lang"] + r["pre"] + (decode_steps - 1) * r["step"], 2)}
+    cores = int(min(sweep, key=lambda k: sweep[k]["clip_estimate_s"])) if sweep else min(n_cpu, 32)
     torch.set_num_threads(cores)
-    dims = Dims(**d)
-    # same distributions as the engines' weights, drawn on the GPU (seconds instead of minutes for 1.5e9 values), moved to the host
-    sd = synthetic.synthetic_state_dict(d, args.seed, device="cuda" if torch.cuda.is_available() else None)
-    sd = {k: v.cpu() for k, v in sd.items()}
-    model = OracleModel(dims, sd, OracleConfig(act="float16"))
-    del sd
-    mel = synthetic.synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 1234)
-    t_start = time.perf_counter()
-    with torch.no_grad():
-        t = time.perf_counter(); xa = model.encoder(mel); t_enc = time.perf_counter() - t
-        t = time.perf_counter(); ckv = model.cross_kv(xa); t_ckv = time.perf_counter() - t
-        sot = dims.n_vocab - 1607                          # <|startoftranscript|> of either vocabulary
-        t = time.perf_counter(); model.decoder(torch.tensor([[sot]]), ckv, None); t_lang = time.perf_counter() - t
-        t = time.perf_counter(); logits, kv = model.decoder(torch.tensor([[sot, sot + 1, sot + 101]]), ckv, None); t_pre = time.perf_counter() - t
-        n_meas, t_loop = 0, 0.0
-        while n_meas < decode_steps - 1 and (n_meas < 4 or time.perf_counter() - t_start < time_cap_s):
-            t = time.perf_counter()
-            logits, kv = model.decoder(logits[:, -1:].argmax(-1), ckv, kv)
-            t_loop += time.perf_counter() - t
-            n_meas += 1
-    t_step = t_loop / max(n_meas, 1)
-    total = t_enc + t_ckv + t_lang + t_pre + (decode_steps - 1) * t_step
-    return {
-        "value": round(decode_steps / total, 3), "unit": "tokens/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+    r = clip(dims, model, mel, decode_steps, time_cap_s)
+    total = r["enc"] + r["ckv"] + r["lang"] + r["pre"] + (decode_steps - 1) * r["step"]
+    out = {
+        "value": round(decode_steps / total, 3), "unit": "tokens/s", "cores": cores, "host_cpu_count": n_cpu, "kind": "port",
         "rtf": round(total / 30.0, 3),
         "sample": (f"oracle, fp16-input mode, batch 1, {args.model} at full depth ({dims.n_audio_layer}+{dims.n_text_layer} layers): "
-                   f"encoder {t_enc:.2f}s, cross-K/V {t_ckv:.2f}s, language-ID pass {t_lang:.2f}s, prefill {t_pre:.2f}s, "
-                   f"{n_meas} of {decode_steps - 1} greedy steps measured at {t_step:.3f}s each"
-                   + ("" if n_meas == decode_steps - 1 else f" (time cap {time_cap_s:.0f}s; the rest priced at that rate)")),
+                   f"encoder {r['enc']:.2f}s, cross-K/V {r['ckv']:.2f}s, language-ID pass {r['lang']:.2f}s, prefill {r['pre']:.2f}s, "
+                   f"{r['n']} of {decode_steps - 1} greedy steps measured at {r['step']:.3f}s each"
+                   + ("" if r["n"] == decode_steps - 1 else f" (time cap {time_cap_s:.0f}s; the rest priced at that rate)")),
+        "thread_sweep": sweep or None,
+        "thread_sweep_note": "encoder once + 3 greedy steps per thread count (torch.set_num_threads), whole clip priced from them; `cores` = the fastest",
     }
+    del model
+    if "tiny.en" in synthetic.DIMS and args.model != "tiny.en":
+        d2, m2, mel2 = build("tiny.en")
+        r2 = clip(d2, m2, mel2, decode_steps, 60.0)
+        t2 = r2["enc"] + r2["ckv"] + r2["lang"] + r2["pre"] + (decode_steps - 1) * r2["step"]
+        out["tiny_en"] = {"value": round(decode_steps / t2, 2), "unit": "tokens/s", "rtf": round(t2 / 30.0, 4), "cores": cores,
+                          "sample": (f"oracle, fp16-input mode, batch 1, tiny.en's shape ({d2.n_audio_layer}+{d2.n_text_layer} layers, {d2.n_vocab} tokens; "
+                                     f"BASELINE.json configs[0]): encoder {r2['enc']:.3f}s, cross-K/V {r2['ckv']:.3f}s, first pass {r2['lang']:.3f}s, "
+                                     f"prefill {r2['pre']:.3f}s, {r2['n']} greedy steps at {r2['step'] * 1e3:.1f} ms each")}
+    return out
 
 
 def pmc_traffic(group: int, kv_bytes: int) -> dict:

@@ -167,16 +167,23 @@ def eval_torch(whisper_encoding, whisper_decoding, mel, model) -> list:
     return whisper_decoding.post_process(tokens, sum_logprobs, no_speech_probs, audio_features, languages)
 
 
-def load_torch_model(checkpoint_file: str, device):
-    try:
-        from whisper.model import ModelDimensions, Whisper          # openai-whisper
-    except ImportError as e:
-        raise RuntimeError("--test_torch needs a PyTorch Whisper implementation (pip package `openai-whisper`); "
-                           "the engines themselves do not") from e
-    checkpoint = torch.load(checkpoint_file, map_location="cpu")
-    model = Whisper(ModelDimensions(**checkpoint["dims"]))
-    model.load_state_dict(checkpoint["model_state_dict"])
-    return model.to(device)
+def load_torch_model(checkpoint_file: str, device, factory: Optional[str] = None):
+    """The model of the PyTorch comparison path (W/summarize.py:78-84 builds the reference's in-tree `Whisper` from the checkpoint).
+    Default: this package's own PyTorch Whisper (torch_model.py) over the same checkpoint.  `factory` = "module:callable" names any
+    other implementation: `callable(checkpoint_file, device)` must return an object with `.encoder(mel)`, `.logits(tokens, xa)`,
+    `.decoder(tokens, xa, kv_cache=)` and `.install_kv_cache_hooks()` -- what eval_torch drives (e.g. openai-whisper's `Whisper`)."""
+    if factory:
+        import importlib
+        mod_name, _, fn_name = factory.partition(":")
+        fn = getattr(importlib.import_module(mod_name), fn_name or "load_model")
+        model = fn(checkpoint_file, device)
+    else:
+        import torch_model
+        model = torch_model.load_model(checkpoint_file, device)
+    for need in ("encoder", "logits", "decoder", "install_kv_cache_hooks"):
+        if not hasattr(model, need):
+            raise RuntimeError(f"--torch_model {factory}: the object it returned has no `{need}`")
+    return model
 
 
 def score(hypotheses: List[str], references: List[str], normalizer=None) -> float:
@@ -282,16 +289,21 @@ def main(args) -> Optional[dict]:
     import torch.distributed as dist
     import dp
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(args.device) if args.device else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+    if args.test_trt_llm and device.type != "cuda":
+        raise RuntimeError("--test_trt_llm runs the HIP engines: it needs a GPU (only --test_torch runs on the host)")
     engine_dir = Path(args.engine_dir)
-    whisper_encoding = WhisperEncoding(engine_dir)
-    whisper_decoding = WhisperDecoding(engine_dir, vocab_path=args.vocab)
+    only_torch = not args.test_trt_llm                 # the PyTorch path alone needs the engine directory's configuration, not its engines
+    whisper_encoding = WhisperEncoding(engine_dir, only_torch=only_torch)
+    whisper_decoding = WhisperDecoding(engine_dir, only_torch=only_torch, vocab_path=args.vocab)
+    if args.sample_len:
+        whisper_decoding.sample_len = args.sample_len
     pairs = discover(args.dataset_dir)
     mine = rank_share(pairs, args.batch_size, rank, world, whisper_decoding.balanced_order, args.no_sort_by_duration)
     report = {}
     runs = []
     if args.test_torch:
-        model = load_torch_model(args.checkpoint_file, device)
+        model = load_torch_model(args.checkpoint_file, device, args.torch_model)
         runs.append(("Torch", lambda mel: eval_torch(whisper_encoding, whisper_decoding, mel, model)))
     if args.test_trt_llm:
         runs.append(("whisper-mi355", lambda mel: eval_engines(whisper_encoding, whisper_decoding, mel)))
@@ -307,7 +319,7 @@ def main(args) -> Optional[dict]:
             logger.info(f"{name} (total latency: {seconds} sec)")
             logger.info(f"{name} beam 0 result")
             logger.info(f"\nWER: {value * 100:.2f} %")
-            report[name] = dict(wer=value, seconds=seconds, utterances=len(hyps))
+            report[name] = dict(wer=value, seconds=seconds, utterances=len(hyps), hypotheses=list(hyps))
     return report if rank == 0 else None
 
 
@@ -324,6 +336,10 @@ def parse_arguments(argv=None):
     parser.add_argument('--vocab', type=str, default=None, help='path to multilingual.tiktoken / gpt2.tiktoken')
     parser.add_argument('--no_sort_by_duration', action='store_true',
                         help='keep the directory order instead of batching clips of similar duration (plan_batches)')
+    parser.add_argument('--torch_model', type=str, default=None,
+                        help='--test_torch: "module:callable" returning the PyTorch model for (checkpoint_file, device); default: torch_model.load_model')
+    parser.add_argument('--device', type=str, default=None, help='default: the current GPU (cpu serves --test_torch alone)')
+    parser.add_argument('--sample_len', type=int, default=None, help='tokens sampled per utterance at most (default: n_text_ctx // 2)')
     parser.add_argument('--overlap_encoder', action='store_true',
                         help='run the encoder of the next batch beside the decode loop of the current one (eval_engines_stream)')
     return parser.parse_args(argv)
