@@ -599,12 +599,13 @@ DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
     w.part = c.take<float>(w.part_elems);
     w.nsplit = cross_nsplit(B, d.n_text_head);
     w.cross_ws = c.take<float>((size_t)B * d.n_text_head * w.nsplit * L * 66);
-    w.gran_x = c.take<unsigned long long>(C / 2 + 8);
-    w.gran_h = c.take<unsigned long long>(2 * C + 8);
-    w.gran_q = c.take<unsigned long long>(C + 8);
-    w.gran_c = c.take<unsigned long long>(C / 2 + 8);
-    w.gran_p = c.take<unsigned long long>((size_t)d.n_text_head * 66 * 4 + 8);
-    w.gran_s = c.take<unsigned long long>(3 * C + 8);
+    const size_t R = M < (size_t)CHAIN_MAX_ROWS ? M : (size_t)CHAIN_MAX_ROWS;      // rows the one-launch step serves (gemv_chain.hip): every edge [rows][...]
+    w.gran_x = c.take<unsigned long long>(R * (C / 2) + 8);
+    w.gran_h = c.take<unsigned long long>(R * 2 * C + 8);
+    w.gran_q = c.take<unsigned long long>(R * C + 8);
+    w.gran_c = c.take<unsigned long long>(R * (C / 2) + 8);
+    w.gran_p = c.take<unsigned long long>(R * d.n_text_head * 66 * 4 + 8);
+    w.gran_s = c.take<unsigned long long>(R * 3 * C + 8);
     w.layer_io = c.take<wm::ChainLayerIo>((size_t)d.n_text_layer);
     w.generation = c.take<unsigned>(4);
     w.total = align_up(c.off);
@@ -671,7 +672,7 @@ struct ChainDev {
     std::mutex mu;
     int n_cu = 0;
     unsigned* err_host = nullptr; unsigned* err_dev = nullptr;
-    bool declined = false; std::string reason;
+    bool declined = false; std::string reason, footprint;
     std::map<long long, bool> resident;
     std::atomic<long long> launches{0};
     std::atomic<long long> declined_calls{0};
@@ -747,6 +748,12 @@ int self_attn_waves(int rows) {
     return w ? w : (rows <= small_path_max_rows() ? 4 : 1);
 }
 
+// rows (utterances) of a group the one-launch step serves: CHAIN_MAX_ROWS (2) unless WM_CHAIN_ROWS=1 keeps it to one (lab: A/B runs)
+int chain_max_rows() {
+    static const int r = [] { const int v = lab_env_int("WM_CHAIN_ROWS", CHAIN_MAX_ROWS); return v < 1 ? 1 : (v > CHAIN_MAX_ROWS ? CHAIN_MAX_ROWS : v); }();
+    return r;
+}
+
 struct GroupStep {
     const wm_engine* e; const wm_decoder_io* io; DecWs w;
     int B, L, T, C, H, M;
@@ -813,14 +820,14 @@ struct GroupStep {
                       "takes the launch-per-kernel path from then on (wm_set_decode_chain re-arms the one-launch forms)", e->device);
             return 1;
         }
-        if (alone && small && M == 1 && !e->dec.empty() && e->chain_dev && g_decode_chain.load(std::memory_order_relaxed) && !io->qkv_amax) {
+        if (alone && small && L == 1 && M <= chain_max_rows() && !e->dec.empty() && e->chain_dev && g_decode_chain.load(std::memory_order_relaxed) && !io->qkv_amax) {
             if (chain_dev_init(cd, e->device)) return 2;
             const int n_cu = cd.n_cu;
             // one-row groups run a decoder layer (or the whole step) as one launch -- with the in-place cache (past[i] == present[i]), four
             // key-range pieces, fp16 cross K/V, the four-wave self-attention form; anything else takes the launch-per-kernel path
             chain_wgs = n_cu > 256 ? 256 : n_cu; chain_err = cd.err_dev; chain_cd = &cd;
             bool ok = gemv_chain_supports(C, e->dec[0].qkv.wcode, n_cu) && w.nsplit == 4 && !e->i8cross() && self_attn_waves(M) == 4 &&
-                      io->present_capacity <= 512 && H + H * w.nsplit <= chain_wgs;
+                      io->present_capacity <= 512 && M * (H + H * w.nsplit) <= chain_wgs;
             for (int i = 0; ok && i < e->dims.n_text_layer; ++i)
                 ok = io->present[i] && io->cross[i] &&
                      (T == 0 ? io->n_past_dev == nullptr : (io->past[i] == io->present[i] && io->past_capacity == io->present_capacity));
@@ -830,13 +837,15 @@ struct GroupStep {
                 std::lock_guard<std::mutex> lk(cd.mu);
                 ok = !cd.declined;
                 if (ok) {
-                    const long long key = ((long long)e->dec[0].qkv.wcode << 40) | ((long long)(e->i8kv() ? 1 : 0) << 32) | ((long long)e->dims.n_audio_ctx << 8) | w.nsplit;
+                    const long long key = ((long long)M << 48) | ((long long)e->dec[0].qkv.wcode << 40) | ((long long)(e->i8kv() ? 1 : 0) << 32) | ((long long)e->dims.n_audio_ctx << 8) | w.nsplit;
                     auto it = cd.resident.find(key);
                     if (it == cd.resident.end()) {
                         bool fits = false;
-                        if (gemv_chain_resident(e->dec[0].qkv.wcode, e->i8kv() ? 1 : 0, e->dims.n_audio_ctx, w.nsplit, chain_wgs, n_cu, &fits)) return 2;
+                        char why[200] = "";
+                        if (gemv_chain_resident(e->dec[0].qkv.wcode, e->i8kv() ? 1 : 0, M, e->dims.n_audio_ctx, w.nsplit, chain_wgs, n_cu, &fits, why, sizeof(why))) return 2;
                         it = cd.resident.emplace(key, fits).first;
-                        if (!fits) cd.reason = "the runtime's occupancy figure says the device cannot hold the launch's workgroups together";
+                        cd.footprint = why;
+                        if (!fits) cd.reason = why;
                     }
                     ok = it->second;
                 }
@@ -858,6 +867,9 @@ struct GroupStep {
         p.out32 = w.part; p.w8 = e->dec[0].out.wcode; p.gelu_kind = e->gelu();
         p.x = w.x; p.gran_x = w.gran_x; p.gran_h = w.gran_h; p.err = chain_err;
         p.generation = w.generation;
+        p.rows = M;                                   // (L == 1: one row per utterance; the utterances' buffers are slices of [B, 2, H, T, 64])
+        p.cross_row_bytes = (long)2 * H * d.n_audio_ctx * 64 * 2;
+        p.self_row_bytes = (long)2 * H * io->present_capacity * 64 * (e->i8kv() ? 1 : 2);
     }
 
     // decoder layer i of a one-row group as ONE launch (gemv_chain.hip): self-attention, out, cq, cross-attention, merge + cout, mlp1,
@@ -1414,6 +1426,7 @@ int wm_decode_chain_status(wm_chain_status* out) {
     out->declined = cd.declined ? 1 : 0;
     out->error_pending = chain_err_peek(cd) ? 1 : 0;
     snprintf(out->reason, sizeof(out->reason), "%s", cd.reason.c_str());
+    snprintf(out->footprint, sizeof(out->footprint), "%s", cd.footprint.c_str());
     return 0;
 }
 

@@ -94,7 +94,79 @@ enum ChainIn : int {
     CHAIN_IN_LDS = 0,          // the row is in s_in[0] already (chain_merge_tagged has put it there)
     CHAIN_IN_GRANULES = 1      // an fp16 row published as granules in this launch: `gran`, tagged `tag`
 };
-template <int WB, bool WIDE, bool LN>
+// NR activation rows (1 | 2).  The MFMA's 16 A rows carry the activation rows alternately (A row = lane & 15, row = lane & (NR - 1)), so
+// a row's sums are the same chain of MFMA steps whatever NR is, and come out in accumulator element `row` of the first 16 lanes.
+// Where the rows of a stage's input sit in LDS (s_in is two arrays of CHAIN_MAX_IN + 8 halves):
+//   NR == 1: s_in[slot] -- every slot keeps its own copy (no barrier between a slot's sweep and its reads)
+//   NR == 2: rows the whole workgroup shares (LayerNorm output, merged attention rows, the wide stage's hidden rows): s_in[row];
+//            rows a slot sweeps for itself (K <= 1536): four blocks of 1544 halves, block 2 * slot + row
+template <int NR, bool WIDE, bool SHARED>
+__device__ __forceinline__ h16* chain_in_row(h16 (*s_in)[CHAIN_MAX_IN + 8], int slot, int row) {
+    if constexpr (NR == 1) return &s_in[slot][0];
+    else if constexpr (WIDE || SHARED) return &s_in[row][0];
+    else return &s_in[0][0] + (2 * slot + row) * 1544;
+}
+
+// gemv_small's LayerNorm of ONE row by one wave: the row in registers (a lane: pieces lane, lane + 64, lane + 128 of 8 halves), two-pass
+// fp32 statistics, affine step, the normalised row to `dst` in LDS -- same operations, same order.  The row comes from plain memory
+// (`xrow`: as the launches before this one left it) or from the granules the previous stage's owners have just published (`gx`, `tag`).
+__device__ __forceinline__ void chain_ln_row(const GemvChainParams& p, const ChainStage& st, const h16* xrow, const unsigned long long* gx, unsigned tag,
+                                             bool x_in_granules, h16* dst, int lane) {
+    constexpr int XP = 3;
+    const int pieces_per_row = st.K >> 3;
+    half8v xr[XP], gp[XP], bp[XP];
+#pragma unroll
+    for (int u = 0; u < XP; ++u) {
+        gp[u] = *CHAIN_GLOBAL(half8v, st.ln_g + min(lane + 64 * u, pieces_per_row - 1) * 8);
+        bp[u] = *CHAIN_GLOBAL(half8v, st.ln_b + min(lane + 64 * u, pieces_per_row - 1) * 8);
+    }
+    bool ok = true;
+    if (!x_in_granules) {                             // the row as the launches before this one left it (plain memory)
+#pragma unroll
+        for (int u = 0; u < XP; ++u) xr[u] = *(const half8v*)(xrow + min(lane + 64 * u, pieces_per_row - 1) * 8);
+    } else {                                          // the row the previous stage's owners have just published
+        int first[2 * XP];
+        u32x4 val[2 * XP];
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {                // piece q = granules 4 q .. 4 q + 3 = two 16-byte loads
+            const int q = min(lane + 64 * u, pieces_per_row - 1);
+            first[2 * u] = 4 * q; first[2 * u + 1] = 4 * q + 2;
+        }
+        ok = sweep_granules16<2 * XP>(gx, first, tag, val, p.err, lane);
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const u32x4 v = u32x4{val[2 * u].x, val[2 * u].z, val[2 * u + 1].x, val[2 * u + 1].z};
+            xr[u] = __builtin_bit_cast(half8v, v);
+        }
+    }
+    if (ok) {
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < XP; ++u)
+            if (lane + 64 * u < pieces_per_row) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += (float)xr[u][e];
+            }
+        const float mean = wave_sum_pre_mfma(sum) / (float)st.K;
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < XP; ++u)
+            if (lane + 64 * u < pieces_per_row) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)xr[u][e] - mean; sq += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum_pre_mfma(sq) / (float)st.K + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            half8v x = xr[u];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (h16)(((float)x[e] - mean) * rstd * (float)gp[u][e] + (float)bp[u][e]);
+            if (lane + 64 * u < pieces_per_row) *(half8v*)(dst + (lane + 64 * u) * 8) = x;
+        }
+    }
+}
+
+template <int WB, bool WIDE, bool LN, int NR>
 __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const ChainStage& st, int s, unsigned epoch, bool& own_valid,
                                             float (*s_red)[64][4], h16 (*s_in)[CHAIN_MAX_IN + 8], h16 (*s_own)[16],
                                             int in_kind, const unsigned long long* gran, unsigned tag, bool x_in_granules) {
@@ -111,6 +183,8 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     const int grp = blockIdx.x + slot * gridDim.x;            // this slot's group of 16 output channels
     const bool has_group = grp < st.n_blocks;
     const int nb = has_group ? grp : st.n_blocks - 1;         // (idle slots re-read valid memory; nothing of theirs is stored)
+    const int n_out = st.n_blocks * 16;                       // output channels of the stage = elements between the rows of its outputs
+    const int row_a = NR == 1 ? 0 : rl & (NR - 1);            // the activation row this lane's A fragments carry
 
     // an idle slot (no group of this stage falls to it) only keeps the workgroup's barriers company: it touches no memory, so that
     // waves which carry LDS-DMA requests for a later stage (the cross-attention's K / V rows) are not made to wait for them here
@@ -150,99 +224,57 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 
     // ---- 2. the stage's input row ------------------------------------------------------------------------------------------
     if constexpr (LN) {
-        // gemv_small's LayerNorm at one row: wave 0 of the slot holds the row in registers (a lane: pieces lane, lane + 64,
-        // lane + 128 of 8 halves), two-pass fp32 statistics, affine step, the normalised row to LDS -- same operations, same order
-        constexpr int XP = 3;
-        const int pieces_per_row = st.K >> 3;
-        if (wslot == 0 && has_group) {
-            half8v xr[XP], gp[XP], bp[XP];
-#pragma unroll
-            for (int u = 0; u < XP; ++u) {
-                gp[u] = *CHAIN_GLOBAL(half8v, st.ln_g + min(lane + 64 * u, pieces_per_row - 1) * 8);
-                bp[u] = *CHAIN_GLOBAL(half8v, st.ln_b + min(lane + 64 * u, pieces_per_row - 1) * 8);
-            }
-            bool ok = true;
-            if (!x_in_granules) {                             // the row as the launches before this one left it (plain memory)
-#pragma unroll
-                for (int u = 0; u < XP; ++u) xr[u] = *(const half8v*)(p.x + min(lane + 64 * u, pieces_per_row - 1) * 8);
-            } else {                                          // the row the previous stage's owners have just published
-                int first[2 * XP];
-                u32x4 val[2 * XP];
-#pragma unroll
-                for (int u = 0; u < XP; ++u) {                // piece q = granules 4 q .. 4 q + 3 = two 16-byte loads
-                    const int q = min(lane + 64 * u, pieces_per_row - 1);
-                    first[2 * u] = 4 * q; first[2 * u + 1] = 4 * q + 2;
-                }
-                ok = sweep_granules16<2 * XP>(p.gran_x, first, epoch - 1, val, p.err, lane);
-#pragma unroll
-                for (int u = 0; u < XP; ++u) {
-                    const u32x4 v = u32x4{val[2 * u].x, val[2 * u].z, val[2 * u + 1].x, val[2 * u + 1].z};
-                    xr[u] = __builtin_bit_cast(half8v, v);
-                }
-            }
-            if (ok) {
-                float sum = 0.f;
-#pragma unroll
-                for (int u = 0; u < XP; ++u)
-                    if (lane + 64 * u < pieces_per_row) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) sum += (float)xr[u][e];
-                    }
-                const float mean = wave_sum_pre_mfma(sum) / (float)st.K;
-                float sq = 0.f;
-#pragma unroll
-                for (int u = 0; u < XP; ++u)
-                    if (lane + 64 * u < pieces_per_row) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { const float d = (float)xr[u][e] - mean; sq += d * d; }
-                    }
-                const float rstd = rsqrtf(wave_sum_pre_mfma(sq) / (float)st.K + 1e-5f);
-#pragma unroll
-                for (int u = 0; u < XP; ++u) {
-                    half8v x = xr[u];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = (h16)(((float)x[e] - mean) * rstd * (float)gp[u][e] + (float)bp[u][e]);
-                    if (lane + 64 * u < pieces_per_row) *(half8v*)(&s_in[slot][(lane + 64 * u) * 8]) = x;
-                }
-            }
+        // NR == 1: wave 0 of the slot normalises the row for its slot.  NR == 2: waves 0 and 1 of the WORKGROUP (slot 0's: they never
+        // carry LDS-DMA requests) normalise rows 0 and 1, once, for both slots
+        if constexpr (NR == 1) {
+            if (wslot == 0) chain_ln_row(p, st, p.x, p.gran_x, epoch - 1, x_in_granules, chain_in_row<NR, WIDE, true>(s_in, slot, 0), lane);
+        } else {
+            if (wid < NR) chain_ln_row(p, st, p.x + wid * st.K, p.gran_x + wid * (st.K >> 1), epoch - 1, x_in_granules, chain_in_row<NR, WIDE, true>(s_in, 0, wid), lane);
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
             const int t_last = max(t_end[0] - 1, t_begin[0]);
-            const h16* arow = &s_in[slot][0] + (KT / 4) * g + (size_t)min(t_begin[0] + i, t_last) * KT;
+            const h16* arow = chain_in_row<NR, WIDE, true>(s_in, slot, row_a) + (KT / 4) * g + (size_t)min(t_begin[0] + i, t_last) * KT;
 #pragma unroll
             for (int m = 0; m < NM; ++m) a[0][i][m] = *(const half8v*)(arow + m * 8);
         }
     } else if (!WIDE && in_kind == CHAIN_IN_LDS) {
-        // the merged attention row is in s_in[0] (chain_merge_tagged, all eight waves, ended by a barrier)
+        // the merged attention rows are in s_in[row] (chain_merge_tagged, all eight waves, ended by a barrier)
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int t_last = max(t_end[j] - 1, t_begin[j]);
 #pragma unroll
             for (int i = 0; i < TB; ++i) {
-                const h16* arow = &s_in[0][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
+                const h16* arow = &s_in[row_a][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
 #pragma unroll
                 for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
             }
         }
     } else {
-        // the hidden row the previous stage has just published (mode 1): every wave sweeps the granules of ITS K slices into LDS
-        // (tps x KT halves per slice = 3 16-byte loads per lane at most) and reads its fragments back -- no barrier, its own data
+        // the hidden rows the previous stage has just published (mode 1): every wave sweeps the granules of ITS K slices into LDS
+        // (tps x KT halves per slice = 3 16-byte loads per lane and row at most, both rows in one pass) and reads its fragments
+        // back -- no barrier, its own data
+        const int in_stride = st.K >> 1;                                      // granules between the rows of the stage's input
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int n_in = (t_end[j] - t_begin[j]) * KT;                    // halves of this slice (0: absent)
             const int g0 = t_begin[j] * KT / 2;                               // first granule
             const int n_ld = n_in / 4;                                        // 16-byte loads (4 halves each)
-            int first[3];
-            u32x4 val[3];
+            int first[3 * NR];
+            u32x4 val[3 * NR];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) first[k] = g0 + 2 * min(lane + 64 * k, max(n_ld - 1, 0));
-            const bool ok = n_ld > 0 && sweep_granules16<3>(gran, first, tag, val, p.err, lane);
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) first[3 * r + k] = r * in_stride + g0 + 2 * min(lane + 64 * k, max(n_ld - 1, 0));
+            const bool ok = n_ld > 0 && sweep_granules16<3 * NR>(gran, first, tag, val, p.err, lane);
             if (ok) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    if (lane + 64 * k < n_ld) *(uint2*)(&s_in[slot][t_begin[j] * KT + (lane + 64 * k) * 4]) = make_uint2(val[k].x, val[k].z);
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (lane + 64 * k < n_ld)
+                            *(uint2*)(chain_in_row<NR, WIDE, false>(s_in, slot, r) + t_begin[j] * KT + (lane + 64 * k) * 4) = make_uint2(val[3 * r + k].x, val[3 * r + k].z);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave's LDS writes before its reads
@@ -251,7 +283,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             const int t_last = max(t_end[j] - 1, t_begin[j]);
 #pragma unroll
             for (int i = 0; i < TB; ++i) {
-                const h16* arow = &s_in[slot][0] + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
+                const h16* arow = chain_in_row<NR, WIDE, false>(s_in, slot, row_a) + (KT / 4) * g + (size_t)min(t_begin[j] + i, t_last) * KT;
 #pragma unroll
                 for (int m = 0; m < NM; ++m) a[j][i][m] = *(const half8v*)(arow + m * 8);
             }
@@ -315,32 +347,35 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 #pragma unroll
             for (int r = 0; r < 4; ++r) sum[r] += tw[r];
         }
-        const float y = sum[0];                               // row 0 (lanes 0-15); the other lanes hold rows that do not exist
         const float bias = has_bias ? (float)bias_raw : 0.f;
-        if (st.mode == 0) {
-            if (g == 0) {
-                p.out32[col] = y;                             // raw sums for the attention kernel of the next launch
-                unsigned long long* gq = s == p.cross_at ? p.gran_q : p.gran_s;      // ... or of this launch's attention stages: cross (q) | self (q, k, v of the next layer)
-                if (gq)
-                    __hip_atomic_store((chain_gu64*)(gq + col), ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, y),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            const float y16 = r16(y + bias);                  // the Linear's fp16 output
-            h16 out;
-            if (st.mode == 1) {
-                out = (h16)(p.gelu_kind == 2 ? gelu_tanh(y16) : gelu_erf(y16));
-            } else {                                          // mode 2: the residual stream, this slot's 16 channels
-                const h16 xo = own_valid ? s_own[slot][rl] : p.x[col];
-                out = (h16)r16((float)xo + y16);
-                if (g == 0) { s_own[slot][rl] = out; p.x[col] = out; }
-            }
-            // two channels per granule: the even lane stores {epoch, own | neighbour << 16}
-            const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, out);
-            const unsigned nb_bits = __shfl_xor(bits, 1);
-            if (g == 0 && (rl & 1) == 0) {
-                unsigned long long* dst = (st.mode == 1 ? p.gran_h : p.gran_x) + (col >> 1);
-                __hip_atomic_store((chain_gu64*)dst, ((unsigned long long)epoch << 32) | (bits | (nb_bits << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float y = sum[r];                           // row r (lanes 0-15; element r of the accumulator); the other lanes hold rows that do not exist
+            if (st.mode == 0) {
+                if (g == 0) {
+                    p.out32[r * n_out + col] = y;             // raw sums for the attention kernel of the next launch
+                    unsigned long long* gq = s == p.cross_at ? p.gran_q : p.gran_s;      // ... or of this launch's attention stages: cross (q) | self (q, k, v of the next layer)
+                    if (gq)
+                        __hip_atomic_store((chain_gu64*)(gq + r * n_out + col), ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, y),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                const float y16 = r16(y + bias);              // the Linear's fp16 output
+                h16 out;
+                if (st.mode == 1) {
+                    out = (h16)(p.gelu_kind == 2 ? gelu_tanh(y16) : gelu_erf(y16));
+                } else {                                      // mode 2: the residual stream, this slot's 16 channels
+                    const h16 xo = own_valid ? s_own[slot * NR + r][rl] : p.x[r * n_out + col];
+                    out = (h16)r16((float)xo + y16);
+                    if (g == 0) { s_own[slot * NR + r][rl] = out; p.x[r * n_out + col] = out; }
+                }
+                // two channels per granule: the even lane stores {epoch, own | neighbour << 16}
+                const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, out);
+                const unsigned nb_bits = __shfl_xor(bits, 1);
+                if (g == 0 && (rl & 1) == 0) {
+                    unsigned long long* dst = (st.mode == 1 ? p.gran_h : p.gran_x) + r * (n_out >> 1) + (col >> 1);
+                    __hip_atomic_store((chain_gu64*)dst, ((unsigned long long)epoch << 32) | (bits | (nb_bits << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -365,14 +400,15 @@ constexpr unsigned CHAIN_EPOCH_LIVE = 0x80000000u;
 __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, const void* cross_kv, unsigned char* kv_lds, int per_split) {
     // waves 4-7: this workgroup's piece of K, then of V, as 1 KiB pieces (8 rows of 128 B) into LDS, linear
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_items = p.cross_heads * p.cross_nsplit, item = (int)blockIdx.x - ((int)gridDim.x - n_items);     // the LAST workgroups (see the kernel)
+    const int per_row = p.cross_heads * p.cross_nsplit, n_items = p.rows * per_row;
+    const int item = (int)blockIdx.x - ((int)gridDim.x - n_items);       // the LAST workgroups (see the kernel): item = (row, piece, head)
     if (wid < 4 || item < 0) return;
-    const int h = item % p.cross_heads, sp = item / p.cross_heads;
+    const int urow = item / per_row, h = (item % per_row) % p.cross_heads, sp = (item % per_row) / p.cross_heads;
     const int k_begin = sp * per_split, nkeys = max(0, min(p.cross_Tk, k_begin + per_split) - k_begin);
     if (nkeys == 0) return;
     const int n_pieces = (nkeys + 7) >> 3;
     for (int m = 0; m < 2; ++m) {
-        const unsigned char* src = (const unsigned char*)cross_kv + ((size_t)(m * p.cross_heads + h) * p.cross_Tk + k_begin) * 128;
+        const unsigned char* src = (const unsigned char*)cross_kv + (size_t)urow * p.cross_row_bytes + ((size_t)(m * p.cross_heads + h) * p.cross_Tk + k_begin) * 128;
         for (int pc = wid - 4; pc < n_pieces; pc += 4) {
             const int row = min(pc * 8 + (lane >> 3), nkeys - 1);        // rows past the piece re-read its last row (never used)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * 128 + (lane & 7) * 16),
@@ -387,10 +423,14 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     constexpr int STRIDE = 4 * RPI * UNR;
     constexpr int KB = 3, KB2 = 2;                 // iterations whose rows are requested together (P.V | scores, a wave's share)
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_items = p.cross_heads * p.cross_nsplit, item = (int)blockIdx.x - ((int)gridDim.x - n_items);
+    const int per_row = p.cross_heads * p.cross_nsplit, n_items = p.rows * per_row;
+    const int item = (int)blockIdx.x - ((int)gridDim.x - n_items);
     const bool has_item = item >= 0;
-    const int h = has_item ? item % p.cross_heads : 0, sp = has_item ? item / p.cross_heads : 0;
+    const int urow = has_item ? item / per_row : 0;
+    const int h = has_item ? (item % per_row) % p.cross_heads : 0, sp = has_item ? (item % per_row) / p.cross_heads : 0;
     const int k_begin = sp * per_split, nkeys = has_item ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
+    const unsigned long long* gran_q = p.gran_q + (size_t)urow * p.cross_heads * 64;              // this row's q sums
+    unsigned long long* gran_p = p.gran_p + (size_t)urow * p.cross_heads * 66 * 4;               // ... and its pieces' partial results
     const int sub = lane % LPR, rowi = lane / LPR;
     const int first = (wid & 3) * (RPI * UNR);
     const bool worker = wid < 4 && has_item && nkeys > 0;
@@ -405,7 +445,7 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     if (wid == 0 && has_item) {                                               // the head's 64 q sums, as the last Linear published them
         int fst[1] = {h * 64 + 2 * min(lane, 31)};
         u32x4 val[1];
-        if (sweep_granules16<1>(p.gran_q, fst, epoch_q, val, p.err, lane) && lane < 32) {
+        if (sweep_granules16<1>(gran_q, fst, epoch_q, val, p.err, lane) && lane < 32) {
             unsigned q0 = val[0].x, q1 = val[0].z;
             asm volatile("" : "+v"(q0), "+v"(q1));            // (kept apart: the pair was stored as (x, x) when the compiler formed it itself)
             s_q[2 * lane] = __builtin_bit_cast(float, q0);
@@ -416,7 +456,7 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     // the piece's partial result (max, sum, o[64]) as tagged granules, [head][66][4 pieces]: a lane of the merge finds the four
     // pieces of a value side by side
     auto put = [&](int r, float v) {
-        __hip_atomic_store((chain_gu64*)(p.gran_p + ((size_t)h * 66 + r) * 4 + sp), ((unsigned long long)epoch_q << 32) | __builtin_bit_cast(unsigned, v),
+        __hip_atomic_store((chain_gu64*)(gran_p + ((size_t)h * 66 + r) * 4 + sp), ((unsigned long long)epoch_q << 32) | __builtin_bit_cast(unsigned, v),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if (has_item && nkeys == 0) {                                              // an empty piece: the neutral element (attn_cross_kernel)
@@ -547,9 +587,12 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
 // num = sum_q o_q f_q in piece order, (h16)(num / den) -- with every lane holding all four (m, l) pairs itself instead of taking
 // them from lanes 0-3 (the same values: fmaxf and the products do not depend on who computes them).  All eight waves share the
 // heads (three per wave at 20 heads), a wave's 18 loads are in flight together; the merged row goes to s_in[0].  Ends with a barrier.
-__device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, unsigned tag, h16* s_row) {
+__device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, unsigned tag, h16 (*s_in)[CHAIN_MAX_IN + 8]) {
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int MH = 3;
+  for (int row = 0; row < p.rows; ++row) {                    // (a row's heads as at one row; the rows one after the other)
+    const unsigned long long* gran_p = p.gran_p + (size_t)row * p.merge_heads * 66 * 4;
+    h16* s_row = &s_in[row][0];
     for (int h0 = wid; h0 < p.merge_heads; h0 += 8 * MH) {
         int first[6 * MH];
         u32x4 val[6 * MH];
@@ -560,7 +603,7 @@ __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, uns
             first[6 * u + 2] = (h * 66 + 1) * 4; first[6 * u + 3] = (h * 66 + 1) * 4 + 2;
             first[6 * u + 4] = (h * 66 + 2 + lane) * 4; first[6 * u + 5] = (h * 66 + 2 + lane) * 4 + 2;
         }
-        if (!sweep_granules16<6 * MH>(p.gran_p, first, tag, val, p.err, lane)) break;
+        if (!sweep_granules16<6 * MH>(gran_p, first, tag, val, p.err, lane)) break;
 #pragma unroll
         for (int u = 0; u < MH; ++u) {
             const int h = h0 + 8 * u;
@@ -584,6 +627,7 @@ __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, uns
             s_row[h * 64 + lane] = (h16)(num / den);
         }
     }
+  }
     __syncthreads();
 }
 
@@ -615,8 +659,10 @@ __device__ __forceinline__ int chain_self_prefetch(const GemvChainParams& p, con
 // P.V by wave-wide 16-byte loads of whole V rows, partial sums added in (wave, row, block) order) -- bit for bit.  The head's 64
 // outputs are published as granules (p.gran_c, tagged with the launch's epoch) for the out projection, this launch's next stage.
 template <bool I8>
-__device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const ChainLayerArgs& la, int T, unsigned epoch0, unsigned tag_s, int h, float* s_p, h16 (*s_new)[64],
+__device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const ChainLayerArgs& la_, int T, unsigned epoch0, unsigned tag_s, int h, int urow, float* s_p, h16 (*s_new)[64],
                                                  float (*s_r2)[4], float* s_o_flat, const unsigned char* lds_rows, int lds_v_off) {
+    ChainLayerArgs la = la_;                                  // this row's share of the cache ([row][2][H][cap][64])
+    la.self_cache = (unsigned char*)la_.self_cache + (size_t)urow * p.self_row_bytes;
     constexpr float SCALE = 0.35355339059327373f;     // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
     constexpr int ES = I8 ? 1 : 2;
     constexpr int ROW_B = 64 * ES;
@@ -659,7 +705,8 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
         const int bstep = la.self_bias ? C : 0;
         const h16 bq_raw = bsrc[0], bk_raw = bsrc[bstep], bv_raw = bsrc[2 * bstep];
         if (p.gran_s) {                               // the sums the qkv stage of THIS launch has just published (the whole step in one launch)
-            int first[3] = {h * 64 + 2 * min(lane, 31), C + h * 64 + 2 * min(lane, 31), 2 * C + h * 64 + 2 * min(lane, 31)};
+            const int r0 = urow * 3 * C;              // (rows of 3 C sums)
+            int first[3] = {r0 + h * 64 + 2 * min(lane, 31), r0 + C + h * 64 + 2 * min(lane, 31), r0 + 2 * C + h * 64 + 2 * min(lane, 31)};
             u32x4 val[3];
             float* s_f = s_p;                         // (s_p is not in use yet: 3 x 64 floats)
             if (sweep_granules16<3>(p.gran_s, first, tag_s, val, p.err, lane) && lane < 32) {
@@ -674,8 +721,8 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS writes before its reads
             q += s_f[lane]; k += s_f[64 + lane]; v += s_f[128 + lane];
         } else {
-            const float* row = p.self_part + h * 64 + lane;
-            q += row[0]; k += row[C]; v += row[2 * C];
+            const float* part = p.self_part + (size_t)urow * 3 * C + h * 64 + lane;
+            q += part[0]; k += part[C]; v += part[2 * C];
         }
         q = r16(q + (la.self_bias ? (float)bq_raw : 0.f));
         k = r16(k + (la.self_bias ? (float)bk_raw : 0.f));
@@ -785,11 +832,11 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
             for (int r = 0; r < VROWS; ++r) acc += s_o_flat[(w * 64 + r * NCH + ch) * (DIMS + 1) + d];
         for (int j = T; j < nk; ++j) acc = fmaf(s_p[j], (float)s_vnew[lane], acc);
         const h16 out = (h16)f32_as_is(acc);
-        if (p.self_out) p.self_out[h * 64 + lane] = out;      // (plain copy: tests)
+        if (p.self_out) p.self_out[urow * C + h * 64 + lane] = out;      // (plain copy: tests)
         const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, out);
         const unsigned nb_bits = __shfl_xor(bits, 1);
         if ((lane & 1) == 0)
-            __hip_atomic_store((chain_gu64*)(p.gran_c + ((h * 64 + lane) >> 1)), ((unsigned long long)epoch0 << 32) | (bits | (nb_bits << 16)),
+            __hip_atomic_store((chain_gu64*)(p.gran_c + ((urow * C + h * 64 + lane) >> 1)), ((unsigned long long)epoch0 << 32) | (bits | (nb_bits << 16)),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // The cache append, position T: LAST.  A workgroup barrier waits for the wave's stores to be acknowledged by memory (2 us here),
         // and nothing in this launch reads the new row from memory -- the next token step does.
@@ -806,11 +853,11 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     __syncthreads();
 }
 
-template <int WB, bool I8KV>
+template <int WB, bool I8KV, int NR>
 __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     __shared__ __attribute__((aligned(16))) float s_red[16][64][4];
     __shared__ __attribute__((aligned(16))) h16 s_in[2][CHAIN_MAX_IN + 8];
-    __shared__ __attribute__((aligned(16))) h16 s_own[2][16];
+    __shared__ __attribute__((aligned(16))) h16 s_own[2 * NR][16];       // [slot][row]: the slot's 16 channels of the residual rows
     constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);
     constexpr int TB = WB == 16 ? 10 : 5;
     // epochs never repeat: the generation word counts the decoder calls on this workspace (the embedding kernel that opens a call
@@ -850,11 +897,14 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     // both slots of the widest), the last ones idle through most stages -- and the four upper waves of a workgroup that carries
     // K / V rows in flight must not meet a stage's "everything of mine has landed" wait before those rows are due.
     chain_cross_prefetch(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
-    const int self_base = max((int)gridDim.x - p.cross_heads * p.cross_nsplit - p.self_heads, 0);
-    const int self_h = (int)blockIdx.x - self_base;                      // this workgroup's self-attention head, if 0 <= self_h < self_heads
-    const bool self_wg = self_h >= 0 && self_h < p.self_heads && self_base >= 0 && (int)blockIdx.x < (int)gridDim.x - p.cross_heads * p.cross_nsplit;
+    const int n_cross_wgs = NR * p.cross_heads * p.cross_nsplit, n_self_wgs = NR * p.self_heads;      // one (row, head, piece) | (row, head) each
+    const int self_base = max((int)gridDim.x - n_cross_wgs - n_self_wgs, 0);
+    const int self_idx = (int)blockIdx.x - self_base;                    // this workgroup's self-attention (row, head), if 0 <= self_idx < rows x heads
+    const bool self_wg = self_idx >= 0 && self_idx < n_self_wgs && (int)blockIdx.x < (int)gridDim.x - n_cross_wgs;
+    const int self_h = self_wg ? self_idx % p.self_heads : 0, self_r = self_wg ? self_idx / p.self_heads : 0;
+    const size_t self_row_off = (size_t)self_r * p.self_row_bytes;       // this row's share of a layer's cache
     int self_v_off = 0;                                                  // > 0: the head's cached rows of the NEXT self-attention stage are (on their way) in LDS
-    if (self_wg) self_v_off = chain_self_prefetch<I8KV>(p, whole ? s_lio[0].cache : p.self_cache, T_now, self_h, kv_lds, 2 * per_split * 128);
+    if (self_wg) self_v_off = chain_self_prefetch<I8KV>(p, (const unsigned char*)(whole ? s_lio[0].cache : p.self_cache) + self_row_off, T_now, self_h, kv_lds, 2 * per_split * 128);
     bool own_valid = false, x_in_granules = false;
     for (int l = whole ? -1 : 0; l < (whole ? p.n_layers : 1); ++l) {
         const unsigned epoch0 = gen | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);
@@ -870,9 +920,9 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
             float* s_o_flat = (float*)&s_in[0][0];
             const unsigned tag_s = (gen | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
-            chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, self_h, s_p, s_new, s_r2, s_o_flat, kv_lds, self_v_off);
+            chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, self_h, self_r, s_p, s_new, s_r2, s_o_flat, kv_lds, self_v_off);
             // the NEXT layer's cached rows set out now (the stage's last barrier is behind every read of this layer's)
-            self_v_off = (whole && l + 1 < p.n_layers) ? chain_self_prefetch<I8KV>(p, s_lio[l + 1].cache, T_now, self_h, kv_lds, 2 * per_split * 128) : 0;
+            self_v_off = (whole && l + 1 < p.n_layers) ? chain_self_prefetch<I8KV>(p, (const unsigned char*)s_lio[l + 1].cache + self_row_off, T_now, self_h, kv_lds, 2 * per_split * 128) : 0;
         }
         const int s_first = l < 0 ? 5 : 0;
         const int s_end = !whole ? p.n_stages : (l < 0 ? 6 : (l + 1 < p.n_layers ? 6 : 5));
@@ -891,13 +941,13 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             const unsigned long long* gran = p.gran_h;
             unsigned tag = epoch - 1;
             if (s == p.merge_at) {                                // (only the workgroups that own a group of this stage need the row)
-                if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged(p, epoch0 + (unsigned)p.cross_at + 1, &s_in[0][0]);
+                if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged(p, epoch0 + (unsigned)p.cross_at + 1, s_in);
                 in_kind = CHAIN_IN_LDS;
             }
             else if (s == 0) { gran = p.gran_c; tag = epoch0; }
-            if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
-            else if (st.ln_g) chain_stage<WB, false, true>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
-            else chain_stage<WB, false, false>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+            if (wide) chain_stage<WB, true, false, NR>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+            else if (st.ln_g) chain_stage<WB, false, true, NR>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
+            else chain_stage<WB, false, false, NR>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
             if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
             if (l >= 0 && s == p.cross_at) {
                 chain_cross_stage(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
@@ -916,12 +966,18 @@ static int chain_set_lds_attribute() {
     const unsigned long long bit = 1ull << (dev & 63);
     if (attr_set.load(std::memory_order_acquire) & bit) return 0;
     auto each_kernel = [&](auto&& f) -> int {
-        if (int rc = f(gemv_chain_kernel<4, false>)) return rc;
-        if (int rc = f(gemv_chain_kernel<4, true>)) return rc;
-        if (int rc = f(gemv_chain_kernel<8, false>)) return rc;
-        if (int rc = f(gemv_chain_kernel<8, true>)) return rc;
-        if (int rc = f(gemv_chain_kernel<16, false>)) return rc;
-        return f(gemv_chain_kernel<16, true>);
+        if (int rc = f(gemv_chain_kernel<4, false, 1>)) return rc;
+        if (int rc = f(gemv_chain_kernel<4, true, 1>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, false, 1>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, true, 1>)) return rc;
+        if (int rc = f(gemv_chain_kernel<16, false, 1>)) return rc;
+        if (int rc = f(gemv_chain_kernel<16, true, 1>)) return rc;
+        if (int rc = f(gemv_chain_kernel<4, false, 2>)) return rc;
+        if (int rc = f(gemv_chain_kernel<4, true, 2>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, false, 2>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, true, 2>)) return rc;
+        if (int rc = f(gemv_chain_kernel<16, false, 2>)) return rc;
+        return f(gemv_chain_kernel<16, true, 2>);
     };
     if (each_kernel([&](auto* k) -> int { WM_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_DYN_LDS)); return 0; })) return 2;
     attr_set.fetch_or(bit, std::memory_order_release);
@@ -931,21 +987,47 @@ static int chain_set_lds_attribute() {
 // Can the CURRENT device hold the launch's n_wg workgroups TOGETHER?  They wait for each other, so one that is never scheduled makes the
 // others spin until their bounded waits give up: the runtime's occupancy figure for this instantiation at its LDS footprint (static +
 // the K / V pieces) times the CUs must cover the grid.  *ok = false is an answer, not an error.
-int gemv_chain_resident(int w8, int self_i8, int cross_Tk, int cross_nsplit, int n_wg, int n_cu, bool* ok) {
+// every instantiation by its run-time selectors
+template <typename F>
+static auto chain_pick(int w8, bool i8, int rows, F&& f) {
+    if (rows == 2) {
+        if (w8 == 4) return i8 ? f(gemv_chain_kernel<4, true, 2>) : f(gemv_chain_kernel<4, false, 2>);
+        if (w8) return i8 ? f(gemv_chain_kernel<8, true, 2>) : f(gemv_chain_kernel<8, false, 2>);
+        return i8 ? f(gemv_chain_kernel<16, true, 2>) : f(gemv_chain_kernel<16, false, 2>);
+    }
+    if (w8 == 4) return i8 ? f(gemv_chain_kernel<4, true, 1>) : f(gemv_chain_kernel<4, false, 1>);
+    if (w8) return i8 ? f(gemv_chain_kernel<8, true, 1>) : f(gemv_chain_kernel<8, false, 1>);
+    return i8 ? f(gemv_chain_kernel<16, true, 1>) : f(gemv_chain_kernel<16, false, 1>);
+}
+
+int gemv_chain_resident(int w8, int self_i8, int rows, int cross_Tk, int cross_nsplit, int n_wg, int n_cu, bool* ok, char* why, size_t why_cap) {
     *ok = false;
     WM_REQUIRE(cross_nsplit >= 1 && cross_Tk >= 1 && n_wg >= 1 && n_cu >= 1, "gemv_chain_resident: bad arguments");
+    WM_REQUIRE(rows == 1 || rows == 2, "gemv_chain_resident: rows=%d", rows);
     const int per_split = (((cross_Tk + cross_nsplit - 1) / cross_nsplit) + 7) & ~7;
     const size_t dyn = (size_t)2 * per_split * 128 + 1024;
-    if (dyn > CHAIN_DYN_LDS) return 0;
+    if (dyn > CHAIN_DYN_LDS) { if (why) snprintf(why, why_cap, "cross-attention pieces of %d keys do not fit LDS", per_split); return 0; }
     if (chain_set_lds_attribute()) return 2;
-    int per_cu = 0;
-    auto ask = [&](auto* k) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, 512, dyn); };
-    hipError_t rc;
-    if (w8 == 4) rc = self_i8 ? ask(gemv_chain_kernel<4, true>) : ask(gemv_chain_kernel<4, false>);
-    else if (w8) rc = self_i8 ? ask(gemv_chain_kernel<8, true>) : ask(gemv_chain_kernel<8, false>);
-    else rc = self_i8 ? ask(gemv_chain_kernel<16, true>) : ask(gemv_chain_kernel<16, false>);
+    // What one workgroup takes of a CU, from the function's own attributes, against what a CU has: 512 threads = 8 waves = 2 per SIMD
+    // (512 registers per SIMD lane), static + dynamic LDS of the CU's.  The runtime's occupancy call is asked too and reported, but not
+    // trusted alone: with this launch's footprint (158 of 160 KB) ROCm 7.2's answers 0 workgroups per CU for a kernel that ROCm 7.0's
+    // -- the runtime torch's wheel bundles, whichever is loaded first serves the process -- and the hardware hold (profiles/r5g_*).
+    hipFuncAttributes fa{};
+    int per_cu_api = -1, dev = 0, lds_cu = 0, lds_blk = 0;
+    const hipError_t rc = chain_pick(w8, self_i8 != 0, rows, [&](auto* k) {
+        hipError_t e = hipFuncGetAttributes(&fa, (const void*)k);
+        if (e == hipSuccess && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_api, (const void*)k, 512, dyn) != hipSuccess) { (void)hipGetLastError(); per_cu_api = -1; }
+        return e;
+    });
     WM_CHECK_HIP(rc);
-    *ok = per_cu >= 1 && (long)per_cu * n_cu >= n_wg;
+    WM_CHECK_HIP(hipGetDevice(&dev));
+    WM_CHECK_HIP(hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev));
+    WM_CHECK_HIP(hipDeviceGetAttribute(&lds_blk, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    const size_t lds_have = (size_t)(lds_cu > lds_blk ? lds_cu : lds_blk);
+    const bool lds_ok = fa.sharedSizeBytes + dyn <= lds_have, regs_ok = fa.numRegs <= 256, grid_ok = n_wg <= n_cu;
+    *ok = lds_ok && regs_ok && grid_ok;
+    if (why) snprintf(why, why_cap, "%zu + %zu B of LDS per workgroup (a CU has %zu), %d registers, %d workgroups on %d CUs; the runtime's occupancy call says %d per CU%s",
+                      (size_t)fa.sharedSizeBytes, dyn, lds_have, fa.numRegs, n_wg, n_cu, per_cu_api, *ok ? "" : ": the launch's workgroups cannot be resident together");
     return 0;
 }
 
@@ -1003,20 +1085,18 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs_all, int n_
     WM_REQUIRE(p.merge_nsplit == 4 && p.cross_nsplit == 4 && p.merge_heads == p.cross_heads, "gemv_chain: the attention pieces travel as [head][66][4]: 4 pieces");
     WM_REQUIRE(p.self_heads >= 1 && p.self_heads * 64 == hs[0].K && !hs[0].ln_g && (p.self_t_dev || (p.self_T >= 0 && p.self_T < p.self_cap)) && p.self_cap <= 512,
                "gemv_chain: self-attention stage: bad arguments");
-    WM_REQUIRE(n_wg >= p.self_heads + p.cross_heads * p.cross_nsplit, "gemv_chain: %d workgroups for the attention stages", n_wg);
+    WM_REQUIRE(p.rows == 1 || p.rows == 2, "gemv_chain: rows=%d (one or two activation rows)", p.rows);
+    WM_REQUIRE(p.rows == 1 || (p.cross_row_bytes > 0 && p.self_row_bytes > 0), "gemv_chain: two rows need the strides between their cross K/V and caches");
+    WM_REQUIRE(n_wg >= p.rows * (p.self_heads + p.cross_heads * p.cross_nsplit), "gemv_chain: %d workgroups for the attention stages of %d rows", n_wg, p.rows);
     WM_REQUIRE(hs[p.cross_at].mode == 0 && p.cross_Tk >= 1 && p.cross_heads * 64 == hs[p.cross_at].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
     const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
     WM_REQUIRE(per_split <= CHAIN_CROSS_KEYS, "gemv_chain: %d keys per piece", per_split);
     const size_t dyn = (size_t)2 * per_split * 128 + 1024;
     WM_REQUIRE(dyn <= CHAIN_DYN_LDS, "gemv_chain: cross-attention pieces of %d keys do not fit LDS", per_split);
-    widest = widest > p.cross_heads * p.cross_nsplit ? widest : p.cross_heads * p.cross_nsplit;
+    widest = widest > p.rows * p.cross_heads * p.cross_nsplit ? widest : p.rows * p.cross_heads * p.cross_nsplit;
     WM_REQUIRE(n_wg >= widest, "gemv_chain: %d workgroups for stages that need %d", n_wg, widest);
     if (chain_set_lds_attribute()) return 2;
-    const bool i8 = p.self_i8 != 0;
-    auto go = [&](auto* k) { hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), dyn, stream, p); };
-    if (p.w8 == 4) { if (i8) go(gemv_chain_kernel<4, true>); else go(gemv_chain_kernel<4, false>); }
-    else if (p.w8) { if (i8) go(gemv_chain_kernel<8, true>); else go(gemv_chain_kernel<8, false>); }
-    else { if (i8) go(gemv_chain_kernel<16, true>); else go(gemv_chain_kernel<16, false>); }
+    chain_pick(p.w8, p.self_i8 != 0, p.rows, [&](auto* k) { hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), dyn, stream, p); return 0; });
     WM_LAUNCH_CHECK(stream, "gemv_chain");
     return 0;
 }

@@ -75,6 +75,7 @@ int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
 // A chain of gemv_small Linears at ONE activation row in one launch (batch 1): stage inputs / outputs between the stages travel
 // as {epoch, value} granules, the first stage reads plain memory, mode-0 results and the residual row go back to plain memory.
 constexpr int CHAIN_MAX_STAGES = 6;
+constexpr int CHAIN_MAX_ROWS = 2;            // activation rows one launch serves (gemv_chain.hip)
 constexpr int DECODE_CHAIN_DEFAULT = 2;      // one-row groups: 0 a launch per kernel, 1 one launch per decoder layer, 2 one per token step
 struct ChainStage {                                           // (an engine keeps its layers' stages in DEVICE memory: a chain's
     const void* Wt; const h16* scale; const h16* bias;         // arguments stay small -- by value they were 330 bytes, and the runtime
@@ -108,11 +109,16 @@ struct GemvChainParams {
     const float* self_part; const h16* self_bias; void* self_cache; int self_cap, self_T, self_heads, self_i8; const int32_t* self_t_dev;
     float self_kv_scale; h16* self_out; unsigned long long* gran_c;     // C / 2 entries; self_out: optional plain copy [C] (tests)
     int n_layers; const ChainLayerStatic* lstat; const ChainLayerIo* lio; unsigned long long* gran_s;
+    // ROWS.  rows = 1 | 2 activation rows (utterances) in one launch: x [rows][C], every granule edge [rows][...], out32 [rows][N],
+    // self_part [rows][3C]; the rows' cross K/V and caches lie cross_row_bytes / self_row_bytes apart (the [B, 2, H, T, 64] buffers of
+    // a batch).  A row's arithmetic does not depend on rows (the MFMA's A rows carry the activation rows alternately).  Two rows put
+    // 2 x (heads + heads x pieces) attention workgroups in the launch; the Linear stages cost what they cost at one row.
+    int rows; long cross_row_bytes, self_row_bytes;
     unsigned* err;                                            // set non-zero when a bounded wait gives up
     const unsigned* generation; int launch_id;                // epochs: (*generation << 10) | (layer or launch_id << 3), + stage + 1 (generation: one per decoder call)
 };
 bool gemv_chain_supports(int C, int w8, int n_cu);
-int gemv_chain_resident(int w8, int self_i8, int cross_Tk, int cross_nsplit, int n_wg, int n_cu, bool* ok);      // can the current device hold the launch's workgroups together?
+int gemv_chain_resident(int w8, int self_i8, int rows, int cross_Tk, int cross_nsplit, int n_wg, int n_cu, bool* ok, char* why, size_t why_cap);      // can the current device hold the launch's workgroups together?
 int launch_occupy(int n_wg, size_t lds_bytes, long long usec, hipStream_t stream);      // diagnostic: workgroups that hold LDS and sleep
 int launch_gemv_chain(const GemvChainParams& p, const ChainStage* host_stages, int n_wg, hipStream_t stream);
 int launch_chain_io_table(ChainLayerIo* dst, const ChainLayerIo* host, int n, hipStream_t stream);      // fills the caller's table (small launches, arguments by value)     // host_stages: the same descriptors, for the argument checks

@@ -98,7 +98,7 @@ class WmFlacStreamInfo(C.Structure):
 class WmChainStatus(C.Structure):
     """wm_chain_status (include/whisper_mi355.h)."""
     _fields_ = [("mode", C.c_int32), ("declined", C.c_int32), ("error_pending", C.c_int32), ("pad_", C.c_int32),
-                ("launches", C.c_int64), ("declined_calls", C.c_int64), ("reason", C.c_char * 160)]
+                ("launches", C.c_int64), ("declined_calls", C.c_int64), ("reason", C.c_char * 200), ("footprint", C.c_char * 200)]
 
 
 def chain_status() -> dict:
@@ -106,7 +106,7 @@ def chain_status() -> dict:
     st = WmChainStatus()
     check(load_library().wm_decode_chain_status(C.byref(st)), "wm_decode_chain_status")
     return {"mode": st.mode, "declined": bool(st.declined), "error_pending": bool(st.error_pending), "launches": int(st.launches),
-            "declined_calls": int(st.declined_calls), "reason": st.reason.decode()}
+            "declined_calls": int(st.declined_calls), "reason": st.reason.decode(), "footprint": st.footprint.decode()}
 
 
 class WmDims(C.Structure):

@@ -298,8 +298,9 @@ int wm_set_gemm_small_tiles(int tiles);
  * use mode 0 there); a call that does not qualify takes the launch-per-kernel path.
  * < 0 = default; returns the previous value.  Captured graphs keep the form they were captured with.
  * Robustness.  The launch's workgroups wait for each other, so they must be resident together.  The library therefore takes the
- * one-launch forms only when (a) the runtime's occupancy figure for the kernel at its LDS footprint times the device's CUs covers the
- * grid (asked once per device and kernel variant), (b) the stream of the call owns every CU (a stream created with a CU mask that
+ * one-launch forms only when (a) a workgroup's footprint -- static + dynamic LDS and registers, from the function's attributes -- fits a
+ * CU and the grid is no larger than the device's CUs (checked once per device and kernel variant; the runtime's occupancy call is
+ * reported beside it but not trusted alone: ROCm 7.2's answers 0 for a footprint that runs), (b) the stream of the call owns every CU (a stream created with a CU mask that
  * leaves it fewer -- wm_stream_create_cu_mask, hipExtStreamCreateWithCUMask -- takes the launch-per-kernel path) and (c) no earlier
  * launch on the device has given up.  Every wait inside the launch is bounded (about a second): a wave that gives up sets a word in
  * pinned host memory and the rest of the launch falls through.
@@ -317,7 +318,8 @@ typedef struct wm_chain_status {
     int32_t pad_;
     int64_t launches;           /* one-launch steps / layers issued (or captured) on this device */
     int64_t declined_calls;     /* decoder calls that qualified by shape but took the launch-per-kernel path for reasons (a)-(c) */
-    char reason[160];           /* why the device is declined ("" if it is not) */
+    char reason[200];           /* why the device is declined, or why the last residency check said no ("" otherwise) */
+    char footprint[200];        /* the last residency check in words: LDS and registers of a workgroup against a CU's, the runtime's own figure */
 } wm_chain_status;
 int wm_set_decode_chain(int on);
 int wm_decode_chain_error(int* out);

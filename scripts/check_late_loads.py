@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "eddie-wang-hackathon2023_amd", "csrc")
 # kernel-name pattern -> allowed sites, why
 ALLOWED = [
-    (r"gemv_chain_kernelILi(4|8|16)ELb[01]E", 12, "seven polls of the error word inside bounded waits (every 64th spin), the first residual read of a launch (p.x: twice, once per stage form), the self-attention's K block beyond 64 cached keys, the qkv sums read back from LDS through a flat pointer"),
+    (r"gemv_chain_kernelILi(4|8|16)ELb[01]ELi2E", 16, "the two-row kernels: the one-row kernel's sites + the first residual read of a launch for the second row (p.x, once per stage form; only the first mode-2 stage of a launch takes it, later ones read the workgroup's own copy in LDS)"),
+    (r"gemv_chain_kernelILi(4|8|16)ELb[01]ELi1E", 12, "seven polls of the error word inside bounded waits (every 64th spin), the first residual read of a launch (p.x: twice, once per stage form), the self-attention's K block beyond 64 cached keys, the qkv sums read back from LDS through a flat pointer"),
     (r"gemv_small_kernelILi(4|8|16)ELi1E", 1, "M <= 16 forms: the fp16 logits form's single fragment load"),
     (r"gemv_small_kernelILi(4|8|16)ELi2E", 16, "17-32-row forms (not used: the small path serves <= 16 rows)"),
     (r"gemm_rows_kernel", 0, ""),

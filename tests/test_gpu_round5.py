@@ -168,6 +168,84 @@ def test_full_depth_batch1_one_launch_step_matches_oracle_and_the_launch_per_ker
             assert torch.equal(a, b), (mode, use_graphs)
     assert len(set(r[2][0, 3:].tolist())) > 3                      # a real decode, not one token repeated
 
+    # ---- (d) TWO utterances (round 5: the one-launch step serves groups of two rows): the same three forms at full depth, and each
+    # utterance's tokens are the ones it gets alone (rows do not see each other) --------------------------------------------------
+    mel2 = torch.cat([mel, synthetic_mel(1, 3000, 80, 777).cuda()])
+    xa2 = enc.get_audio_features(mel2)
+    outs2 = []
+    for mode in (0, 2):
+        lib.wm_set_decode_chain(mode)
+        dec = WhisperDecoding(Path(out), options=DecodingOptions(sample_len=10))
+        dec.detect_language(xa2)
+        for use_graphs in (False, True):
+            dec.use_graphs = use_graphs
+            for st in dec._state.values():
+                st['graphs'].clear()
+            before = native.chain_status()["launches"]
+            t, lp, _ = dec.main_loop(xa2, ignore_eot=True)
+            assert (native.chain_status()["launches"] > before) == (mode > 0), (mode, use_graphs)
+            outs2.append((mode, use_graphs, t.cpu(), lp.cpu(), [c.clone() for c in dec._state[2]['kv']]))
+        del dec
+    for mode, use_graphs, t, lp, kv in outs2[1:]:
+        assert torch.equal(t, outs2[0][2]) and torch.equal(lp, outs2[0][3]), (mode, use_graphs)
+        for a, b in zip(kv, outs2[0][4]):
+            assert torch.equal(a, b), (mode, use_graphs)
+    assert torch.equal(outs2[0][2][0], r[2][0])                     # utterance 0 beside another one == utterance 0 alone
+    assert not torch.equal(outs2[0][2][0], outs2[0][2][1])
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"], st_
+
+
+# ------------------------------------------------------------------------------------------ two rows in one launch
+@pytest.mark.parametrize("model,weight_only,int8_kv", [("micro-fullvocab", False, False), ("micro-fullvocab", True, True),
+                                                        ("tiny", True, False), ("tiny", "int4", True), ("large-v2-6layer", True, True),
+                                                        ("large-v2-6layer", False, False)])
+def test_two_row_step_equals_the_launch_per_kernel_path(lib, tmp_path_factory, chain_rearmed, model, weight_only, int8_kv):
+    """Round 5: groups of TWO rows (two utterances decoded together) take the one-launch forms too -- 2 x (heads + heads x pieces)
+    attention workgroups, the Linear stages carry both rows in the MFMA's A operand.  Same arithmetic as a launch per kernel: token
+    ids, log-probabilities and the whole KV cache of a batch-2 decode are IDENTICAL in the three forms, eagerly and under graph
+    replay, no workgroup gave up a wait, and each utterance's tokens are the ones it gets when it is decoded alone."""
+    from test_gpu_model import build_engine
+    if model not in synthetic.DIMS:
+        pytest.skip(f"no synthetic model {model}")
+    tmp = tmp_path_factory.mktemp("chain2")
+    dims = Dims(**synthetic.DIMS[model])
+    kv_scales = [0.05 + 0.01 * i for i in range(dims.n_text_layer)] if int8_kv else None
+    eng = build_engine(tmp, model, 3, weight_only, int8_kv, kv_scales)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(2, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    outs = []
+    for on in (0, 1, 2):
+        lib.wm_set_decode_chain(on)
+        dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
+        dec.detect_language(xa)
+        for use_graphs in (False, True):
+            dec.use_graphs = use_graphs
+            for st in dec._state.values():
+                st['graphs'].clear()
+            before = native.chain_status()["launches"]
+            t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+            assert (native.chain_status()["launches"] > before) == (on > 0), (on, use_graphs)
+            outs.append((on, use_graphs, t.cpu(), lp.cpu(), [c.clone() for c in dec._state[2]['kv']]))
+        del dec
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"], st_
+    ref = outs[0]
+    for on, use_graphs, t, lp, kv in outs[1:]:
+        assert torch.equal(t, ref[2]), (on, use_graphs)
+        assert torch.equal(lp, ref[3]), (on, use_graphs)
+        for a, b in zip(kv, ref[4]):
+            assert torch.equal(a, b), (on, use_graphs)
+    assert len(set(ref[2][0, 3:].tolist())) > 3 and not torch.equal(ref[2][0], ref[2][1])
+    lib.wm_set_decode_chain(2)
+    for b in (0, 1):                                                           # alone: the one-row launch
+        solo = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
+        xb = xa[b:b + 1].contiguous()
+        solo.detect_language(xb)
+        t1, lp1, _ = solo.main_loop(xb, ignore_eot=True)
+        assert torch.equal(t1[0].cpu(), ref[2][b]) and torch.equal(lp1[0].cpu(), ref[3][b]), b
+        del solo
+
 
 # ------------------------------------------------------------------------------------------ hardening
 def test_one_launch_step_is_declined_on_a_cu_masked_stream(lib, tmpdir_module, chain_rearmed):
