@@ -483,6 +483,7 @@ def main():
             enc.prefetch(mel, args.encoder_cus)
         e0 = mark()
         tokens, sum_lp, _ = dec.main_loop(xa, ignore_eot=True)
+        enc.loop_ended()            # the prefetched pass gives back its CU budget once the GPU is past this point
         e1 = mark()
         loop_events.append((e0, e1, last["prefetched"]))
         last["xa"] = xa
@@ -607,7 +608,7 @@ def main():
         loop_ms = [a.elapsed_time(b) for a, b in loops]
         # the same five batches PIPELINED as the headline's steps are (summarize.py --overlap_encoder): the encoder of batch n + 1 on
         # --encoder-cus CUs beside the decode loop of batch n
-        rp_elapsed = None
+        rp_elapsed, released = None, []
         if args.encoder_cus > 0:
             if use_dist:
                 dist.barrier()
@@ -619,8 +620,10 @@ def main():
                 if i + 1 < len(batches):
                     enc.prefetch(mel, args.encoder_cus)
                 dec.main_loop(xa_p, row_limit=torch.as_tensor(limits, dtype=torch.int32))
+                enc.loop_ended()
                 if i + 1 < len(batches):
                     xa_p = enc.collect()
+                    released.append(enc.last_release_layer)
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
@@ -639,6 +642,7 @@ def main():
                   "tokens_match_the_limits": bool((got == batches[0]).all()),
                   "ms_per_batch": round(r_elapsed * 1e3 / n_jobs, 1), "decode_loop_ms": [round(x, 1) for x in loop_ms],
                   "ms_per_batch_pipelined": round(rp_elapsed * 1e3 / n_jobs, 1) if rp_elapsed else None,
+                  "pipelined_encoder_released_at_layer": released or None,
                   "useful_tokens_per_s_pipelined": round(float(all_limits.sum()) * world / rp_elapsed, 1) if rp_elapsed else None,
                   "audio_seconds": round(audio_s, 1), "rtf": round(best / audio_s, 6),
                   "test_clean_estimate_s": round(best * 2620.0 / (n_jobs * B * world), 2),

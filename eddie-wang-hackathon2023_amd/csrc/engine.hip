@@ -451,37 +451,48 @@ int wm_encoder_forward(const wm_engine* e, const void* mel, int B, void* out, vo
 
 int wm_encoder_forward_shared(const wm_engine* e, const void* mel, int B, void* out, void* workspace,
                               size_t workspace_bytes, int cu_budget, wm_stream_t stream_) {
+    return wm_encoder_forward_range(e, mel, B, out, workspace, workspace_bytes, cu_budget, 0, e ? e->dims.n_audio_layer : 0, stream_);
+}
+
+// Layers [layer_begin, layer_end) of the encoder pass: the convolutions belong to a range that starts at layer 0, the final LayerNorm
+// (which writes `out`) to one that ends at n_audio_layer; between the calls of one pass the residual stream lives in the workspace.
+int wm_encoder_forward_range(const wm_engine* e, const void* mel, int B, void* out, void* workspace,
+                             size_t workspace_bytes, int cu_budget, int layer_begin, int layer_end, wm_stream_t stream_) {
     WM_REQUIRE(e && e->kind == WM_ENGINE_ENCODER, "wm_encoder_forward: not an encoder engine");
     WM_REQUIRE(mel && out && workspace && B >= 1, "wm_encoder_forward: null argument or empty batch");
     WM_REQUIRE(cu_budget >= 0, "wm_encoder_forward_shared: cu_budget=%d", cu_budget);
     hipStream_t s = (hipStream_t)stream_;
     const wm_dims& d = e->dims;
+    WM_REQUIRE(layer_begin >= 0 && layer_begin <= layer_end && layer_end <= d.n_audio_layer, "wm_encoder_forward_range: layers [%d, %d) of %d",
+               layer_begin, layer_end, d.n_audio_layer);
     const int T = d.n_audio_ctx, Tin = 2 * T, C = d.n_audio_state, H = d.n_audio_head, M = B * T;
     WM_REQUIRE(C == H * 64, "head size must be 64 (n_state %d, heads %d)", C, H);
     EncWs w = carve_encoder(e, B, workspace);
     WM_REQUIRE(workspace_bytes >= w.total, "encoder workspace too small: %zu < %zu", workspace_bytes, w.total);
 
-    // mel -> token-major, zero padded; slack after the last row is read by the K=256 view (x 0 weights)
-    WM_CHECK_HIP(hipMemsetAsync(w.melT + (size_t)B * (Tin + 2) * d.n_mels, 0, 512 * sizeof(h16), s));
-    if (launch_mel_transpose_pad((const h16*)mel, B, d.n_mels, Tin, w.melT, s)) return 2;
-    // conv1 (k3 s1 p1) + GELU as a GEMM over a strided view: row t = padded rows t, t+1, t+2
-    {
-        GemmBigParams p{};
-        p.a_rows = Tin; p.a_bstride = (long)(Tin + 2) * d.n_mels;
-        p.c_rows = Tin; p.c_bstride = (long)(Tin + 2) * C;
-        WM_REQUIRE(e->conv1.K >= 3 * d.n_mels, "conv1 weight K=%d < 3*n_mels", e->conv1.K);
-        if (big(e->conv1, e, w.melT, d.n_mels, B * Tin, w.c1 + C, C, e->gelu(), nullptr, 0, s, &p, cu_budget)) return 2;
-        if (launch_zero_pad_rows(w.c1, B, Tin + 2, C, s)) return 2;
-    }
-    // conv2 (k3 s2 p1) + GELU + positional embedding: row t = padded rows 2t, 2t+1, 2t+2
-    {
-        GemmBigParams p{};
-        p.a_rows = T; p.a_bstride = (long)(Tin + 2) * C;
-        p.residual = e->enc_pos; p.ldr = C; p.res_mod = T;
-        if (big(e->conv2, e, w.c1, 2 * C, M, w.x, C, e->gelu(), nullptr, 0, s, &p, cu_budget)) return 2;
+    if (layer_begin == 0) {
+        // mel -> token-major, zero padded; slack after the last row is read by the K=256 view (x 0 weights)
+        WM_CHECK_HIP(hipMemsetAsync(w.melT + (size_t)B * (Tin + 2) * d.n_mels, 0, 512 * sizeof(h16), s));
+        if (launch_mel_transpose_pad((const h16*)mel, B, d.n_mels, Tin, w.melT, s)) return 2;
+        // conv1 (k3 s1 p1) + GELU as a GEMM over a strided view: row t = padded rows t, t+1, t+2
+        {
+            GemmBigParams p{};
+            p.a_rows = Tin; p.a_bstride = (long)(Tin + 2) * d.n_mels;
+            p.c_rows = Tin; p.c_bstride = (long)(Tin + 2) * C;
+            WM_REQUIRE(e->conv1.K >= 3 * d.n_mels, "conv1 weight K=%d < 3*n_mels", e->conv1.K);
+            if (big(e->conv1, e, w.melT, d.n_mels, B * Tin, w.c1 + C, C, e->gelu(), nullptr, 0, s, &p, cu_budget)) return 2;
+            if (launch_zero_pad_rows(w.c1, B, Tin + 2, C, s)) return 2;
+        }
+        // conv2 (k3 s2 p1) + GELU + positional embedding: row t = padded rows 2t, 2t+1, 2t+2
+        {
+            GemmBigParams p{};
+            p.a_rows = T; p.a_bstride = (long)(Tin + 2) * C;
+            p.residual = e->enc_pos; p.ldr = C; p.res_mod = T;
+            if (big(e->conv2, e, w.c1, 2 * C, M, w.x, C, e->gelu(), nullptr, 0, s, &p, cu_budget)) return 2;
+        }
     }
     const float qk_scale = 0.35355339059327373f;    // 64^-0.25
-    for (int i = 0; i < d.n_audio_layer; ++i) {
+    for (int i = layer_begin; i < layer_end; ++i) {
         const EncLayer& L = e->enc[i];
         if (launch_layernorm(w.x, C, M, C, L.ln1g, L.ln1b, w.xn, C, s)) return 2;
         {
@@ -496,7 +507,8 @@ int wm_encoder_forward_shared(const wm_engine* e, const void* mel, int B, void* 
         if (big(L.mlp1, e, w.xn, C, M, w.hid, 4 * C, e->gelu(), nullptr, 0, s, nullptr, cu_budget, w.wq)) return 2;
         if (big(L.mlp2, e, w.hid, 4 * C, M, w.x, C, 0, w.x, C, s, nullptr, cu_budget, w.wq)) return 2;
     }
-    if (launch_layernorm(w.x, C, M, C, e->lnpg, e->lnpb, (h16*)out, C, s)) return 2;
+    if (layer_end == d.n_audio_layer)
+        if (launch_layernorm(w.x, C, M, C, e->lnpg, e->lnpb, (h16*)out, C, s)) return 2;
     return 0;
 }
 

@@ -98,16 +98,26 @@ class WhisperEncoding:
     # cu_budget workgroups pinned to as many CUs the encoder leaves the rest of the chip to the decode kernels, which are
     # then never dispatched behind a 128 KB-LDS GEMM tile.  prefetch() enqueues from a helper thread on a stream of its
     # own (the ctypes calls release the GIL); collect() joins it and makes the current stream wait for the result.
+    #
+    # Round 5: the budget is given back when the loop ends.  A pass confined to 96 CUs takes three times the whole chip's time; beside
+    # a decode loop of 128 tokens x 576 utterances that is the point, behind a loop that ended after 30 tokens (LibriSpeech-like
+    # lengths) it made the pipelined schedule 34 % SLOWER than one stage after the other.  The helper thread therefore issues the
+    # pass LAYER BY LAYER (wm_encoder_forward_range), at most two layers ahead of the GPU, and looks before each layer whether
+    # the loop has ended -- `loop_ended()` records an event on the caller's stream behind the loop; the helper polls it -- from then
+    # on the layers still to come are issued for the whole chip.  No prediction of the loop's length is needed, a short loop costs
+    # at most the two layers already queued, and the result is bit-identical whatever the cut (same tiles, other workgroups).
     def prefetch(self, mel, cu_budget: int = DEFAULT_SHARED_CU_BUDGET):
         import threading
         assert getattr(self, "_prefetch", None) is None, "one prefetch at a time"
         if getattr(self, "_prefetch_stream", None) is None:
             self._prefetch_stream = torch.cuda.Stream(device=mel.device)
-        side, box = self._prefetch_stream, {}
+        side, box = self._prefetch_stream, {"loop_done": None, "released_at": None}
         side.wait_stream(torch.cuda.current_stream())          # mel may still be in flight on the caller's stream
         device = mel.device
 
         timed = bool(getattr(self, "time_prefetch", False))        # bench.py: events around the prefetched pass and around collect()'s wait
+        n_layer = self.session.dims['n_audio_layer']
+        release = bool(getattr(self, "release_budget_when_loop_ends", True)) and cu_budget > 0
 
         def work():
             try:
@@ -115,7 +125,23 @@ class WhisperEncoding:
                 with torch.cuda.stream(side):
                     if timed:
                         box["t0"] = torch.cuda.Event(enable_timing=True); box["t0"].record()
-                    box["xa"] = self.get_audio_features_async(mel, cu_budget=cu_budget)
+                    m16 = mel.type(torch.float16).contiguous()
+                    d = self.session.dims
+                    out = torch.empty((m16.shape[0], d['n_audio_ctx'], d['n_audio_state']), dtype=torch.float16, device=m16.device)
+                    if not release:
+                        self.session.encoder_forward(m16, out, side.cuda_stream, cu_budget)
+                    else:
+                        budget, done = cu_budget, []
+                        for i in range(n_layer):
+                            if len(done) >= 2:
+                                done[-2].synchronize()             # at most two layers queued ahead of the GPU: the look below is fresh
+                            ev = box["loop_done"]
+                            if budget > 0 and ev is not None and ev.query():
+                                budget, box["released_at"] = 0, i  # the loop has ended: the whole chip for what is left
+                            self.session.encoder_forward_range(m16, out, side.cuda_stream, budget, i, i + 1)
+                            e = torch.cuda.Event(); e.record()
+                            done.append(e)
+                    box["xa"] = stamp_generation(out)
                     if timed:
                         box["t1"] = torch.cuda.Event(enable_timing=True); box["t1"].record()
             except BaseException as exc:                       # re-raised by collect()
@@ -125,8 +151,19 @@ class WhisperEncoding:
         th.start()
         self._prefetch = (th, box)
 
+    def loop_ended(self):
+        """Tell a pass in flight (prefetch) that the decode loop it runs beside has been issued to its end: an event behind the loop on the
+        CURRENT stream (WhisperDecoding.main_loop joins its group streams into it before it returns); once the GPU has passed it, the
+        encoder layers still to come take the whole chip.  Harmless without a pass in flight."""
+        pending = getattr(self, "_prefetch", None)
+        if pending is not None and pending[1].get("loop_done") is None:
+            ev = torch.cuda.Event()
+            ev.record()
+            pending[1]["loop_done"] = ev
+
     def collect(self):
         """The audio features of the batch handed to prefetch(); the current stream waits for them."""
+        self.loop_ended()                        # (a caller that did not say so: whatever it ran beside the pass lies before this point)
         th, box = self._prefetch
         self._prefetch = None
         th.join()
@@ -140,5 +177,6 @@ class WhisperEncoding:
             w1 = torch.cuda.Event(enable_timing=True); w1.record()
             self.prefetch_events = getattr(self, "prefetch_events", [])
             self.prefetch_events.append((box["t0"], box["t1"], w0, w1))
+        self.last_release_layer = box.get("released_at")        # layer from which the pass had the whole chip (None: budget to the end)
         box["xa"].record_stream(cur)             # allocated on the side stream, used on this one
         return box["xa"]

@@ -72,7 +72,7 @@ LIB_PATH = os.environ.get("WM_LIBRARY_PATH") or os.path.join(_HERE, "libwhisper_
 EXPORTS = (
     "wm_version", "wm_last_error", "wm_device_count", "wm_engine_create", "wm_engine_destroy",
     "wm_engine_info", "wm_engine_weight_bytes", "wm_encoder_workspace_bytes", "wm_encoder_forward",
-    "wm_encoder_forward_shared",
+    "wm_encoder_forward_shared", "wm_encoder_forward_range",
     "wm_cross_kv_workspace_bytes", "wm_cross_kv", "wm_decoder_workspace_bytes", "wm_decoder_step",
     "wm_greedy_step", "wm_gemm", "wm_gemm_skinny", "wm_gemm_skinny_default_ksplit", "wm_layernorm",
     "wm_attn_encoder", "wm_attn_decode_cross", "wm_attn_decode_self", "wm_quantize_i8",
@@ -200,6 +200,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.wm_encoder_workspace_bytes.restype = sz
     lib.wm_encoder_forward.argtypes = [vp, vp, i32, vp, vp, sz, vp]
     lib.wm_encoder_forward_shared.argtypes = [vp, vp, i32, vp, vp, sz, i32, vp]
+    lib.wm_encoder_forward_range.argtypes = [vp, vp, i32, vp, vp, sz, i32, i32, i32, vp]
     lib.wm_cross_kv_workspace_bytes.argtypes = [vp, i32]
     lib.wm_cross_kv_workspace_bytes.restype = sz
     lib.wm_cross_kv.argtypes = [vp, vp, i32, C.POINTER(vp), vp, sz, vp]

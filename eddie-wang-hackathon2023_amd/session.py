@@ -192,6 +192,15 @@ class Session(object):
         check(lib.wm_encoder_forward_shared(self._engine.handle, mel.data_ptr(), b, out.data_ptr(), ws.data_ptr(),
                                             ws.numel(), int(cu_budget), stream), "wm_encoder_forward")
 
+    def encoder_forward_range(self, mel: torch.Tensor, out: torch.Tensor, stream: int, cu_budget: int, layer_begin: int, layer_end: int):
+        """Layers [layer_begin, layer_end) of the pass (wm_encoder_forward_range): the convolutions with a range that starts at 0, the
+        final LayerNorm with one that ends at n_audio_layer; the residual stream stays in the session's encoder workspace in between."""
+        lib = self._engine.lib
+        b = mel.shape[0]
+        ws = self._workspace(("enc",), lib.wm_encoder_workspace_bytes(self._engine.handle, b))
+        check(lib.wm_encoder_forward_range(self._engine.handle, mel.data_ptr(), b, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           int(cu_budget), int(layer_begin), int(layer_end), stream), "wm_encoder_forward_range")
+
     def cross_kv(self, xa: torch.Tensor, outs: Sequence[torch.Tensor], stream: int):
         lib = self._engine.lib
         b = xa.shape[0]

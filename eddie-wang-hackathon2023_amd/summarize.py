@@ -157,6 +157,7 @@ def eval_engines_stream(whisper_encoding, whisper_decoding, mels, cu_budget: Opt
         if pending:
             whisper_encoding.prefetch(mel, budget)
         tokens, sum_logprobs, no_speech_probs = whisper_decoding.main_loop(audio_features)
+        whisper_encoding.loop_ended()          # the pass in flight gives back its CU budget once the GPU has finished this loop
         yield whisper_decoding.post_process(tokens, sum_logprobs, no_speech_probs, audio_features, languages)
 
 

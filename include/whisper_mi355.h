@@ -87,6 +87,14 @@ int wm_encoder_forward(const wm_engine* e, const void* mel, int batch, void* out
  * to wm_encoder_forward's (same tiles, same arithmetic, fewer workgroups walking over them).  0 = the whole chip. */
 int wm_encoder_forward_shared(const wm_engine* e, const void* mel, int batch, void* out,
                               void* workspace, size_t workspace_bytes, int cu_budget, wm_stream_t stream);
+/* The same pass in pieces (ABI 7): layers [layer_begin, layer_end) of the encoder on `cu_budget` CUs (0 = the whole chip).  A range
+ * that starts at 0 runs the two convolutions first, one that ends at n_audio_layer the final LayerNorm, which writes `out`; between
+ * the calls of one pass the residual stream lives in `workspace` (same workspace, same batch, calls in layer order on one stream
+ * or ordered streams).  A caller that runs the pass beside a decode loop gives back the CU budget the moment the loop has ended:
+ * the layers still to come are issued with cu_budget 0 (WhisperEncoding.prefetch does, layer by layer).  Bit-identical to
+ * wm_encoder_forward whatever the cut and the budgets.                                                                        */
+int wm_encoder_forward_range(const wm_engine* e, const void* mel, int batch, void* out, void* workspace, size_t workspace_bytes,
+                             int cu_budget, int layer_begin, int layer_end, wm_stream_t stream);
 
 /* ---- cross-attention K/V engine: W/decoding.py:515-541 -> CrossAttn_KV.forward (model.py:469-540)
  * xa          : fp16 [batch, n_audio_ctx, n_text_state]

@@ -438,3 +438,41 @@ def test_a_first_call_under_stream_capture_carries_its_own_initialisation(lib, t
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
     st_ = native.chain_status()
     assert not st_["error_pending"] and not st_["declined"], st_
+
+
+# ------------------------------------------------------------------------------------------ the encoder beside the loop gives its CUs back
+def test_prefetched_encoder_pass_is_bit_identical_whenever_the_budget_is_released(lib, tmpdir_module):
+    """WhisperEncoding.prefetch issues the pass layer by layer (wm_encoder_forward_range) on a CU budget and hands the layers still to
+    come to the whole chip once `loop_ended()`'s event has passed: whatever the cut -- released before the first layer, somewhere in
+    the middle, never -- the audio features are the bits of the plain pass (same tiles, other workgroups), and the pieces of a pass
+    issued by hand add up to it."""
+    import time
+    eng, dims = _small_engine(tmpdir_module, "tiny", True, False)
+    enc = WhisperEncoding(eng)
+    mel = synthetic_mel(6, 2 * dims.n_audio_ctx, dims.n_mels, 5).cuda()
+    ref = enc.get_audio_features(mel).clone()
+    released = []
+    for when in ("at once", "later", "never"):
+        enc.prefetch(mel, 64)
+        if when == "at once":
+            enc.loop_ended()
+        elif when == "later":
+            time.sleep(0.02)
+            torch.cuda.synchronize()
+            enc.loop_ended()
+        xa = enc.collect()
+        torch.cuda.synchronize()
+        released.append(enc.last_release_layer)
+        assert torch.equal(xa.view(torch.int16), ref.view(torch.int16)), when
+    assert released[0] is not None and released[0] <= 2, released
+    # by hand: three ranges with three budgets
+    out = torch.empty_like(ref)
+    s = torch.cuda.current_stream().cuda_stream
+    n = dims.n_audio_layer
+    enc.session.encoder_forward_range(mel, out, s, 32, 0, 1)
+    enc.session.encoder_forward_range(mel, out, s, 0, 1, n - 1)
+    enc.session.encoder_forward_range(mel, out, s, 96, n - 1, n)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    with pytest.raises(native.WmError):
+        enc.session.encoder_forward_range(mel, out, s, 0, 2, 1)
