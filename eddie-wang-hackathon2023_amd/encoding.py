@@ -102,10 +102,10 @@ class WhisperEncoding:
     # Round 5: the budget is given back when the loop ends.  A pass confined to 96 CUs takes three times the whole chip's time; beside
     # a decode loop of 128 tokens x 576 utterances that is the point, behind a loop that ended after 30 tokens (LibriSpeech-like
     # lengths) it made the pipelined schedule 34 % SLOWER than one stage after the other.  The helper thread therefore issues the
-    # pass LAYER BY LAYER (wm_encoder_forward_range), at most two layers ahead of the GPU, and looks before each layer whether
+    # pass LAYER BY LAYER (wm_encoder_forward_range), each layer when the one before it has finished, and looks before each layer whether
     # the loop has ended -- `loop_ended()` records an event on the caller's stream behind the loop; the helper polls it -- from then
     # on the layers still to come are issued for the whole chip.  No prediction of the loop's length is needed, a short loop costs
-    # at most the two layers already queued, and the result is bit-identical whatever the cut (same tiles, other workgroups).
+    # at most the layer that is running, and the result is bit-identical whatever the cut (same tiles, other workgroups).
     def prefetch(self, mel, cu_budget: int = DEFAULT_SHARED_CU_BUDGET):
         import threading
         assert getattr(self, "_prefetch", None) is None, "one prefetch at a time"
@@ -133,8 +133,11 @@ class WhisperEncoding:
                     else:
                         budget, done = cu_budget, []
                         for i in range(n_layer):
-                            if len(done) >= 2:
-                                done[-2].synchronize()             # at most two layers queued ahead of the GPU: the look below is fresh
+                            if done:
+                                done[-1].synchronize()             # a layer is issued when the one before it has finished: the look below is fresh
+                                                                   # (the GPU idles for the ~0.1 ms the host needs to issue a layer's 7 launches,
+                                                                   # 0.1-0.2 % of a 45-135 ms layer; two layers queued ahead cost a short loop
+                                                                   # 180 ms of budget-confined work behind its end: profiles/r5h_*)
                             ev = box["loop_done"]
                             if budget > 0 and ev is not None and ev.query():
                                 budget, box["released_at"] = 0, i  # the loop has ended: the whole chip for what is left
