@@ -467,6 +467,41 @@ class WhisperDecoding:
                 audio_features = audio_features.unsqueeze(0)
             n_audio, dev = audio_features.shape[0], audio_features.device
             cfg = self.decoder_config
+            if self.n_group > 1 and self.device_sampling and audio_features.is_cuda:
+                # best_of / beam candidates: main_loop decodes n_audio x n_group rows.  The state keeps ONE buffer set at a time, so a
+                # language pass over n_audio rows would free and re-allocate the caches, the cross K/V buffers and the graphs on every
+                # clip.  The pass runs over the candidates' rows instead -- the SAME repeated tensor main_loop will use
+                # (_candidate_rows): one buffer set, the cross K/V computed once for both calls -- and reads every n_group-th row
+                languages_r, probs_r = self._detect_language_rows(self._candidate_rows(audio_features), False, _retry)
+                languages = languages_r[:: self.n_group]
+                language_probs = probs_r[:: self.n_group] if probs_r is not None else None
+                if self.options.language is None:
+                    self.tokens = self.tokens[:: self.n_group].contiguous()
+                if single:
+                    language_probs = language_probs[0] if language_probs is not None else None
+                return languages, language_probs
+            return self._detect_language_rows(audio_features, single, _retry)
+        return languages, language_probs
+
+    def _candidate_rows(self, audio_features):
+        """The audio features with every clip repeated n_group times (best_of / beam candidates share their utterance's audio: the
+        reference repeats the features too, W/decoding.py:538-539) -- ONE tensor per encoder run, so that the language pass and the
+        decode loop key the same cross K/V (`_features_key`) and the same buffer set."""
+        from encoding import stamp_generation
+        key = self._features_key(audio_features)
+        c = getattr(self, "_rep_cache", None)
+        if key is not None and c is not None and c[0] == key:
+            return c[1]
+        rep = stamp_generation(audio_features.repeat_interleave(self.n_group, dim=0))
+        self._rep_cache = (key, rep, audio_features)       # (the original kept alive: its pointer is part of the key)
+        return rep
+
+    def _detect_language_rows(self, audio_features, single, _retry):
+        """The pass itself over the rows of `audio_features` [n, n_audio_ctx, C] (detect_language)."""
+        if True:
+            languages, language_probs = None, None
+            n_audio, dev = audio_features.shape[0], audio_features.device
+            cfg = self.decoder_config
             st = self._fast_state(n_audio, dev)
             one_row = any(hi - lo <= 2 for lo, hi in self._groups(n_audio)[1])      # groups of one or two rows may run as ONE launch per step
             if one_row and native.chain_status()["error_pending"]:                  # (a peek at a host word: no synchronisation)
@@ -488,7 +523,7 @@ class WhisperDecoding:
                                                   st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g)
                 main.wait_stream(streams[g])
             if one_row and not _retry and self._chain_gave_up("language pass"):
-                return self.detect_language(audio_features[0] if single else audio_features, _retry=True)
+                return self._detect_language_rows(audio_features, single, True)
             language_tokens, language_probs, languages = self._language_from_logits(
                 st['lang_logits'][:, 0].float(), n_audio, single)
             if self.options.language is None:
@@ -782,6 +817,7 @@ class WhisperDecoding:
         HBM-bound part of a step) the other group runs its latency-bound weight-streaming chain.
         Rows that have emitted EOT drop out of the attention kernels and a group whose rows are all
         finished is no longer stepped (`skip_finished_rows`): the loop's cost follows the live rows."""
+        features_in = audio_features
         if self.options.temperature != 0 or self.n_group != 1:
             # Sampling options (W/decoding.py:274-300 temperature, :92-115 best_of + ranker).  Round 4: the device loop takes them --
             # the draw is a Gumbel-max inside the greedy kernel, candidates are rows like any others.  `device_sampling = False`
@@ -789,7 +825,7 @@ class WhisperDecoding:
             if not self.device_sampling or not audio_features.is_cuda:
                 return self.main_loop_reference(audio_features)
             if self.n_group > 1:      # candidates share their utterance's audio: the reference repeats the features too (:538-539 of this file)
-                audio_features = audio_features.repeat_interleave(self.n_group, dim=0)
+                audio_features = self._candidate_rows(audio_features)
         dev = audio_features.device
         tokens0 = self._initial_token_rows(audio_features.shape[0] // self.n_group, dev)
         n_batch, L0 = tokens0.shape
@@ -919,8 +955,7 @@ class WhisperDecoding:
             # one-row groups run the token step as ONE launch whose workgroups wait for each other with bounded spins; a wait that was
             # given up invalidates the step and every token after it.  The utterance is decoded again, in this process, on the
             # launch-per-kernel path (the library has taken the device off the one-launch forms; the captured graphs are gone).
-            return self.main_loop(audio_features[:: self.n_group] if self.n_group > 1 and audio_features.shape[0] == n_batch else audio_features,
-                                  ignore_eot=ignore_eot, row_limit=row_limit, _retry=True)
+            return self.main_loop(features_in, ignore_eot=ignore_eot, row_limit=row_limit, _retry=True)
         return out
 
     def _main_loop_partitioned(self, audio_features, st, cross, L0, n_micro, bounds, ignore_eot):
