@@ -929,17 +929,21 @@ struct GroupStep {
     // uses torch.empty).  A state the library has not initialised under this (address, workspace_id) is cleared by a memset ON THE
     // STREAM OF THE CALL, ahead of the embedding kernel that opens the call (which counts the cleared call counter up to 1: tag 0 is
     // never valid, and bit 31 of every epoch is set besides).  workspace_id == 0 vouches for nothing: cleared on every call.  Under
-    // stream capture the nodes are recorded but not run, so nothing is remembered: a captured call always carries its own initialisation.
+    // stream capture the nodes are recorded but not run, so a captured call is never REMEMBERED: one that meets a state no eager
+    // call has initialised carries the initialisation inside its graph (every replay clears and rewrites: correct, slower), one that
+    // follows an eager call on the same (address, id) -- decoding.py's order -- relies on the state that call left.
     bool ws_fresh = false, ws_capturing = false;
     int chain_prepare_workspace(hipStream_t s) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         ws_capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-        ws_fresh = io->workspace_id == 0 || ws_capturing;
-        if (!ws_fresh) {
+        ws_fresh = true;
+        if (io->workspace_id != 0) {
             std::lock_guard<std::mutex> lk(e->chain_io_mu);
             auto it = e->chain_io_seen.find(w.layer_io);
+            // known: an EAGER call has initialised this state under this id (it persists in the workspace: a call captured later
+            // relies on it, like an eager one -- a memset node and four table launches in every replay cost the batch-1 step 2 %)
             ws_fresh = it == e->chain_io_seen.end() || it->second.id != io->workspace_id;
-            if (ws_fresh) {
+            if (ws_fresh && !ws_capturing) {         // (a captured call enqueues nothing: it initialises inside its graph and is not remembered)
                 if (e->chain_io_seen.size() > 4096) e->chain_io_seen.clear();
                 wm_engine::ChainWsSeen& seen = e->chain_io_seen[w.layer_io];
                 seen.id = io->workspace_id; seen.tab.clear();
@@ -958,16 +962,20 @@ struct GroupStep {
         const int n = e->dims.n_text_layer;
         std::vector<ChainLayerIo> tab((size_t)n);
         for (int i = 0; i < n; ++i) tab[i] = ChainLayerIo{io->cross[i], io->present[i]};
-        if (io->workspace_id == 0 || ws_capturing) {     // nothing is vouched for (or remembered): the table is rewritten on every call
+        if (io->workspace_id == 0) {                 // nothing is vouched for: the table is rewritten on every call
             if (launch_chain_io_table(w.layer_io, tab.data(), n, s)) return 2;
         } else {
             std::lock_guard<std::mutex> lk(e->chain_io_mu);
-            wm_engine::ChainWsSeen& seen = e->chain_io_seen[w.layer_io];
-            const bool same = !ws_fresh && seen.id == io->workspace_id && seen.tab.size() == tab.size() &&
-                              memcmp(seen.tab.data(), tab.data(), tab.size() * sizeof(ChainLayerIo)) == 0;
+            auto it = e->chain_io_seen.find(w.layer_io);
+            const bool have = it != e->chain_io_seen.end() && it->second.id == io->workspace_id;
+            const bool same = !ws_fresh && have && it->second.tab.size() == tab.size() &&
+                              memcmp(it->second.tab.data(), tab.data(), tab.size() * sizeof(ChainLayerIo)) == 0;
             if (!same) {
                 if (launch_chain_io_table(w.layer_io, tab.data(), n, s)) return 2;
-                seen.id = io->workspace_id; seen.tab = tab;
+                if (have) {
+                    if (ws_capturing) it->second.tab.clear();      // the replay will rewrite the table: what an eager call wrote is no longer known to be there
+                    else it->second.tab = tab;
+                }
             }
         }
         GemvChainParams p{};

@@ -131,8 +131,10 @@ class WhisperEncoding:
                     if not release:
                         self.session.encoder_forward(m16, out, side.cuda_stream, cu_budget)
                     else:
-                        budget, done = cu_budget, []
-                        for i in range(n_layer):
+                        # layers per issue: a layer of B clips takes ~ 0.23 ms x B on a 96-CU budget and the helper thread needs ~ 0.1 ms to
+                        # wake up and issue one -- small batches go in chunks of several layers (B = 1: two chunks; from 20 clips on: one layer)
+                        budget, done, chunk = cu_budget, [], max(1, -(-20 // int(m16.shape[0])))
+                        for i in range(0, n_layer, chunk):
                             if done:
                                 done[-1].synchronize()             # a layer is issued when the one before it has finished: the look below is fresh
                                                                    # (the GPU idles for the ~0.1 ms the host needs to issue a layer's 7 launches,
@@ -141,7 +143,7 @@ class WhisperEncoding:
                             ev = box["loop_done"]
                             if budget > 0 and ev is not None and ev.query():
                                 budget, box["released_at"] = 0, i  # the loop has ended: the whole chip for what is left
-                            self.session.encoder_forward_range(m16, out, side.cuda_stream, budget, i, i + 1)
+                            self.session.encoder_forward_range(m16, out, side.cuda_stream, budget, i, min(n_layer, i + chunk))
                             e = torch.cuda.Event(); e.record()
                             done.append(e)
                     box["xa"] = stamp_generation(out)

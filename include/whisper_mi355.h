@@ -149,7 +149,9 @@ typedef struct wm_decoder_io {
      * with a non-zero id once per (address, id), and the table is rewritten only when the pointers differ from what the library last
      * wrote there.  A non-zero id is the caller's promise that since the id was first passed nothing but wm_decoder_step calls of this
      * engine with the same (batch, n_new) have written to the workspace: give every allocation a new id, and a new one whenever the
-     * memory is reused for anything else.  Calls that are being captured into a graph always carry their own initialisation. */
+     * memory is reused for anything else.  A call that is being captured into a graph is never remembered: if no eager call has
+     * initialised the state under this (address, id) before, the graph carries the initialisation and every replay repeats it --
+     * issue one eager call first (as WhisperDecoding.main_loop does) to keep it out of the graph. */
     uint64_t workspace_id;
 } wm_decoder_io;
 size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new);
