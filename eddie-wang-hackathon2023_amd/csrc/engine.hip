@@ -1423,7 +1423,9 @@ int wm_set_decode_chain(int on) {
 int wm_decode_chain_error(int* out) {
     WM_REQUIRE(out, "wm_decode_chain_error: null argument");
     ChainDev& cd = chain_dev_slot(current_device_index());
-    WM_CHECK_HIP(hipDeviceSynchronize());            // the word is current for everything the caller has enqueued so far
+    // No synchronisation here (round 5: a device-wide one also waited for whatever ran beside the loop -- the next batch's encoder on its
+    // own stream -- and cost the pipelined batch-1 job 3.5 %): the word is in host memory and current for every step whose results the
+    // caller has already waited for.
     const unsigned v = chain_err_peek(cd);
     *out = (int)v;
     if (v) {

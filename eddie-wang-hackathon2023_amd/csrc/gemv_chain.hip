@@ -397,13 +397,15 @@ struct ChainLayerArgs { const h16* cross_kv; const h16* cross_qbias; void* self_
 constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
 constexpr unsigned CHAIN_EPOCH_LIVE = 0x80000000u;
 
+template <int NR>
 __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, const void* cross_kv, unsigned char* kv_lds, int per_split) {
     // waves 4-7: this workgroup's piece of K, then of V, as 1 KiB pieces (8 rows of 128 B) into LDS, linear
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int per_row = p.cross_heads * p.cross_nsplit, n_items = p.rows * per_row;
+    const int per_row = p.cross_heads * p.cross_nsplit, n_items = NR * per_row;
     const int item = (int)blockIdx.x - ((int)gridDim.x - n_items);       // the LAST workgroups (see the kernel): item = (row, piece, head)
     if (wid < 4 || item < 0) return;
-    const int urow = item / per_row, h = (item % per_row) % p.cross_heads, sp = (item % per_row) / p.cross_heads;
+    const int urow = NR == 1 ? 0 : item / per_row, rem = NR == 1 ? item : item - urow * per_row;
+    const int h = rem % p.cross_heads, sp = rem / p.cross_heads;
     const int k_begin = sp * per_split, nkeys = max(0, min(p.cross_Tk, k_begin + per_split) - k_begin);
     if (nkeys == 0) return;
     const int n_pieces = (nkeys + 7) >> 3;
@@ -417,17 +419,18 @@ __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, c
     }
 }
 
+template <int NR>
 __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, const ChainLayerArgs& la, unsigned epoch_q, const unsigned char* kv_lds, int per_split,
                                                   float* s_sc, float (*s_redc)[2] /* [8] */, float (*s_o)[64], float* s_q) {
     constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
     constexpr int STRIDE = 4 * RPI * UNR;
     constexpr int KB = 3, KB2 = 2;                 // iterations whose rows are requested together (P.V | scores, a wave's share)
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int per_row = p.cross_heads * p.cross_nsplit, n_items = p.rows * per_row;
+    const int per_row = p.cross_heads * p.cross_nsplit, n_items = NR * per_row;
     const int item = (int)blockIdx.x - ((int)gridDim.x - n_items);
     const bool has_item = item >= 0;
-    const int urow = has_item ? item / per_row : 0;
-    const int h = has_item ? (item % per_row) % p.cross_heads : 0, sp = has_item ? (item % per_row) / p.cross_heads : 0;
+    const int urow = (has_item && NR > 1) ? item / per_row : 0, rem = item - urow * per_row;
+    const int h = has_item ? rem % p.cross_heads : 0, sp = has_item ? rem / p.cross_heads : 0;
     const int k_begin = sp * per_split, nkeys = has_item ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
     const unsigned long long* gran_q = p.gran_q + (size_t)urow * p.cross_heads * 64;              // this row's q sums
     unsigned long long* gran_p = p.gran_p + (size_t)urow * p.cross_heads * 66 * 4;               // ... and its pieces' partial results
@@ -587,10 +590,12 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
 // num = sum_q o_q f_q in piece order, (h16)(num / den) -- with every lane holding all four (m, l) pairs itself instead of taking
 // them from lanes 0-3 (the same values: fmaxf and the products do not depend on who computes them).  All eight waves share the
 // heads (three per wave at 20 heads), a wave's 18 loads are in flight together; the merged row goes to s_in[0].  Ends with a barrier.
+template <int NR>
 __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, unsigned tag, h16 (*s_in)[CHAIN_MAX_IN + 8]) {
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int MH = 3;
-  for (int row = 0; row < p.rows; ++row) {                    // (a row's heads as at one row; the rows one after the other)
+#pragma unroll
+  for (int row = 0; row < NR; ++row) {                        // (a row's heads as at one row; the rows one after the other)
     const unsigned long long* gran_p = p.gran_p + (size_t)row * p.merge_heads * 66 * 4;
     h16* s_row = &s_in[row][0];
     for (int h0 = wid; h0 < p.merge_heads; h0 += 8 * MH) {
@@ -896,7 +901,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     // self-attention's heads to the ones before them: the first workgroups own the output groups of every n_state-wide Linear (and
     // both slots of the widest), the last ones idle through most stages -- and the four upper waves of a workgroup that carries
     // K / V rows in flight must not meet a stage's "everything of mine has landed" wait before those rows are due.
-    chain_cross_prefetch(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
+    chain_cross_prefetch<NR>(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
     const int n_cross_wgs = NR * p.cross_heads * p.cross_nsplit, n_self_wgs = NR * p.self_heads;      // one (row, head, piece) | (row, head) each
     const int self_base = max((int)gridDim.x - n_cross_wgs - n_self_wgs, 0);
     const int self_idx = (int)blockIdx.x - self_base;                    // this workgroup's self-attention (row, head), if 0 <= self_idx < rows x heads
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             const unsigned long long* gran = p.gran_h;
             unsigned tag = epoch - 1;
             if (s == p.merge_at) {                                // (only the workgroups that own a group of this stage need the row)
-                if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged(p, epoch0 + (unsigned)p.cross_at + 1, s_in);
+                if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged<NR>(p, epoch0 + (unsigned)p.cross_at + 1, s_in);
                 in_kind = CHAIN_IN_LDS;
             }
             else if (s == 0) { gran = p.gran_c; tag = epoch0; }
@@ -950,9 +955,9 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             else chain_stage<WB, false, false, NR>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
             if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
             if (l >= 0 && s == p.cross_at) {
-                chain_cross_stage(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
+                chain_cross_stage<NR>(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
                 // the NEXT layer's K / V rows set out now: they have the rest of this layer to arrive
-                if (whole && l + 1 < p.n_layers) chain_cross_prefetch(p, s_lio[l + 1].cross_kv, kv_lds, per_split);
+                if (whole && l + 1 < p.n_layers) chain_cross_prefetch<NR>(p, s_lio[l + 1].cross_kv, kv_lds, per_split);
             }
         }
     }

@@ -522,10 +522,10 @@ class WhisperDecoding:
                                                   [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
                                                   st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g)
                 main.wait_stream(streams[g])
+            language_tokens, language_probs, languages = self._language_from_logits(
+                st['lang_logits'][:, 0].float(), n_audio, single)                # (brings the logits to the host: the pass has finished)
             if one_row and not _retry and self._chain_gave_up("language pass"):
                 return self._detect_language_rows(audio_features, single, True)
-            language_tokens, language_probs, languages = self._language_from_logits(
-                st['lang_logits'][:, 0].float(), n_audio, single)
             if self.options.language is None:
                 self.tokens = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
                 self.tokens[:, self.sot_index + 1] = language_tokens.cpu()        # write language tokens

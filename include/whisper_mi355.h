@@ -315,8 +315,9 @@ int wm_set_gemm_small_tiles(int tiles);
  * launch on the device has given up.  Every wait inside the launch is bounded (about a second): a wave that gives up sets a word in
  * pinned host memory and the rest of the launch falls through.
  * wm_decode_chain_error: *out != 0 when a workgroup of a chain gave up a wait since the last call -- the results of that step and of
- * everything decoded from it are NOT valid (another tenant held CUs or LDS while the launch was dispatched).  The call synchronises
- * with the device, clears the word and takes the device off the one-launch forms (wm_set_decode_chain re-arms it): decode the
+ * everything decoded from it are NOT valid (another tenant held CUs or LDS while the launch was dispatched).  The call does not
+ * synchronise (the word lives in host memory): ask after waiting for the steps in question, e.g. after reading their logits.  It
+ * clears the word and takes the device off the one-launch forms (wm_set_decode_chain re-arms it): decode the
  * utterance again, it now runs a launch per kernel (WhisperDecoding.main_loop / detect_language do exactly that, with one warning).
  * Until it has been called, every wm_decoder_step / wm_decoder_step_multi on that device returns 1 (wm_last_error says why) -- a
  * caller that never looks cannot go on decoding from garbage.  (Calls under stream capture are exempt: they enqueue nothing.)
