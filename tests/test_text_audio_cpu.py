@@ -217,8 +217,9 @@ def test_summarize_dataset_discovery_and_scoring(golden_dir, tmp_path):
 def test_pipelined_evaluation_protocol_with_fakes():
     """summarize.eval_engines_stream / transcribe_dataset_stream: the host-side pipelining protocol on fakes (no GPU, no
     library).  The encoder of batch n + 1 is handed to prefetch() after the language pass of batch n and before its decode
-    loop, collect() is called once per prefetch, the first batch is encoded directly, a budget of 0 switches the overlap off,
-    and results come back in batch order."""
+    loop, `loop_ended()` follows every decode loop (round 5: the pass in flight gives back its CU budget from there), collect() is
+    called once per prefetch, the first batch is encoded directly, a budget of 0 switches the overlap off, and results come back in
+    batch order."""
     import summarize as S
     log = []
 
@@ -227,6 +228,7 @@ def test_pipelined_evaluation_protocol_with_fakes():
         def get_audio_features_async(self, mel): log.append(("encode", mel)); return ("xa", mel)
         def prefetch(self, mel, budget): assert self.pending is None; log.append(("prefetch", mel, budget)); self.pending = mel
         def collect(self): mel, self.pending = self.pending, None; log.append(("collect", mel)); return ("xa", mel)
+        def loop_ended(self): log.append(("loop ended", self.pending))
 
     class Dec:
         def detect_language(self, xa): log.append(("lang", xa[1])); return ["en"], None
@@ -235,13 +237,13 @@ def test_pipelined_evaluation_protocol_with_fakes():
 
     out = list(S.eval_engines_stream(Enc(), Dec(), iter(["a", "b", "c"]), cu_budget=24))
     assert out == [[("result", "a")], [("result", "b")], [("result", "c")]]
-    assert log == [("encode", "a"), ("lang", "a"), ("prefetch", "b", 24), ("loop", "a"),
-                   ("collect", "b"), ("lang", "b"), ("prefetch", "c", 24), ("loop", "b"),
-                   ("collect", "c"), ("lang", "c"), ("loop", "c")]
+    assert log == [("encode", "a"), ("lang", "a"), ("prefetch", "b", 24), ("loop", "a"), ("loop ended", "b"),
+                   ("collect", "b"), ("lang", "b"), ("prefetch", "c", 24), ("loop", "b"), ("loop ended", "c"),
+                   ("collect", "c"), ("lang", "c"), ("loop", "c"), ("loop ended", None)]
     log.clear()
     out = list(S.eval_engines_stream(Enc(), Dec(), iter(["a", "b"]), cu_budget=0))
     assert out == [[("result", "a")], [("result", "b")]]
-    assert log == [("encode", "a"), ("lang", "a"), ("loop", "a"), ("encode", "b"), ("lang", "b"), ("loop", "b")]
+    assert [e for e in log if e[0] != "loop ended"] == [("encode", "a"), ("lang", "a"), ("loop", "a"), ("encode", "b"), ("lang", "b"), ("loop", "b")]
     assert list(S.eval_engines_stream(Enc(), Dec(), iter([]))) == []
 
 
