@@ -476,3 +476,37 @@ def test_prefetched_encoder_pass_is_bit_identical_whenever_the_budget_is_release
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
     with pytest.raises(native.WmError):
         enc.session.encoder_forward_range(mel, out, s, 0, 2, 1)
+
+
+def test_two_row_step_with_rows_that_finish_at_different_times(lib, tmpdir_module, chain_rearmed):
+    """Per-row completion in a group of two rows: one row ends (its `row_limit`) long before the other.  The launch-per-kernel path drops
+    the finished row from the attention kernels; the one-launch step keeps computing it (a two-row group is stepped while either row
+    decodes; what the finished row's slots compute nobody reads) -- tokens and log-probabilities of both rows are the same in both
+    forms and equal to what each utterance gets alone with its own limit."""
+    eng, dims = _small_engine(tmpdir_module)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(2, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    limits = torch.tensor([3, 14], dtype=torch.int32)
+    outs = {}
+    for mode in (0, 2):
+        lib.wm_set_decode_chain(mode)
+        dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=16))
+        dec.detect_language(xa)
+        before = native.chain_status()["launches"]
+        t, lp, _ = dec.main_loop(xa, row_limit=limits)
+        assert (native.chain_status()["launches"] > before) == (mode > 0)
+        outs[mode] = (t.cpu(), lp.cpu())
+        del dec
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    eot = 50257
+    t = outs[2][0]
+    assert int((t[0, 3:] != eot).sum()) == 3 and int((t[1, 3:] != eot).sum()) == 14
+    for b in (0, 1):
+        solo = WhisperDecoding(eng, options=DecodingOptions(sample_len=16))
+        xb = xa[b:b + 1].contiguous()
+        solo.detect_language(xb)
+        t1, lp1, _ = solo.main_loop(xb, row_limit=limits[b:b + 1])
+        n = t1.shape[1]
+        assert torch.equal(t1[0].cpu(), t[b, :n]) and bool((t[b, n:] == eot).all())
+        assert torch.equal(lp1[0].cpu(), outs[2][1][b])
+        del solo
