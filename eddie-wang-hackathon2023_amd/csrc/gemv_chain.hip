@@ -94,6 +94,9 @@ enum ChainIn : int {
     CHAIN_IN_LDS = 0,          // the row is in s_in[0] already (chain_merge_tagged has put it there)
     CHAIN_IN_GRANULES = 1      // an fp16 row published as granules in this launch: `gran`, tagged `tag`
 };
+template <int NR>
+__device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, unsigned tag, h16 (*s_in)[CHAIN_MAX_IN + 8]);      // (below)
+
 // NR activation rows (1 | 2).  The MFMA's 16 A rows carry the activation rows alternately (A row = lane & 15, row = lane & (NR - 1)), so
 // a row's sums are the same chain of MFMA steps whatever NR is, and come out in accumulator element `row` of the first 16 lanes.
 // Where the rows of a stage's input sit in LDS (s_in is two arrays of CHAIN_MAX_IN + 8 halves):
@@ -170,6 +173,9 @@ template <int WB, bool WIDE, bool LN, int NR>
 __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const ChainStage& st, int s, unsigned epoch, bool& own_valid,
                                             float (*s_red)[64][4], h16 (*s_in)[CHAIN_MAX_IN + 8], h16 (*s_own)[16],
                                             int in_kind, const unsigned long long* gran, unsigned tag, bool x_in_granules) {
+    // in_kind == CHAIN_IN_LDS: the stage's input rows are the merge of the cross-attention's pieces (tagged `tag`), which the workgroup
+    // performs INSIDE this stage, behind the weight requests (round 5: merged first and requested afterwards, the weights' round trip
+    // -- ~ 1 us per layer -- sat between the arrival of the last piece and the multiply)
     constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);   // inputs per 1 KiB weight tile
     constexpr int NM = KT / 32;
     constexpr int TB = WB == 16 ? 10 : 5;
@@ -189,6 +195,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     // an idle slot (no group of this stage falls to it) only keeps the workgroup's barriers company: it touches no memory, so that
     // waves which carry LDS-DMA requests for a later stage (the cross-attention's K / V rows) are not made to wait for them here
     if (!has_group) {
+        if (!LN && !WIDE && in_kind == CHAIN_IN_LDS && (int)blockIdx.x < st.n_blocks) chain_merge_tagged<NR>(p, tag, s_in);      // (all eight waves merge)
         const int nbar = LN ? 3 : 2;
         for (int b = 0; b < nbar; ++b) __syncthreads();
         if (st.mode == 2) own_valid = true;
@@ -240,7 +247,9 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             for (int m = 0; m < NM; ++m) a[0][i][m] = *(const half8v*)(arow + m * 8);
         }
     } else if (!WIDE && in_kind == CHAIN_IN_LDS) {
-        // the merged attention rows are in s_in[row] (chain_merge_tagged, all eight waves, ended by a barrier)
+        // the merged attention rows go to s_in[row] (chain_merge_tagged, all eight waves, ended by a barrier) -- with this stage's weights
+        // already requested
+        chain_merge_tagged<NR>(p, tag, s_in);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int t_last = max(t_end[j] - 1, t_begin[j]);
@@ -945,9 +954,8 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             int in_kind = CHAIN_IN_GRANULES;
             const unsigned long long* gran = p.gran_h;
             unsigned tag = epoch - 1;
-            if (s == p.merge_at) {                                // (only the workgroups that own a group of this stage need the row)
-                if ((int)blockIdx.x < st.n_blocks) chain_merge_tagged<NR>(p, epoch0 + (unsigned)p.cross_at + 1, s_in);
-                in_kind = CHAIN_IN_LDS;
+            if (s == p.merge_at) {                                // (the workgroups that own a group of this stage merge the pieces inside it)
+                in_kind = CHAIN_IN_LDS; tag = epoch0 + (unsigned)p.cross_at + 1;
             }
             else if (s == 0) { gran = p.gran_c; tag = epoch0; }
             if (wide) chain_stage<WB, true, false, NR>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
