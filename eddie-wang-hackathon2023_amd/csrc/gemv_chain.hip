@@ -674,7 +674,7 @@ __device__ __forceinline__ int chain_self_prefetch(const GemvChainParams& p, con
 // outputs are published as granules (p.gran_c, tagged with the launch's epoch) for the out projection, this launch's next stage.
 template <bool I8>
 __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const ChainLayerArgs& la_, int T, unsigned epoch0, unsigned tag_s, int h, int urow, float* s_p, h16 (*s_new)[64],
-                                                 float (*s_r2)[4], float* s_o_flat, const unsigned char* lds_rows, int lds_v_off) {
+                                                 float (*s_r2)[4], float* s_o_flat, float* s_lut, const unsigned char* lds_rows, int lds_v_off) {
     ChainLayerArgs la = la_;                                  // this row's share of the cache ([row][2][H][cap][64])
     la.self_cache = (unsigned char*)la_.self_cache + (size_t)urow * p.self_row_bytes;
     constexpr float SCALE = 0.35355339059327373f;     // 64^-0.25 (attn_decode.hip: ATTN_SCALE)
@@ -711,6 +711,14 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     if (worker && T > 0 && !in_lds) rows_to_registers();
     const float t_dq = la.self_kv_scale;
     const float inv_t = 1.0f / la.self_kv_scale;
+    // int8 cache: what a cached CODE contributes depends on the code and the layer's scale only -- r16(r16(code * t) * SCALE) to a score,
+    // r16(code * t) to P.V (attn_self_wg_kernel's expressions) -- so the 2 x 256 values are computed once per stage (every thread one)
+    // and looked up: the same bits, an LDS read instead of seven vector instructions per cached element (64 dims x 11 instructions per
+    // key and lane were ~ 1.4 us of the stage; round 5)
+    if constexpr (I8) {
+        const float d = r16((float)(int)(int8_t)(tid & 255) * t_dq);
+        s_lut[tid] = tid < 256 ? r16(d * SCALE) : d;
+    }
     float k_new = 0.f, v_new = 0.f;
     if (wid == 0) {                                   // this call's q, k, v of the head (lane = dim): one slab, bias, fp16
         float q = 0.f, k = 0.f, v = 0.f;
@@ -766,8 +774,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
                             const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
-                                const int8_t q8 = (int8_t)((ws[e >> 2] >> (8 * (e & 3))) & 0xff);
-                                const float kd = r16(r16((float)q8 * t_dq) * SCALE);
+                                const float kd = s_lut[(ws[e >> 2] >> (8 * (e & 3))) & 0xff];      // = r16(r16((float)code * t_dq) * SCALE)
                                 acc = fmaf((float)s_q[c * 16 + e], kd, acc);
                             }
                         } else {
@@ -815,10 +822,8 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
             if (I8) {
                 const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                for (int d = 0; d < 16; ++d) {
-                    const int8_t q8 = (int8_t)((ws[d >> 2] >> (8 * (d & 3))) & 0xff);
-                    o[d] = fmaf(pj, r16((float)q8 * t_dq), o[d]);
-                }
+                for (int d = 0; d < 16; ++d)
+                    o[d] = fmaf(pj, s_lut[256 + ((ws[d >> 2] >> (8 * (d & 3))) & 0xff)], o[d]);      // = r16((float)code * t_dq)
             } else {
                 const half8v wh = __builtin_bit_cast(half8v, w);
 #pragma unroll
@@ -933,8 +938,9 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
             float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
             float* s_o_flat = (float*)&s_in[0][0];
+            float* s_lut = &s_red[4][0][0];                 // 2 x 256 floats (s_red[4], s_red[5])
             const unsigned tag_s = (gen | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
-            chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, self_h, self_r, s_p, s_new, s_r2, s_o_flat, kv_lds, self_v_off);
+            chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, self_h, self_r, s_p, s_new, s_r2, s_o_flat, s_lut, kv_lds, self_v_off);
             // the NEXT layer's cached rows set out now (the stage's last barrier is behind every read of this layer's)
             self_v_off = (whole && l + 1 < p.n_layers) ? chain_self_prefetch<I8KV>(p, (const unsigned char*)s_lio[l + 1].cache + self_row_off, T_now, self_h, kv_lds, 2 * per_split * 128) : 0;
         }
