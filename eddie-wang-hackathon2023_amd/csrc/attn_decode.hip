@@ -289,6 +289,10 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
     __shared__ h16 s_qall[MAX_L][64], s_knew[MAX_L][64], s_vnew[MAX_L][64];
     __shared__ float s_o[NT][DIMS + 1];
     __shared__ float s_red[2][SELF_WAVES];
+    // int8 cache: what a cached code contributes depends on the code and the layer's scale only (r16(r16(code t) SCALE) to a score,
+    // r16(code t) to P.V): 2 x 256 values, computed once per launch and looked up -- the same bits as evaluating the expression per
+    // element (seven vector instructions each, ~ a microsecond of a one-wave-per-64-keys score pass; csrc/gemv_chain.hip does the same)
+    __shared__ float s_lut[I8 ? 512 : 1];
 
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int b = blockIdx.y;
@@ -318,6 +322,11 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
     }
     const float t_dq = p.kv_scale;
     const float inv_t = 1.0f / p.kv_scale;
+    if constexpr (I8) {                           // (256 threads: one code each, both tables; the barrier below covers it)
+        const float d = r16((float)(int)(int8_t)(tid & 255) * t_dq);
+        s_lut[tid & 255] = r16(d * ATTN_SCALE);
+        s_lut[256 + (tid & 255)] = d;
+    }
     const size_t sstride = p.part_sstride ? (size_t)p.part_sstride : (size_t)p.B * p.L * p.ldp;
 
     // ---- this call's q, k, v for the head (wave 0; lane = head dim): slabs summed, bias, fp16; cache append -------------------
@@ -394,8 +403,7 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
                             const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
-                                const int8_t q8 = (int8_t)((ws[e >> 2] >> (8 * (e & 3))) & 0xff);
-                                const float kd = r16(r16((float)q8 * t_dq) * ATTN_SCALE);
+                                const float kd = s_lut[(ws[e >> 2] >> (8 * (e & 3))) & 0xff];      // = r16(r16((float)code * t_dq) * ATTN_SCALE)
                                 acc = fmaf((float)s_q[c * 16 + e], kd, acc);
                             }
                         } else {
@@ -438,10 +446,8 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
             if (I8) {
                 const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                for (int d = 0; d < 16; ++d) {
-                    const int8_t q8 = (int8_t)((ws[d >> 2] >> (8 * (d & 3))) & 0xff);
-                    o[d] = fmaf(pj, r16((float)q8 * t_dq), o[d]);
-                }
+                for (int d = 0; d < 16; ++d)
+                    o[d] = fmaf(pj, s_lut[256 + ((ws[d >> 2] >> (8 * (d & 3))) & 0xff)], o[d]);      // = r16((float)code * t_dq)
             } else {
                 const half8v wh = __builtin_bit_cast(half8v, w);
 #pragma unroll
