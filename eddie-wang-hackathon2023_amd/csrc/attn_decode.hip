@@ -848,17 +848,22 @@ __global__ __launch_bounds__(256) void attn_cross_kernel(AttnCrossParams p) {
     };
     pipeline(bufA, bufB, nb, fetch2, consume2);
     // reduce over the row-lanes sharing a column group (lane bits above log2(LPR)), then over the 4 waves
+    static_assert(DPL % 8 == 0, "the cross-row steps take eight values at a time");
 #pragma unroll
-    for (int i = 0; i < L; ++i)
+    for (int i = 0; i < L; ++i) {
 #pragma unroll
         for (int e = 0; e < DPL; ++e) {
             float v = o[i][e];
             if constexpr (LPR == 4) v += __shfl_xor(v, 4);          // (int8 K/V only: no ALU-side exchange reaches lane ^ 4 exactly)
             v += wave_dpp<0x128>(v);                                // lane ^ 8: row_ror:8 inside a row of 16 lanes
-            v = wave_add_xor16(v);                                  // lane ^ 16, lane ^ 32: permlane swaps (common.h) -- no LDS round trips,
-            v = wave_add_xor32(v);                                  // the same pairs and order as the __shfl_xor loop this replaces
             o[i][e] = v;
         }
+#pragma unroll
+        for (int e0 = 0; e0 < DPL; e0 += 8) {                       // lane ^ 16, lane ^ 32: permlane swaps, eight values per step (common.h:
+            wave_add_xor16_x8_nomfma(&o[i][e0]);                    // no LDS round trips; the same pairs and order as the __shfl_xor loop
+            wave_add_xor32_x8_nomfma(&o[i][e0]);                    // this replaces -- and as the single steps did until round 5)
+        }
+    }
     if (rowi == 0) {
 #pragma unroll
         for (int i = 0; i < L; ++i)

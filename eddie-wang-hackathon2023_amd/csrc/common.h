@@ -136,6 +136,29 @@ __device__ __forceinline__ float wave_sum_pre_mfma(float v) {
     return v;
 }
 __device__ __forceinline__ float wave_sum_nomfma(float v) { return wave_sum_pre_mfma(v); }     // kernels without matrix instructions
+// EIGHT values at a time through one cross-row step (own + partner of lane ^ 16 | lane ^ 32), for waves with no matrix instruction
+// in flight: the eight moves, ONE pair of wait states, the eight swaps, one more pair -- instead of eight guarded single steps
+// (wave_add_xor16: 19 + 4 wait states and a dependent move / swap / add each; volatile assembly statements keep their order, so
+// eight of them never interleave).  Per value the same two operands are added in the same order: bit-identical.  The per-item tail
+// of the decode cross-attention -- 8 or 16 partial sums per lane through two such steps -- took 0.78 us of the one-launch step's
+// cross-attention stage with the single steps (scripts/lab/chain_stamps.py, profiles/r5q_*).
+#define WM_X8_STEP(SWAP)                                                                                                         \
+    int x0 = __builtin_bit_cast(int, v[0]), x1 = __builtin_bit_cast(int, v[1]), x2 = __builtin_bit_cast(int, v[2]),              \
+        x3 = __builtin_bit_cast(int, v[3]), x4 = __builtin_bit_cast(int, v[4]), x5 = __builtin_bit_cast(int, v[5]),              \
+        x6 = __builtin_bit_cast(int, v[6]), x7 = __builtin_bit_cast(int, v[7]), y0, y1, y2, y3, y4, y5, y6, y7;                  \
+    asm volatile("v_mov_b32 %8, %0\n\tv_mov_b32 %9, %1\n\tv_mov_b32 %10, %2\n\tv_mov_b32 %11, %3\n\t"                            \
+                 "v_mov_b32 %12, %4\n\tv_mov_b32 %13, %5\n\tv_mov_b32 %14, %6\n\tv_mov_b32 %15, %7\n\ts_nop 1\n\t"                   \
+                 SWAP " %0, %8\n\t" SWAP " %1, %9\n\t" SWAP " %2, %10\n\t" SWAP " %3, %11\n\t"                                    \
+                 SWAP " %4, %12\n\t" SWAP " %5, %13\n\t" SWAP " %6, %14\n\t" SWAP " %7, %15\n\ts_nop 1"                            \
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7),                               \
+                   "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(y4), "=&v"(y5), "=&v"(y6), "=&v"(y7));                      \
+    v[0] = __builtin_bit_cast(float, x0) + __builtin_bit_cast(float, y0); v[1] = __builtin_bit_cast(float, x1) + __builtin_bit_cast(float, y1);   \
+    v[2] = __builtin_bit_cast(float, x2) + __builtin_bit_cast(float, y2); v[3] = __builtin_bit_cast(float, x3) + __builtin_bit_cast(float, y3);   \
+    v[4] = __builtin_bit_cast(float, x4) + __builtin_bit_cast(float, y4); v[5] = __builtin_bit_cast(float, x5) + __builtin_bit_cast(float, y5);   \
+    v[6] = __builtin_bit_cast(float, x6) + __builtin_bit_cast(float, y6); v[7] = __builtin_bit_cast(float, x7) + __builtin_bit_cast(float, y7);
+__device__ __forceinline__ void wave_add_xor16_x8_nomfma(float* v) { WM_X8_STEP("v_permlane16_swap_b32") }
+__device__ __forceinline__ void wave_add_xor32_x8_nomfma(float* v) { WM_X8_STEP("v_permlane32_swap_b32") }
+#undef WM_X8_STEP
 __device__ __forceinline__ float wave_max_nomfma(float v) {
     int x = __builtin_bit_cast(int, v), y;
     asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "=&v"(y));

@@ -574,13 +574,9 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
             }
         }
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) {
-            float v = o[e];
-            v += wave_dpp<0x128>(v);
-            v = wave_add_xor16(v);
-            v = wave_add_xor32(v);
-            o[e] = v;
-        }
+        for (int e = 0; e < DPL; ++e) o[e] += wave_dpp<0x128>(o[e]);
+        wave_add_xor16_x8_nomfma(o);                               // (attn_cross_kernel's steps, eight values at a time: no matrix instruction
+        wave_add_xor32_x8_nomfma(o);                               // of this wave is in flight here -- its last Linear stage ended microseconds ago)
         if (rowi == 0) {
 #pragma unroll
             for (int e = 0; e < DPL; ++e) s_o[wid][sub * DPL + e] = o[e];

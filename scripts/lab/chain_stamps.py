@@ -24,37 +24,48 @@ __device__ unsigned long long g_stamps2[64 * 8 * 8];
 // directly would be waited for (its acknowledgement, ~ 2 us) at the next workgroup barrier and measure mostly itself.
 __shared__ unsigned long long s_stamps[32 + 64];
 __shared__ int s_stamp_layer;
+__shared__ int s_cur_stage;
 __shared__ unsigned long long s_arrive[8];
 extern "C" int wm_lab_chain_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps2), sizeof(g_stamps2)); }
 #define STAMP_ON (threadIdx.x == 0 && blockIdx.x == WM_STAMP_WG)
 #define STAMP(k) do { if (STAMP_ON) s_stamps[k] = wall_clock64(); } while (0)
-#define STAMP2(k) do { if (STAMP_ON) s_stamps[32 + s * 8 + (k)] = wall_clock64(); } while (0)
+#define STAMP2(k) do { if (STAMP_ON) s_stamps[32 + s_cur_stage * 8 + (k)] = wall_clock64(); } while (0)
 #define STAMP_FLUSH(layer) do { if (STAMP_ON) { const int pl = s_stamp_layer; if (pl >= 0 && pl < 64) { for (int i_ = 0; i_ < 32; ++i_) g_stamps[pl * 32 + i_] = s_stamps[i_]; \\
     for (int i_ = 0; i_ < 64; ++i_) g_stamps2[pl * 64 + i_] = s_stamps[32 + i_]; } for (int i_ = 0; i_ < 96; ++i_) s_stamps[i_] = 0; s_stamp_layer = (layer); } } while (0)
 // Where a stage without LayerNorm takes its input row from (wave-uniform):''', 1)
     s = ins_before(s, '    // ---- 1. every weight tile', '    STAMP2(0);\n')
-    s = ins_after(s, '                ok = sweep_granules16<2 * XP>(p.gran_x, first, epoch - 1, val, p.err, lane);\n', '                STAMP2(1);\n')
+    s = ins_after(s, '        ok = sweep_granules16<2 * XP>(gx, first, tag, val, p.err, lane);\n', '        STAMP2(1);\n')
     s = ins_after(s, '        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave\'s LDS writes before its reads\n', '        STAMP2(1);\n')
     s = ins_before(s, '    // ---- 3. multiply', '    STAMP2(2);\n')
     s = ins_before(s, '    // ---- 4. epilogue', '    STAMP2(3);\n')
     s = ins_before(s, '    if (st.mode == 2) own_valid = true;\n    __syncthreads();                                          // s_red / s_in', '    STAMP2(4);\n')
-    s = ins_after(s, '        const unsigned epoch0 = (gen << 10) | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);\n',
+    s = ins_after(s, '        const unsigned epoch0 = gen | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);\n',
                   '        STAMP_FLUSH(whole ? l : p.launch_id);\n        STAMP(0);\n')
     s = ins_before(s, '        const int s_first = l < 0 ? 5 : 0;', '        STAMP(7);\n')
     s = ins_before(s, '    bool own_valid = false, x_in_granules = false;\n    for (int l = whole ? -1 : 0;', '    if (STAMP_ON) s_stamp_layer = -1;\n')
     s = ins_after(s, '            if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch\'s granules\n', '            STAMP(1 + s);\n')
     s = ins_before(s, '                // the NEXT layer\'s K / V rows set out now', '                STAMP(8);\n')
-    s = ins_before(s, '            if (wide) chain_stage<WB, true, false>(p, st, s, epoch, own_valid', '            if (s == p.merge_at) STAMP(9);\n')
-    a, b = s.index('__device__ __forceinline__ void chain_cross_stage('), s.index('__device__ __forceinline__ void chain_merge_tagged(')
+    s = ins_before(s, '            if (wide) chain_stage<WB, true, false, NR>(p, st, s, epoch, own_valid', '            if (STAMP_ON) s_cur_stage = s;\n')
+    s = ins_after(s, '        chain_merge_tagged<NR>(p, tag, s_in);\n', '        STAMP(9);\n')           # (the merge runs inside the stage since round 5)
+    a = s.index('__device__ __forceinline__ void chain_cross_stage(')
+    b = s.index('__device__ __forceinline__ void chain_merge_tagged(', a)
     body = s[a:b]
     for tag, k in (('(A) rows and q sums are in LDS', 11), ('(B)', 12), ('(C)', 13), ('(D)', 14)):
         line = [l for l in body.splitlines(True) if l.strip().startswith('__syncthreads();') and l.rstrip().endswith('// ' + tag)]
         assert len(line) == 1, tag
         body = body.replace(line[0], ('    STAMP(10);\n' if k == 11 else '') + line[0] + f'    STAMP({k});\n', 1)
+    # finer: inside P.V (15: rows and probabilities read, products added; 23: the cross-lane sums done)
+    m1 = '#pragma unroll\n        for (int e = 0; e < DPL; ++e) o[e] += wave_dpp<0x128>(o[e]);'
+    assert body.count(m1) == 1
+    body = body.replace(m1, '        STAMP(15);\n' + m1, 1)
+    m2 = '        if (rowi == 0) {\n#pragma unroll\n            for (int e = 0; e < DPL; ++e) s_o[wid][sub * DPL + e] = o[e];'
+    assert body.count(m2) == 1
+    body = body.replace(m2, '        STAMP(23);\n' + m2, 1)
     s = s[:a] + body + s[b:]
-    a, b = s.index('__device__ __forceinline__ void chain_self_stage('), s.index('template <int WB, bool I8KV>\n__global__ __launch_bounds__(512) void gemv_chain_kernel')
-    body = s[a:b].replace('        q = r16(q + bq);', '        STAMP(17);\n        q = r16(q + bq);', 1)
+    a, b = s.index('__device__ __forceinline__ void chain_self_stage('), s.index('template <int WB, bool I8KV, int NR>\n__global__ __launch_bounds__(512) void gemv_chain_kernel')
+    body = s[a:b].replace('        q = r16(q + (la.self_bias ? (float)bq_raw : 0.f));', '        STAMP(17);\n        q = r16(q + (la.self_bias ? (float)bq_raw : 0.f));', 1)
+    assert 'STAMP(17)' in body
     parts = body.split('    __syncthreads();\n')
     assert len(parts) == 7, len(parts)
     body = (parts[0] + '    STAMP(18);\n    if (blockIdx.x == WM_STAMP_WG && lane == 0) s_arrive[wid] = wall_clock64();\n    __syncthreads();\n    STAMP(19);\n    if (STAMP_ON) for (int w_ = 0; w_ < 8; ++w_) s_stamps[24 + w_] = s_arrive[w_];\n' + parts[1] + '    __syncthreads();\n' + parts[2] + '    __syncthreads();\n' + parts[3]
@@ -65,7 +76,7 @@ extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipM
     out = os.path.join(ROOT, "build/lab")
     os.makedirs(out, exist_ok=True)
     open(os.path.join(out, "gemv_chain_stamps.hip"), "w").write(s)
-    for wg in (0, 160, 200):
+    for wg in (0, 160, 200, 60, 120):       # 0: owner of output groups; one row: 160 self-attention, 200 cross-attention; two rows: 60 self-, 120 cross-attention
         env = dict(os.environ, SRC=os.path.join(out, "gemv_chain_stamps.hip"))
         r = subprocess.run([os.path.join(ROOT, "scripts/lab/build_variant.sh"), f"stamps{wg}", "gemv_chain.hip", f"-DWM_STAMP_WG={wg}"], env=env, stdout=subprocess.PIPE, text=True)
         print(r.stdout.strip().splitlines()[-1])
@@ -83,6 +94,7 @@ def read():
     from oracle.whisper_oracle import Dims, synthetic_mel
     lib = native.load_library()
     model = "large-v2"
+    n_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dims = Dims(**synthetic.DIMS[model])
     sys.argv = ["bench.py", "--model", model]
     args = bench.parse()
@@ -92,7 +104,7 @@ def read():
         bench.build_engines(args, eng_dir)
     enc, dec = WhisperEncoding(eng_dir), WhisperDecoding(eng_dir)
     dec.sample_len = 40
-    xa = enc.get_audio_features(synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    xa = enc.get_audio_features(synthetic_mel(n_rows, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
     dec.detect_language(xa)
     for _ in range(3):
         dec.main_loop(xa, ignore_eot=True)
@@ -106,7 +118,7 @@ def read():
     nx = np.array([st[i + 1][0] for i in range(1, L - 2)], dtype=np.float64) / 100.0
     cols = [("self-attention (from layer start)", 7, 0), ("out", 1, 7), ("cq", 2, 1), ("cross-attention", 8, 2), ("merge of the pieces", 9, 8), ("cout", 3, 9),
             ("mlp1", 4, 3), ("mlp2", 5, 4), ("qkv of the next layer", 6, 5)]
-    print(f"library {os.environ.get('WM_LIBRARY_PATH')}: one workgroup's view, us per layer (mean over layers 1..{L - 3} of the last step at {dec.sample_len} tokens)")
+    print(f"library {os.environ.get('WM_LIBRARY_PATH')}, {n_rows} row(s): one workgroup's view, us per layer (mean over layers 1..{L - 3} of the last step at {dec.sample_len} tokens)")
     tot = 0.0
     for name, hi, lo in cols:
         d = x[:, hi] - x[:, lo]
@@ -130,6 +142,9 @@ def read():
     if st[1, 14] > st[1, 10] > 0:
         print("  cross-attention stage: cq end -> q swept %.2f | scores %.2f | max / exp / sum %.2f | P.V %.2f | sums + publish %.2f" % (
             np.mean(x[:, 11] - x[:, 2]), np.mean(x[:, 12] - x[:, 11]), np.mean(x[:, 13] - x[:, 12]), np.mean(x[:, 14] - x[:, 13]), np.mean(x[:, 8] - x[:, 14])))
+        if st[1, 23] > st[1, 15] > 0:
+            print("    inside P.V: barrier (C) -> rows read and products added %.2f | cross-lane sums %.2f | LDS write + barrier (D) %.2f" % (
+                np.mean(x[:, 15] - x[:, 13]), np.mean(x[:, 23] - x[:, 15]), np.mean(x[:, 14] - x[:, 23])))
     if st[1, 22] > st[1, 16] > 0:
         print("  self-attention stage: table / address prologue %.2f | wait for the qkv sums %.2f | q, k, v formed %.2f | first barrier %.2f | scores + softmax (2 barriers) %.2f | P.V %.2f | sums + publish %.2f" % (
             np.mean(x[:, 16] - x[:, 0]), np.mean(x[:, 17] - x[:, 16]), np.mean(x[:, 18] - x[:, 17]), np.mean(x[:, 19] - x[:, 18]), np.mean(x[:, 20] - x[:, 19]),
