@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
     // int8 cache: what a cached code contributes depends on the code and the layer's scale only (r16(r16(code t) SCALE) to a score,
     // r16(code t) to P.V): 2 x 256 values, computed once per launch and looked up -- the same bits as evaluating the expression per
     // element (seven vector instructions each, ~ a microsecond of a one-wave-per-64-keys score pass; csrc/gemv_chain.hip does the same)
-    __shared__ float s_lut[I8 ? 512 : 1];
+    __shared__ float s_lut[I8 ? 512 + MAX_L * 64 : 1];      // ... and behind them the 64 score factors r16(k * SCALE) of each NEW key
 
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int b = blockIdx.y;
@@ -360,6 +360,7 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
             }
             s_knew[i][lane] = (h16)k;
             s_vnew[i][lane] = (h16)v;
+            if constexpr (I8) s_lut[512 + i * 64 + lane] = r16(k * ATTN_SCALE);      // (k is an fp16 value already)
             const size_t off_k = (size_t)b * p.present_bstride + ((size_t)(0 * p.H + h) * p.present_cap + T + i) * 64 + lane;
             const size_t off_v = (size_t)b * p.present_bstride + ((size_t)(1 * p.H + h) * p.present_cap + T + i) * 64 + lane;
             if (I8) {
@@ -393,29 +394,32 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
             const int j = kb * 64 + lane;
             float sc = -INFINITY;
             if (j < nk) {
+                // ONE chain of 64 products per key, cached or new: a new key's lane (j >= T) takes its factors from the values wave 0 left
+                // behind the tables (int8) / from the new row in LDS (fp16) by a per-lane select -- as a branch of its own its 64 products
+                // were a second pass behind the cached keys' for a handful of lanes.  Same factors, same order of additions.
                 float acc = 0.f;
-                if (j < T) {
-                    const uint4* kr = (const uint4*)(pastK + (size_t)j * ROW_B);
+                const bool cached = j < T;
+                const int jn = cached ? 0 : j - T;
+                const uint4* kr = (const uint4*)(pastK + (size_t)min(j, max(T - 1, 0)) * ROW_B);
 #pragma unroll
-                    for (int c = 0; c < KCH; ++c) {
-                        const uint4 w = kb == wid ? kpre[c] : kr[c];
-                        if (I8) {
-                            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+                for (int c = 0; c < KCH; ++c) {
+                    const uint4 w = (kb == wid && T > 0) ? kpre[c] : kr[c];
+                    if (I8) {
+                        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const float kd = s_lut[(ws[e >> 2] >> (8 * (e & 3))) & 0xff];      // = r16(r16((float)code * t_dq) * ATTN_SCALE)
-                                acc = fmaf((float)s_q[c * 16 + e], kd, acc);
-                            }
-                        } else {
-                            const half8v wh = __builtin_bit_cast(half8v, w);
+                        for (int e = 0; e < 16; ++e) {
+                            const int idx = cached ? (int)((ws[e >> 2] >> (8 * (e & 3))) & 0xff) : 512 + jn * 64 + c * 16 + e;
+                            acc = fmaf((float)s_q[c * 16 + e], s_lut[idx], acc);      // r16(r16((float)code * t_dq) * ATTN_SCALE) | r16(k_new * ATTN_SCALE)
+                        }
+                    } else {
+                        const half8v wh = __builtin_bit_cast(half8v, w);
+                        const half8v kn8 = *(const half8v*)(&s_knew[jn][c * 8]);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) acc = fmaf((float)s_q[c * 8 + e], r16((float)wh[e] * ATTN_SCALE), acc);
+                        for (int e = 0; e < 8; ++e) {
+                            const float xk = cached ? (float)wh[e] : (float)kn8[e];
+                            acc = fmaf((float)s_q[c * 8 + e], r16(xk * ATTN_SCALE), acc);
                         }
                     }
-                } else {
-                    const h16* kn = s_knew[j - T];
-#pragma unroll 8
-                    for (int e = 0; e < 64; ++e) acc = fmaf((float)s_q[e], r16((float)kn[e] * ATTN_SCALE), acc);
                 }
                 sc = r16(f32_as_is(acc));
                 s_p[j] = sc;

@@ -747,6 +747,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
         v = r16(v + (la.self_bias ? (float)bv_raw : 0.f));
         s_knew[lane] = (h16)k;
         s_vnew[lane] = (h16)v;
+        if constexpr (I8) s_lut[512 + lane] = r16(k * SCALE);      // the new key's 64 score factors (k is an fp16 value already)
         k_new = k; v_new = v;                         // (the cache append waits for the end of the stage: see there)
         s_q[lane] = (h16)r16(q * SCALE);
     }
@@ -756,10 +757,14 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     const int nk = T + 1;
     float mx = -INFINITY;
     if (worker) {
+        // (q stays in LDS: one broadcast read per product.  The head's 64 q values in registers, read once, made the score pass 1.8 ->
+        // 2.75 us -- profiles/r5t_*)
         for (int kb = wid; kb * 64 < nk; kb += NW) {
             const int j = kb * 64 + lane;
             float sc = -INFINITY;
             if (j < nk) {
+                // (tried in round 5: ONE chain for cached and new keys, the new key's lane selecting its factors per element instead of
+                // running a branch of its own -- faster in attn_self_wg_kernel, 0.5 us SLOWER here (profiles/r5s_*): kept as two branches)
                 float acc = 0.f;
                 if (j < T) {
                     const uint4* kr = (const uint4*)(pastK + (size_t)j * ROW_B);
@@ -780,9 +785,14 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
                         }
                     }
                 } else {
-                    const h16* kn = s_knew;
+                    if constexpr (I8) {                       // the new key: its 64 factors r16(k * SCALE) wait behind the tables
 #pragma unroll 8
-                    for (int e = 0; e < 64; ++e) acc = fmaf((float)s_q[e], r16((float)kn[e] * SCALE), acc);
+                        for (int e = 0; e < 64; ++e) acc = fmaf((float)s_q[e], s_lut[512 + e], acc);
+                    } else {
+                        const h16* kn = s_knew;
+#pragma unroll 8
+                        for (int e = 0; e < 64; ++e) acc = fmaf((float)s_q[e], r16((float)kn[e] * SCALE), acc);
+                    }
                 }
                 sc = r16(f32_as_is(acc));
                 s_p[j] = sc;
@@ -841,10 +851,18 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
     __syncthreads();
     if (wid == 0) {
         const int ch = lane / DIMS, d = lane % DIMS;
-        float acc = 0.f;
+        // (the NW x VROWS partial sums are READ first, all of them in flight, and added afterwards in attn_self_wg_kernel's (wave, row) order:
+        // read and added one by one they were 64 dependent LDS round trips, most of the stage's last 1.2 us)
+        float part[NW][VROWS];
+#pragma unroll
         for (int w = 0; w < NW; ++w)
 #pragma unroll
-            for (int r = 0; r < VROWS; ++r) acc += s_o_flat[(w * 64 + r * NCH + ch) * (DIMS + 1) + d];
+            for (int r = 0; r < VROWS; ++r) part[w][r] = s_o_flat[(w * 64 + r * NCH + ch) * (DIMS + 1) + d];
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int r = 0; r < VROWS; ++r) acc += part[w][r];
         for (int j = T; j < nk; ++j) acc = fmaf(s_p[j], (float)s_vnew[lane], acc);
         const h16 out = (h16)f32_as_is(acc);
         if (p.self_out) p.self_out[urow * C + h * 64 + lane] = out;      // (plain copy: tests)
@@ -934,7 +952,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
             float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
             float* s_o_flat = (float*)&s_in[0][0];
-            float* s_lut = &s_red[4][0][0];                 // 2 x 256 floats (s_red[4], s_red[5])
+            float* s_lut = &s_red[4][0][0];                 // 2 x 256 floats + the new key's 64 (s_red[4] .. s_red[6])
             const unsigned tag_s = (gen | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
             chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, self_h, self_r, s_p, s_new, s_r2, s_o_flat, s_lut, kv_lds, self_v_off);
             // the NEXT layer's cached rows set out now (the stage's last barrier is behind every read of this layer's)

@@ -68,7 +68,7 @@ extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipM
     assert 'STAMP(17)' in body
     parts = body.split('    __syncthreads();\n')
     assert len(parts) == 7, len(parts)
-    body = (parts[0] + '    STAMP(18);\n    if (blockIdx.x == WM_STAMP_WG && lane == 0) s_arrive[wid] = wall_clock64();\n    __syncthreads();\n    STAMP(19);\n    if (STAMP_ON) for (int w_ = 0; w_ < 8; ++w_) s_stamps[24 + w_] = s_arrive[w_];\n' + parts[1] + '    __syncthreads();\n' + parts[2] + '    __syncthreads();\n' + parts[3]
+    body = (parts[0] + '    STAMP(18);\n    if (blockIdx.x == WM_STAMP_WG && lane == 0) s_arrive[wid] = wall_clock64();\n    __syncthreads();\n    STAMP(19);\n    if (STAMP_ON) for (int w_ = 0; w_ < 8; ++w_) s_stamps[24 + w_] = s_arrive[w_];\n' + parts[1] + '    STAMP(15);\n    __syncthreads();\n' + parts[2] + '    __syncthreads();\n    STAMP(23);\n' + parts[3]
             + '    __syncthreads();\n    STAMP(20);\n' + parts[4] + '    __syncthreads();\n    STAMP(21);\n' + parts[5] + '    STAMP(22);\n    __syncthreads();\n' + parts[6])
     body = body.replace('    const float t_dq = la.self_kv_scale;', '    STAMP(16);\n    const float t_dq = la.self_kv_scale;', 1)
     s = s[:a] + body + s[b:]
@@ -149,6 +149,9 @@ def read():
         print("  self-attention stage: table / address prologue %.2f | wait for the qkv sums %.2f | q, k, v formed %.2f | first barrier %.2f | scores + softmax (2 barriers) %.2f | P.V %.2f | sums + publish %.2f" % (
             np.mean(x[:, 16] - x[:, 0]), np.mean(x[:, 17] - x[:, 16]), np.mean(x[:, 18] - x[:, 17]), np.mean(x[:, 19] - x[:, 18]), np.mean(x[:, 20] - x[:, 19]),
             np.mean(x[:, 21] - x[:, 20]), np.mean(x[:, 22] - x[:, 21])))
+        if st[1, 23] > st[1, 15] > 0:
+            print("    inside scores + softmax: scores of wave 0 (to its arrival at barrier 2) %.2f | barrier 2 + exponentials + sum + barrier 3 %.2f | normalise + barrier 4 %.2f" % (
+                np.mean(x[:, 15] - x[:, 19]), np.mean(x[:, 23] - x[:, 15]), np.mean(x[:, 20] - x[:, 23])))
         print("    arrival of waves 0..7 at the stage's first barrier, us after (negative: before) wave 0 starts the layer:", " ".join("%.2f" % np.mean(x[:, 24 + w] - x[:, 0]) for w in range(8)), "| released %.2f" % np.mean(x[:, 19] - x[:, 0]))
 
 
