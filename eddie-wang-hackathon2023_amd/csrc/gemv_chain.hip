@@ -350,12 +350,19 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     // ---- 4. epilogue of the slot (its wave 0; row 0 sits in the lanes of the first 16-lane group): gemv_small's, the result
     // published as granules for the stages behind it ------------------------------------------------------------------------
     if (wslot == 0 && has_group) {
-        float4v sum = *(const float4v*)&s_red[(WIDE ? 0 : 4 * slot)][lane][0];
-        for (int w = 1; w < slices; ++w) {
-            const float4v tw = *(const float4v*)&s_red[(WIDE ? 0 : 4 * slot) + w][lane][0];
+        // (the slices' sums are READ first -- all in flight -- and added afterwards in slice order: read and added one by one they were up to
+        // sixteen dependent LDS round trips: the wide stage's epilogue 0.85 -> 0.66 us, profiles/r5v_*)
+        constexpr int MAXS = WIDE ? 16 : 4;
+        float4v part[MAXS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum[r] += tw[r];
-        }
+        for (int w = 0; w < MAXS; ++w) part[w] = *(const float4v*)&s_red[(WIDE ? 0 : 4 * slot) + (w < slices ? w : 0)][lane][0];
+        float4v sum = part[0];
+#pragma unroll
+        for (int w = 1; w < MAXS; ++w)
+            if (w < slices) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] += part[w][r];
+            }
         const float bias = has_bias ? (float)bias_raw : 0.f;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -493,6 +500,8 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
         // ---- pass 1: scores -- a key's score is its own (no sum across keys), so ALL EIGHT waves take part: wave w scores the rows
         // attn_cross_kernel's wave w & 3 scores, in the iterations k with k & 1 == w >> 2 (the upper four waves have nothing else to
         // do once their K / V rows have landed).  The rows of two iterations are read from LDS before the first is used. ----------
+        // (tried in round 5: units of 8 rows dealt evenly over the eight waves -- six each instead of eight on waves 0-3 and four on waves
+        // 4-7 -- with a wave's six rows read together: the pass took 1.50 instead of 1.36 us, profiles/r5v_*; not kept)
         const int half = wid >> 2;
         for (int k0 = half; k0 < nb; k0 += 2 * KB2) {
             half8v hv[KB2][UNR];
