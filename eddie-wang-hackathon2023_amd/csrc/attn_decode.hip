@@ -472,10 +472,17 @@ __global__ __launch_bounds__(64 * SELF_WAVES) void attn_self_wg_kernel(AttnSelfP
         __syncthreads();
         if (wid == 0) {                           // lane = head dim: chunk lane / DIMS of every (wave, row-in-block) partial sum
             const int ch = lane / DIMS, d = lane % DIMS;
-            float acc = 0.f;
+            // (the partial sums are READ first, all in flight, and added afterwards in (wave, row) order: csrc/gemv_chain.hip, profiles/r5u_*)
+            float part[SELF_WAVES][VROWS];
+#pragma unroll
             for (int w = 0; w < SELF_WAVES; ++w)
 #pragma unroll
-                for (int r = 0; r < VROWS; ++r) acc += s_o[w * 64 + r * NCH + ch][d];
+                for (int r = 0; r < VROWS; ++r) part[w][r] = s_o[w * 64 + r * NCH + ch][d];
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < SELF_WAVES; ++w)
+#pragma unroll
+                for (int r = 0; r < VROWS; ++r) acc += part[w][r];
             for (int j = T; j < nk; ++j) acc = fmaf(s_p[j], (float)s_vnew[j - T][lane], acc);
             p.out[(size_t)(b * p.L + i) * p.ldo + h * 64 + lane] = (h16)f32_as_is(acc);
         }

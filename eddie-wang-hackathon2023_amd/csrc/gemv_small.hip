@@ -226,11 +226,33 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void gemv_small_kernel(GemvSmallPa
     for (int mt = 0; mt < MT; ++mt) {
         float y[4];
         if (nwave > 1) {
-            float4v s = *(const float4v*)&s_red[0][mt][lane][0];
-            for (int w = 1; w < nwave; ++w) {
-                const float4v tw = *(const float4v*)&s_red[w][mt][lane][0];
+            // (the waves' sums are read FOUR at a time -- in flight together -- and added in wave order: read and added one by one they are up
+            // to sixteen dependent LDS round trips; four at a time keeps the kernel inside its 128 registers.  csrc/gemv_chain.hip's
+            // epilogue reads all of them at once, profiles/r5v_*)
+            float4v s;
+            if constexpr (WB == 4 || MT > 1) {                    // (the int4 and the two-row-tile forms have no registers to spare: one at a time)
+                s = *(const float4v*)&s_red[0][mt][lane][0];
+                for (int w = 1; w < nwave; ++w) {
+                    const float4v tw = *(const float4v*)&s_red[w][mt][lane][0];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[r] += tw[r];
+                    for (int r = 0; r < 4; ++r) s[r] += tw[r];
+                }
+            } else {
+                s = float4v{0.f, 0.f, 0.f, 0.f};
+                for (int w0 = 0; w0 < nwave; w0 += 4) {
+                    float4v part[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) part[k] = *(const float4v*)&s_red[w0 + k < nwave ? w0 + k : 0][mt][lane][0];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (w0 + k < nwave) {
+                            if (w0 + k == 0) s = part[0];
+                            else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) s[r] += part[k][r];
+                            }
+                        }
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = s[r];
