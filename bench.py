@@ -119,7 +119,7 @@ def cpu_baseline(args, decode_steps: int, time_cap_s: float = 150.0):
     encoder, cross K/V, language-ID pass, 3-token prefill and the greedy steps.  The decode loop is timed for as many
     of the `decode_steps` tokens as fit in the time cap (every step costs the same: the per-token time of the measured
     steps is applied to the rest, and `sample` says how many were measured).
-    Threads: a short sweep first (encoder once + 3 greedy steps at 16 / 32 / 64 / 128 threads, as far as the box has cores) picks
+    Threads: a short sweep first (encoder once + 3 greedy steps at 8 / 16 / 32 / 64 / 128 threads, as far as the box has cores) picks
     the count with the fastest whole clip (127 steps + encoder); the sweep is reported (`thread_sweep`), `cores` is what the timed
     clip used.  `tiny_en`: the same path for tiny.en's shape (BASELINE.json configs[0]), every step measured."""
     from oracle.whisper_oracle import Dims, OracleConfig, OracleModel
@@ -152,7 +152,7 @@ def cpu_baseline(args, decode_steps: int, time_cap_s: float = 150.0):
 
     dims, model, mel = build(args.model)
     sweep = {}
-    for n in (16, 32, 64, 128):
+    for n in (8, 16, 32, 64, 128):
         if n <= n_cpu:
             torch.set_num_threads(n)
             r = clip(dims, model, mel, 4, 0.0)

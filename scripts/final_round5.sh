@@ -27,6 +27,6 @@ s = d["second_figure"]; print({k: s[k] for k in ("ms_per_batch", "ms_per_batch_p
 print("cpu", {k: d["cpu_baseline"].get(k) for k in ("value", "cores", "thread_sweep", "tiny_en")})
 for b in (1, 2, 4, 8, 32):
     x = json.load(open(f"gpurun_out/r5z_bench_b{b}.json")); print("batch", b, x["roofline"]["decode_step_ms"], "ms per token,", x["value"], "tokens/s")
-f = json.load(open("gpurun_out/r5z_bench_force_dist.json")); print("force-dist", f["value"], f["n_gpus"])
+f = json.loads(open("gpurun_out/r5z_bench_force_dist.json").readline()); print("force-dist", f["value"], f["n_gpus"])
 PY
 head -4 gpurun_out/r5z_bench_kernel_stats.csv; cat gpurun_out/r5z_cross_attn_trace_hist.txt
