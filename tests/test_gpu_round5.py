@@ -510,3 +510,34 @@ def test_two_row_step_with_rows_that_finish_at_different_times(lib, tmpdir_modul
         assert torch.equal(t1[0].cpu(), t[b, :n]) and bool((t[b, n:] == eot).all())
         assert torch.equal(lp1[0].cpu(), outs[2][1][b])
         del solo
+
+
+def test_best_of_two_candidates_of_one_utterance_take_the_two_row_step(lib, tmpdir_module, chain_rearmed):
+    """`best_of = 2` on ONE utterance: two candidate rows that share the clip's audio (their own copies of its cross K/V) -- a group of
+    two rows, i.e. the two-row one-launch step with the draw inside the greedy kernel.  The run is repeatable under torch.manual_seed,
+    identical to the launch-per-kernel path (the draws are keyed on seed, global row, position and token: not on the decode form), the
+    candidates differ from each other, and the language pass and the loop share ONE buffer set (no re-allocation between them)."""
+    eng, dims = _small_engine(tmpdir_module, "micro-fullvocab", True, True)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(1, 2 * dims.n_audio_ctx, dims.n_mels, 79).cuda())
+    outs = {}
+    for mode in (0, 2):
+        lib.wm_set_decode_chain(mode)
+        dec = WhisperDecoding(eng, options=DecodingOptions(temperature=0.8, best_of=2, sample_len=10))
+        languages, _ = dec.detect_language(xa)
+        assert len(languages) == 1 and list(dec._state.keys()) == [2]            # the pass ran over the candidates' rows: the loop's buffer set
+        state = dec._state[2]
+        before = native.chain_status()["launches"]
+        torch.manual_seed(11)
+        t, lp, nsp = dec.main_loop(xa)
+        assert dec._state[2] is state and t.shape[0] == 2
+        assert (native.chain_status()["launches"] > before) == (mode > 0)
+        torch.manual_seed(11)
+        t_again, lp_again, _ = dec.main_loop(xa)
+        assert torch.equal(t.cpu(), t_again.cpu()) and torch.equal(lp.cpu(), lp_again.cpu())
+        res = dec.post_process(t, lp, nsp, xa, languages)
+        assert len(res) == 1 and np.isfinite(res[0].avg_logprob)
+        outs[mode] = (t.cpu(), lp.cpu())
+        del dec
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert not torch.equal(outs[2][0][0], outs[2][0][1])
