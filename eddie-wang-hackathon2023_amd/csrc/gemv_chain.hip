@@ -347,9 +347,10 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     }
     __syncthreads();
 
-    // ---- 4. epilogue of the slot (its wave 0; row 0 sits in the lanes of the first 16-lane group): gemv_small's, the result
-    // published as granules for the stages behind it ------------------------------------------------------------------------
-    if (wslot == 0 && has_group) {
+    // ---- 4. epilogue of the slot (row 0 sits in the lanes of the first 16-lane group, element 0 of the accumulator; row 1 in element
+    // 1): gemv_small's, the result published as granules for the stages behind it.  Wave r of the slot finishes row r: at two rows the
+    // epilogues run side by side (one wave doing both in turn cost the two-row step ~ 2 us per layer, profiles/r5q_*_b2) ---------------
+    if (wslot < NR && has_group) {
         // (the slices' sums are READ first -- all in flight -- and added afterwards in slice order: read and added one by one they were up to
         // sixteen dependent LDS round trips: the wide stage's epilogue 0.85 -> 0.66 us, profiles/r5v_*)
         constexpr int MAXS = WIDE ? 16 : 4;
@@ -364,9 +365,9 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
                 for (int r = 0; r < 4; ++r) sum[r] += part[w][r];
             }
         const float bias = has_bias ? (float)bias_raw : 0.f;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const float y = sum[r];                           // row r (lanes 0-15; element r of the accumulator); the other lanes hold rows that do not exist
+        {
+            const int r = NR == 1 ? 0 : wslot;                // (wave-uniform)
+            const float y = NR == 1 ? sum[0] : (wslot == 0 ? sum[0] : sum[1]);      // row r; the lanes beyond the first 16 hold rows that do not exist
             if (st.mode == 0) {
                 if (g == 0) {
                     p.out32[r * n_out + col] = y;             // raw sums for the attention kernel of the next launch
