@@ -73,7 +73,13 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
                          "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]), "+v"(val[12]), "+v"(val[13]), "+v"(val[14]), "+v"(val[15]),
                          "+v"(val[16]), "+v"(val[17]) :: "memory");
-        else static_assert(NL == 1 || NL == 3 || NL == 6 || NL == 18, "sweep sizes of the chain");
+        else if constexpr (NL == 9)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
+                         "+v"(val[8]) :: "memory");
+        else if constexpr (NL == 15)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
+                         "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]), "+v"(val[12]), "+v"(val[13]), "+v"(val[14]) :: "memory");
+        else static_assert(NL == 1 || NL == 3 || NL == 6 || NL == 9 || NL == 15 || NL == 18, "sweep sizes of the chain");
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) ok &= val[k].y == epoch && val[k].w == epoch;
@@ -608,31 +614,39 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
 template <int NR>
 __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, unsigned tag, h16 (*s_in)[CHAIN_MAX_IN + 8]) {
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int MH = 3;
-#pragma unroll
-  for (int row = 0; row < NR; ++row) {                        // (a row's heads as at one row; the rows one after the other)
-    const unsigned long long* gran_p = p.gran_p + (size_t)row * p.merge_heads * 66 * 4;
-    h16* s_row = &s_in[row][0];
-    for (int h0 = wid; h0 < p.merge_heads; h0 += 8 * MH) {
-        int first[6 * MH];
-        u32x4 val[6 * MH];
+    // The (row, head) pairs -- pair = row * heads + head: the pieces' granules of the rows lie back to back -- are dealt over the eight waves,
+    // MH per wave and pass: three at one row (20 heads), five at two rows (40 pairs): ONE pass either way (the rows one after the other cost
+    // the two-row step a second pass, ~ 1.2 us per layer).  Per pair a lane loads its own output value's four pieces (2 x 16 B) and ONE 16-byte
+    // chunk of the pair's eight (maximum, sum) values -- lanes 0-3 the four chunks, the others repeat them -- which are the same for every
+    // lane and read across the wave (v_readlane): 3 loads per pair instead of 6 (15 per pass at two rows; 30 spilled 164 bytes per lane).
+    constexpr int MH = NR == 1 ? 3 : 5;
+    const int n_pairs = NR * p.merge_heads;
+    for (int i0 = wid; i0 < n_pairs; i0 += 8 * MH) {
+        int first[3 * MH];
+        u32x4 val[3 * MH];
 #pragma unroll
         for (int u = 0; u < MH; ++u) {
-            const int h = min(h0 + 8 * u, p.merge_heads - 1);
-            first[6 * u + 0] = (h * 66 + 0) * 4; first[6 * u + 1] = (h * 66 + 0) * 4 + 2;
-            first[6 * u + 2] = (h * 66 + 1) * 4; first[6 * u + 3] = (h * 66 + 1) * 4 + 2;
-            first[6 * u + 4] = (h * 66 + 2 + lane) * 4; first[6 * u + 5] = (h * 66 + 2 + lane) * 4 + 2;
+            const int pr = min(i0 + 8 * u, n_pairs - 1);
+            first[3 * u + 0] = (pr * 66) * 4 + 2 * (lane & 3);       // granules 0-7 of the pair: m[4] | l[4], chunk lane & 3
+            first[3 * u + 1] = (pr * 66 + 2 + lane) * 4; first[3 * u + 2] = (pr * 66 + 2 + lane) * 4 + 2;
         }
-        if (!sweep_granules16<6 * MH>(gran_p, first, tag, val, p.err, lane)) break;
+        if (!sweep_granules16<3 * MH>(p.gran_p, first, tag, val, p.err, lane)) break;
 #pragma unroll
         for (int u = 0; u < MH; ++u) {
-            const int h = h0 + 8 * u;
-            if (h >= p.merge_heads) break;                            // wave-uniform
-            unsigned mb[4] = {val[6 * u + 0].x, val[6 * u + 0].z, val[6 * u + 1].x, val[6 * u + 1].z};
-            unsigned lb[4] = {val[6 * u + 2].x, val[6 * u + 2].z, val[6 * u + 3].x, val[6 * u + 3].z};
-            unsigned ob[4] = {val[6 * u + 4].x, val[6 * u + 4].z, val[6 * u + 5].x, val[6 * u + 5].z};
+            const int pr = i0 + 8 * u;
+            if (pr >= n_pairs) break;                                 // wave-uniform
+            const int row = NR == 1 ? 0 : pr / p.merge_heads, h = pr - row * p.merge_heads;
+            unsigned cx = val[3 * u].x, cz = val[3 * u].z;
+            asm volatile("" : "+v"(cx), "+v"(cz));
+            unsigned mb[4], lb[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(mb[q]), "+v"(lb[q]), "+v"(ob[q]));      // (see chain_cross_stage: pairs formed by the compiler from a granule load came out as (x, x))
+            for (int q = 0; q < 4; ++q) {                             // piece q: chunk q >> 1 (maxima) / 2 + (q >> 1) (sums), its first or second granule
+                mb[q] = (unsigned)__builtin_amdgcn_readlane((int)((q & 1) ? cz : cx), q >> 1);
+                lb[q] = (unsigned)__builtin_amdgcn_readlane((int)((q & 1) ? cz : cx), 2 + (q >> 1));
+            }
+            unsigned ob[4] = {val[3 * u + 1].x, val[3 * u + 1].z, val[3 * u + 2].x, val[3 * u + 2].z};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(ob[q]));      // (see chain_cross_stage: pairs formed by the compiler from a granule load came out as (x, x))
             float mq[4], lq[4], oq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { mq[q] = __builtin_bit_cast(float, mb[q]); lq[q] = __builtin_bit_cast(float, lb[q]); oq[q] = __builtin_bit_cast(float, ob[q]); }
@@ -644,10 +658,9 @@ __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, uns
                 den += mul_rn(lq[q], f);                              // (products of their own, as attn_cross_combine_kernel forms them: common.h)
                 num += mul_rn(oq[q], f);
             }
-            s_row[h * 64 + lane] = (h16)(num / den);
+            s_in[row][h * 64 + lane] = (h16)(num / den);
         }
     }
-  }
     __syncthreads();
 }
 
