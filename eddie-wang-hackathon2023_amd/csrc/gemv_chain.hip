@@ -67,6 +67,13 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
         for (int k = 0; k < NL; ++k)
             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(val[k]) : "v"(gran + first[k]) : "memory");
         if constexpr (NL == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]) :: "memory");
+        else if constexpr (NL == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]) :: "memory");
+        else if constexpr (NL == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]) :: "memory");
+        else if constexpr (NL == 8)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]) :: "memory");
+        else if constexpr (NL == 12)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
+                         "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]) :: "memory");
         else if constexpr (NL == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]) :: "memory");
         else if constexpr (NL == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]) :: "memory");
         else if constexpr (NL == 18)
@@ -79,7 +86,7 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
         else if constexpr (NL == 15)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
                          "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]), "+v"(val[12]), "+v"(val[13]), "+v"(val[14]) :: "memory");
-        else static_assert(NL == 1 || NL == 3 || NL == 6 || NL == 9 || NL == 15 || NL == 18, "sweep sizes of the chain");
+        else static_assert(NL == 1 || NL == 2 || NL == 3 || NL == 4 || NL == 6 || NL == 8 || NL == 9 || NL == 12 || NL == 15 || NL == 18, "sweep sizes of the chain");
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) ok &= val[k].y == epoch && val[k].w == epoch;
@@ -267,30 +274,39 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             }
         }
     } else {
-        // the hidden rows the previous stage has just published (mode 1): every wave sweeps the granules of ITS K slices into LDS
-        // (tps x KT halves per slice = 3 16-byte loads per lane and row at most, both rows in one pass) and reads its fragments
-        // back -- no barrier, its own data
+        // the hidden rows the previous stage has just published (mode 1): every wave sweeps the granules of ITS K slices into LDS and reads
+        // its fragments back -- no barrier, its own data.  ONE pass for all of the wave's slices and rows (round 5: the wide stage's two
+        // slices were two passes, a fabric round trip each: its input wait was 2.5 us against 1.1-1.5 for the other stages), and only as
+        // many 16-byte loads per slice and row as a slice can need (tps x KT halves: 2 for 8- and 16-bit weights, 3 for 4-bit; the third
+        // load of every pass re-read one granule 64 times)
+        constexpr int NLR = (TB * KT / 4 <= 128) ? 2 : 3;                     // loads per lane, slice and row
         const int in_stride = st.K >> 1;                                      // granules between the rows of the stage's input
+        int first[NS * NR * NLR];
+        u32x4 val[NS * NR * NLR];
+        int n_ld[NS];
+        bool any = false;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int n_in = (t_end[j] - t_begin[j]) * KT;                    // halves of this slice (0: absent)
             const int g0 = t_begin[j] * KT / 2;                               // first granule
-            const int n_ld = n_in / 4;                                        // 16-byte loads (4 halves each)
-            int first[3 * NR];
-            u32x4 val[3 * NR];
+            n_ld[j] = n_in / 4;                                               // 16-byte loads (4 halves each)
+            any |= n_ld[j] > 0;
 #pragma unroll
             for (int r = 0; r < NR; ++r)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) first[3 * r + k] = r * in_stride + g0 + 2 * min(lane + 64 * k, max(n_ld - 1, 0));
-            const bool ok = n_ld > 0 && sweep_granules16<3 * NR>(gran, first, tag, val, p.err, lane);
-            if (ok) {
+                for (int k = 0; k < NLR; ++k) first[(j * NR + r) * NLR + k] = r * in_stride + g0 + 2 * min(lane + 64 * k, max(n_ld[j] - 1, 0));
+        }
+        const bool ok = any && sweep_granules16<NS * NR * NLR>(gran, first, tag, val, p.err, lane);      // (an absent slice re-reads granules of the stage's first tile)
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
 #pragma unroll
                 for (int r = 0; r < NR; ++r)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        if (lane + 64 * k < n_ld)
-                            *(uint2*)(chain_in_row<NR, WIDE, false>(s_in, slot, r) + t_begin[j] * KT + (lane + 64 * k) * 4) = make_uint2(val[3 * r + k].x, val[3 * r + k].z);
-            }
+                    for (int k = 0; k < NLR; ++k)
+                        if (lane + 64 * k < n_ld[j])
+                            *(uint2*)(chain_in_row<NR, WIDE, false>(s_in, slot, r) + t_begin[j] * KT + (lane + 64 * k) * 4) =
+                                make_uint2(val[(j * NR + r) * NLR + k].x, val[(j * NR + r) * NLR + k].z);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave's LDS writes before its reads
 #pragma unroll
