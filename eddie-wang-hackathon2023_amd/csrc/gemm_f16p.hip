@@ -1,5 +1,5 @@
-// fp16 x fp16 -> fp16 GEMM for the compute-bound stages, round-2 structure: PERSISTENT workgroups walking over
-// 256 x 256 output tiles with one continuous operand stream.
+// fp16 x fp16 -> fp16 GEMM for the compute-bound stages: PERSISTENT workgroups walking over 256 x 256 output tiles with one
+// continuous operand stream (round 2), the stream in whole cache lines (round 5).
 //
 //   C = epilogue(A[M,K] . W[N,K]^T)      M = 1500 * batch rows, N % 256 == 0, K % 64 == 0
 //
@@ -13,28 +13,38 @@
 //   * one workgroup per CU lives for the whole launch and takes tiles from a static, XCD-aware list (each XCD owns a
 //     contiguous band of the tile list, its 32 workgroups work on 32 consecutive tiles: an A row panel is fetched from
 //     HBM once and re-used from that XCD's L2 by the N / 256 tiles of its row);
-//   * the operand stream is ONE sequence of 32-deep K stages (A 256 x 32 and W 256 x 32 halves = 32 KB) through a ring
-//     of 4 slots filled by global_load_lds (16 B per lane, 1 KiB per wave instruction).  The stream does not stop at
-//     a tile boundary: while a tile's last K steps and its epilogue run, the first stages of the NEXT tile are already
-//     in flight, so a tile never starts cold;
-//   * THE TWO WAVES OF A SIMD ALTERNATE.  A stage is multiplied in two halves of a wave's channels; each half is one
-//     "load" interval (fragments LDS -> registers, two DMA requests, the stage wait) and one "multiply" interval (16 MFMAs,
-//     nothing else), separated by raw s_barriers.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave
-//     multiplies while its partner loads, and the workgroup's barriers are the clock of that alternation;
-//   * waits are COUNTED: s_waitcnt vmcnt(6) -- everything but this wave's 6 youngest DMA pieces has landed -- once per
-//     stage, never 0 inside a tile; a stage is requested 7 intervals before its first read;
+//   * the operand stream is ONE sequence of 64-deep K SLOTS (A 256 x 64 and W 256 x 64 halves = 64 KB), two of them in LDS, filled
+//     by global_load_lds (16 B per lane, 1 KiB per wave instruction = 8 rows x 128 B: eight WHOLE cache lines).  The stream does
+//     not stop at a tile boundary: while a tile's last slot and its epilogue run, the first slot of the NEXT tile is already in
+//     LDS, so a tile never starts cold.
+//     (Rounds 2-4 streamed 32-deep stages through a ring of four: rows of 64 B, so every cache line of A and W was fetched as two
+//     half-line requests one stage apart.  The counters said what that costs -- one L2 request per 64 bytes, the CU's address unit
+//     busy 68 % of the launch, profiles/r5ai_gemm_l2_pmc -- and the skeleton ablation of round 4 had the symptom: taking the DMA
+//     requests out made the loop 20-30 % faster.  With whole lines per request: qkv 1147 -> 1190, mlp1 1030 -> 1066, mlp2 1148 ->
+//     1177 TFLOP/s at M = 384 000 on random data, interleaved rounds, bit-identical; out 990 either way: profiles/r5aj_*, r5ak_*.)
+//   * THE TWO WAVES OF A SIMD ALTERNATE.  A slot is multiplied as two steps of 32 K (the two 64-byte halves of its rows), a step
+//     in two halves of a wave's channels; each half is one "load" interval (fragments LDS -> registers, DMA requests or the slot
+//     wait) and one "multiply" interval (16 MFMAs, nothing else), separated by raw s_barriers.  Waves 4-7 run one barrier behind
+//     waves 0-3, so on every SIMD one wave multiplies while its partner loads, and the workgroup's barriers are the clock of that
+//     alternation;
+//   * slot g + 1 is requested while the FIRST step of slot g is multiplied (four pieces in each of its two load intervals -- all
+//     eight in the first measured 3-6 % slower, r5ak) into the slot that g - 1 has just left, and waited for (s_waitcnt vmcnt(0):
+//     nothing younger is in the queue) in the last load interval of slot g: six to eight intervals for the pieces to land;
 //   * the epilogue's stores are fire-and-forget: all its global loads (the residual rows) are requested before its first
-//     store, the bias is read from LDS (copied there once per launch), and the first stage wait of the next tile allows the
-//     32 stores to stay in flight on top of the 6 DMA pieces -- the next tile's K loop starts at once.
+//     store, the bias is read from LDS (copied there once per launch); the next tile's first slot is in LDS already and its second
+//     is requested behind the stores.  (Requesting it AHEAD of the epilogue's loads, so that the first wait of the next tile could
+//     leave the stores in flight by count as rounds 2-4 did, put eight DMA pieces in front of the residual rows: out 984 -> 960
+//     TFLOP/s, r5al; touching the residual lines a slot early, and an epilogue in two phases, lost too -- r5ak.)
 // Measured on MI355X, M = 192 000, random data, interleaved rounds in one process (scripts/lab/gemm_lab3.hip; results equal
-// the round-1 kernel's bit for bit): qkv (N 3840, K 1280, q/k scaling) 1008 vs 932 TFLOP/s, out (1280, 1280, residual)
-// 840 vs 764, mlp1 (5120, 1280, GELU) 839 vs 830, mlp2 (1280, 5120, residual) 1102 vs 1036; 8192 x 4096 x 4096: 1208 vs
-// 1122.  What did NOT help on the way (same harness): the deep ring alone, with both waves of a SIMD in step (one barrier
-// per stage, fragments software-pipelined through registers, 4 or 5 stages) was 4-8 % SLOWER than round 1 -- prefetch depth
-// was never the limit, the idle matrix pipe during the common load phase was.
-// LDS image of a stage: rows of 64 B (32 halves); the 16-byte chunk c of row r sits at position c ^ sw(r) with
-// sw(r) = (0, 3, 2, 1)[(r >> 2) & 3] -- applied to the per-lane SOURCE address, the DMA writes LDS linearly -- which makes
-// every ds_read_b128 fragment read (16 rows x one chunk per 16-lane group) conflict-free on the 64 banks.
+// the round-1 kernel's bit for bit), the 32-deep form of round 2: qkv (N 3840, K 1280, q/k scaling) 1008 vs 932 TFLOP/s, out
+// (1280, 1280, residual) 840 vs 764, mlp1 (5120, 1280, GELU) 839 vs 830, mlp2 (1280, 5120, residual) 1102 vs 1036; 8192 x 4096 x
+// 4096: 1208 vs 1122.  What did NOT help on the way (same harness): the deep ring alone, with both waves of a SIMD in step (one
+// barrier per stage, fragments software-pipelined through registers, 4 or 5 stages) was 4-8 % SLOWER than round 1 -- prefetch
+// depth was never the limit, the idle matrix pipe during the common load phase was.
+// LDS image of a slot: rows of 128 B (64 halves); the 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7) -- applied to
+// the per-lane SOURCE address, the DMA writes LDS linearly -- which makes every ds_read_b128 fragment read (16 rows x one chunk
+// per 16-lane group) conflict-free on the 64 banks: within each of the instruction's four lane groups the eight even rows and the
+// eight odd rows each meet eight different chunk positions.
 // MFMA operands are swapped (D = W . A^T) as in gemm_f16.hip: a lane ends up with 4 consecutive output channels of
 // one token row, so bias / GELU / residual / stores work on 8-byte pieces straight from the accumulator layout.
 #include <stdlib.h>
@@ -48,24 +58,18 @@
 namespace wm {
 
 namespace f16p {
-constexpr int BM = 256, BN = 256, BK = 32, NWAVE = 8;
-constexpr int A_PART = BM * BK * 2, STAGE = (BM + BN) * BK * 2;      // 16 KB + 16 KB
+constexpr int BM = 256, BN = 256, BK = 64, NWAVE = 8;         // BK: the depth of a SLOT (two MFMA steps of 32)
+constexpr int A_PART = BM * BK * 2, SLOT = (BM + BN) * BK * 2;       // 32 KB + 32 KB, rows of 128 bytes = whole cache lines
 
 constexpr int MAX_N = 8192;                                          // the bias vector sits in LDS behind the ring: 16 KB
 }  // namespace f16p
 
 // SIMPLE: plain row-major output and residual (the encoder layers' four GEMMs): the epilogue then carries none of the
 // strided-view / head-split / int8 address arithmetic (integer divisions, their branches) the general form is compiled with.
-template <int STAGES, int ACT, bool SIMPLE = false>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU
+template <int ACT, bool SIMPLE = false>      // ACT: 0 none, 1 erf-GELU, 2 tanh-GELU
 __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     using namespace f16p;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    constexpr int WAIT = 4 * STAGES - 10;            // DMA pieces of this wave that may still be in flight when stage s + 1 must have landed
-    // store instructions of one wave's epilogue, the number the first stage wait of the next tile may leave in flight ON TOP of the DMA
-    // pieces: 16 stores of 16 bytes in the SIMPLE form (4 row blocks x 4 block pairs), 32 of 8 bytes in the general one.  It must not
-    // exceed what the epilogue really issues: a larger count would let the wait pass with DMA pieces of the stage still in flight.
-    constexpr int N_STORES = SIMPLE ? 16 : 32;
-
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;           // 4 (M) x 2 (N) waves, each 64 rows x 128 channels
     const int g = lane >> 4;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     const int lo = min(n_tiles, xcd * band), hi = min(n_tiles, lo + band);
     const int my_tiles = (hi - lo - j0 + per_xcd - 1) > 0 ? (hi - lo - j0 + per_xcd - 1) / per_xcd : 0;
     if (my_tiles == 0) return;
-    const int nk = p.K / BK;                         // stages per tile
+    const int nk = p.K / BK;                         // slots per tile
     // Order of a band's tiles.  In plain row-major order the workgroups of an XCD, which march over K roughly in step, hold
     // ~32 / nt_n row panels against ALL nt_n channel tiles: each A panel is fetched once, but the whole weight matrix streams
     // through the XCD's 4 MB L2 once per row panel (N = 5120, K = 1280: 13 MB of W per 0.66 MB of A -- the kernel fetched 11x
@@ -99,19 +103,19 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         tm = row_first + sr * R + (rem - tn * rows_here);
     };
 
-    // ---- loader: per stage this wave requests 2 A pieces and 2 W pieces of 16 rows x 64 B, as two "halves" (one A and one
-    // W piece each).  Addresses are a wave-uniform base per tile (advanced by 64 B per stage) plus a 32-bit lane offset ---
-    const unsigned char* a_base = nullptr;           // row `row0` of the tile, at the stage's K offset
+    // ---- loader: per slot this wave requests 4 A pieces and 4 W pieces of 8 rows x 128 B -- every piece eight WHOLE cache lines.
+    // Addresses are a wave-uniform base per tile (advanced by 128 B per slot) plus a 32-bit lane offset; piece q of W lies 64 q rows
+    // behind piece 0 (a wave-uniform distance), the A pieces keep a lane offset each (the last row panel clamps its rows) -----------
+    const unsigned char* a_base = nullptr;           // row `row0` of the tile, at the slot's K offset
     const unsigned char* w_base = nullptr;
-    uint32_t a_lane[2], w_lane[2];
+    uint32_t a_lane[4], w_lane0;
     auto row_offset = [&](int gr) -> size_t {        // element offset of row gr of A (plain or a strided view)
         return p.a_rows > 0 ? (size_t)(gr / p.a_rows) * p.a_bstride + (size_t)(gr % p.a_rows) * p.lda : (size_t)gr * p.lda;
     };
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r = (wid + NWAVE * q) * 16 + (lane >> 2);                       // row inside the 256-row part
-        const int c = (lane & 3) ^ ((4 - ((r >> 2) & 3)) & 3);                    // source chunk for this LDS slot
-        w_lane[q] = (uint32_t)r * (uint32_t)p.K * 2u + c * 16;
+    {
+        const int r = wid * 8 + (lane >> 3);                                      // row inside the 256-row part (piece q: + 64 q rows, same swizzle)
+        const int c = (lane & 7) ^ ((r >> 1) & 7);                                // source chunk for this LDS position
+        w_lane0 = (uint32_t)r * (uint32_t)p.K * 2u + c * 16;
     }
     auto set_tile = [&](int t) {                     // loader -> tile number t of this workgroup, K offset 0
         int tm, tn;
@@ -120,45 +124,40 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         a_base = (const unsigned char*)(p.A + off0);
         w_base = (const unsigned char*)p.W + (size_t)tn * BN * p.K * 2;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int r = (wid + NWAVE * q) * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((4 - ((r >> 2) & 3)) & 3);
+        for (int q = 0; q < 4; ++q) {
+            const int r = (wid + NWAVE * q) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
             int gr = tm * BM + r;
             if (gr > p.M - 1) gr = p.M - 1;          // rows past the end re-read the last row (never stored)
             a_lane[q] = (uint32_t)((row_offset(gr) - off0) * 2) + c * 16;
         }
     };
-    // Round 4: the loader's bookkeeping off the intervals' critical path (profiles/r4h_gemm_skeleton_ablation.log: with the DMA
-    // requests and fragment reads taken out, the scalar code and branches around them still cost 3-16 % of a launch).  The
-    // loader NEVER stops: past the last stage of the workgroup's last tile it goes on requesting that tile's first stages
-    // (valid memory, slots whose stages have been multiplied) -- so there is no "anything left?" test per request, the queue
-    // always holds the same number of pieces and every stage wait is the same counted wait; the ring slot is a running offset
-    // instead of a modulo; the one stage wait that differs (the first of a tile, with the epilogue's stores in the queue) is peeled.
-    int load_ks = 0, load_tile = 0;                  // stage of its tile whose pieces are requested next
-    uint32_t load_slot = 0;                          // byte offset of that stage's ring slot
-    auto issue_half = [&](int half) {                // this wave's A piece and W piece number `half` of the stage being requested
-        unsigned char* slot = smem + load_slot + (wid + NWAVE * half) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[half]),
-                                         (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_lane[half]),
-                                         (__attribute__((address_space(3))) void*)(slot + A_PART), 16, 0, 0);
-        if (half == 1) {
+    // The loader NEVER stops (round 4): past the last slot of the workgroup's last tile it goes on requesting that tile's first slot
+    // (valid memory, a slot whose contents have been multiplied) -- no "anything left?" test per request, every wait is the same wait.
+    int load_ks = 0, load_tile = 0;                  // slot of its tile whose pieces are requested next
+    uint32_t load_slot = 0;                          // byte offset of that slot in LDS
+    auto issue_pair = [&](int q0) {                  // pieces q0 and q0 + 1 of A and of W of the slot being requested
+#pragma unroll
+        for (int q = q0; q < q0 + 2; ++q) {
+            unsigned char* dst = smem + load_slot + (wid + NWAVE * q) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[q]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + (size_t)q * 64 * p.K * 2 + w_lane0),
+                                             (__attribute__((address_space(3))) void*)(dst + A_PART), 16, 0, 0);
+        }
+        if (q0 == 2) {
             a_base += BK * 2; w_base += BK * 2;
-            load_slot = (load_slot + STAGE) & (STAGES * STAGE - 1);
+            load_slot ^= SLOT;
             if (++load_ks == nk) { load_ks = 0; ++load_tile; set_tile(load_tile < my_tiles ? load_tile : my_tiles - 1); }
         }
     };
     set_tile(0);
-    // what the steady-state schedule below assumes was requested before the first stage is multiplied: stages 0 .. STAGES - 3
-    // complete and the first half of stage STAGES - 2
-#pragma unroll 1
-    for (int s2 = 0; s2 < 2 * (STAGES - 2) + 1; ++s2) issue_half(s2 & 1);
-    // (the half numbering of that loop: 0, 1, 0, 1, 0 -- stages 0 and 1 complete, the first half of stage 2)
+    issue_pair(0); issue_pair(2);                    // slot 0 <- the first 64 K of the first tile (every later slot: while its predecessor's first half is multiplied)
 
-    // ---- fragment addresses inside a stage --------------------------------------------------------------------------
-    const int sw = (4 - ((lane >> 2) & 3)) & 3;                                   // the rows a lane reads have (r >> 2) & 3 = (lane >> 2) & 3
-    const int a_off = (wr * 64 + (lane & 15)) * 64 + ((g ^ sw) << 4);
-    const int b_off = A_PART + (wc * 128 + (lane & 15)) * 64 + ((g ^ sw) << 4);
+    // ---- fragment addresses inside a slot (rows of 128 B; the 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7)) -----
+    const int sw = ((lane & 15) >> 1) & 7;
+    const int a_off0 = (wr * 64 + (lane & 15)) * 128, b_off0 = A_PART + (wc * 128 + (lane & 15)) * 128;
+    const int ch0 = (g ^ sw) << 4;                   // chunk of the first 32 K of the slot; the second: ^ 64
 
     float4v acc[4][8];
     half8v af[4], bx[4];                             // A rows (4 blocks); W channels, first or second 64 of this wave (4 blocks)
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     // the whole bias vector (N <= 8192 channels, zeros without one) behind the ring: the epilogues read it with LDS loads,
     // which do not go through the global-memory counter the DMA pipeline and the stores are timed with
     {
-        h16* bias_lds0 = (h16*)(smem + STAGES * STAGE);
+        h16* bias_lds0 = (h16*)(smem + 2 * SLOT);
         for (int c = tid; c < p.N; c += 512) bias_lds0[c] = p.bias ? p.bias[c] : (h16)0.f;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -176,9 +175,8 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
     // barriers are the clock of that alternation; waves 4-7 run one barrier behind waves 0-3.
     if (wid >= 4) __builtin_amdgcn_s_barrier();
 
-    uint32_t cons_slot = 0;                          // ring slot (byte offset) of the stage being multiplied
+    uint32_t cons_slot = 0;                          // the slot being multiplied (byte offset)
     int t = 0;
-    bool after_epilogue = false;                     // the next stage wait has this wave's epilogue stores in its queue
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -186,15 +184,17 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
             for (int j = 0; j < 8; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    auto stage = [&](auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;      // the first stage of a tile: its wait may have the epilogue's stores in front
+    // one MFMA step of 32 K = one 64-byte half of the slot's rows, as two halves of the wave's channels:
+    // fragments (+ DMA requests | the slot wait) | barrier | 16 MFMAs | barrier, twice
+    auto step = [&](auto half_tag) {
+        constexpr int HALF = decltype(half_tag)::value;
         const unsigned char* st = smem + cons_slot;
-        // ---- first half of the channels: fragments, DMA requests | barrier | 16 MFMAs | barrier ------------------------
+        const int ch = HALF ? (ch0 ^ 64) : ch0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off + i * 1024);
+        for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off0 + ch + i * 2048);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + j * 1024);
-        issue_half(1);                               // completes stage cons + STAGES - 2
+        for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off0 + ch + j * 2048);
+        if (HALF == 0) issue_pair(0);                // the OTHER slot (multiplied before this one) <- the next 64 K of the stream
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -206,16 +206,13 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        // ---- second half ------------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off + (4 + j) * 1024);
-        issue_half(0);                               // opens stage cons + STAGES - 1
-        // Stage cons + 1 is read by waves 0-3 two barriers from here (one for waves 4-7): this wave's pieces of it must have
-        // landed before the next barrier.  Its last pieces were requested STAGES - 3 stages ago; WAIT younger requests may stay
-        // in flight -- plus, on the first stage after an epilogue, the epilogue's stores, which sit behind those pieces in the
-        // queue and must not be waited for here (they drain while the next stage is multiplied).
-        if (FIRST && after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT + N_STORES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT) : "memory");
+        for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off0 + ch + (4 + j) * 2048);
+        if (HALF == 0) issue_pair(2);
+        // The other slot is read by waves 0-3 two barriers from here (one for waves 4-7): this wave's pieces of it -- requested six to
+        // eight intervals ago, nothing younger in the queue but a previous epilogue's stores, which have had as long -- must have landed
+        // before the next barrier.
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -227,13 +224,11 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        cons_slot = (cons_slot + STAGE) & (STAGES * STAGE - 1);
+        if (HALF == 1) cons_slot ^= SLOT;
     };
     for (;;) {
-        stage(std::true_type{});
-        after_epilogue = false;
 #pragma unroll 1
-        for (int ks = 1; ks < nk; ++ks) stage(std::false_type{});
+        for (int ks = 0; ks < nk; ++ks) { step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); }
 
         // Waves 4-7 run one barrier behind: their last barrier of the tile pairs with THIS one.  Without it (round 2) it paired with
         // waves 0-3's first barrier of the next tile, i.e. waves 4-7 sat behind their finished last multiply until waves 0-3 had
@@ -259,7 +254,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         // piece's stores could only be waited for together with them.  The bias comes from LDS (copied there once per launch),
         // the residual rows (64 registers) are all requested up front; then nothing but arithmetic and stores, piece by piece
         // (one piece = one 16-row block x 64 channels: few temporaries alive at a time).
-        const h16* bias_lds = (const h16*)(smem + STAGES * STAGE) + col0 + wc * 128 + ge * 4;
+        const h16* bias_lds = (const h16*)(smem + 2 * SLOT) + col0 + wc * 128 + ge * 4;
         auto finish = [&](auto res_tag) {
             constexpr bool RES = decltype(res_tag)::value;
             half4v r4[RES ? 4 : 1][RES ? 8 : 1];
@@ -463,8 +458,6 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         } else {
             if (p.residual) finish(std::true_type{}); else finish(std::false_type{});
         }
-        // the store count the next stage wait adds is exact only for a tile without an M tail (rows past M skip their stores)
-        if (row0 + BM <= p.M) after_epilogue = true; else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (++t == my_tiles) break;
         zero_acc();
         if (wid >= 4) __builtin_amdgcn_s_barrier();  // one barrier behind waves 0-3 again
@@ -484,16 +477,15 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     WM_REQUIRE(p.ldc % 4 == 0 && p.ldr % 4 == 0, "gemm_f16p: ldc/ldr must be multiples of 4 (8-byte epilogue accesses)");
     WM_REQUIRE(p.M > 0, "gemm_f16p: empty M");
     WM_REQUIRE(p.act >= 0 && p.act <= 2, "gemm_f16p: act=%d", p.act);
-    constexpr int STAGES = 4;                        // 128 KB ring + 16 KB bias of the CU's 160 KB (5 stages measured no faster)
     static std::atomic<int> n_cu_dev[64];
     int dev = 0;
     WM_CHECK_HIP(hipGetDevice(&dev));
     const int slot = (dev >= 0 && dev < 64) ? dev : 0;
     int n_cu = n_cu_dev[slot].load(std::memory_order_relaxed);
     using Kern = void (*)(GemmBigParams);
-    static const Kern kerns[6] = {gemm_f16p_kernel<STAGES, 0>, gemm_f16p_kernel<STAGES, 1>, gemm_f16p_kernel<STAGES, 2>,
-                                  gemm_f16p_kernel<STAGES, 0, true>, gemm_f16p_kernel<STAGES, 1, true>, gemm_f16p_kernel<STAGES, 2, true>};
-    constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE + MAX_N * 2;
+    static const Kern kerns[6] = {gemm_f16p_kernel<0>, gemm_f16p_kernel<1>, gemm_f16p_kernel<2>,
+                                  gemm_f16p_kernel<0, true>, gemm_f16p_kernel<1, true>, gemm_f16p_kernel<2, true>};
+    constexpr size_t LDS_BYTES = (size_t)2 * SLOT + MAX_N * 2;       // two slots + the bias vector: 144 of the CU's 160 KB
     if (n_cu == 0) {
         int v = 0;
         WM_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));

@@ -3,6 +3,18 @@
 // stages fetch every line of A and W in two requests a stage apart: profiles/r5ai_*: TCP_TCC_READ_REQ = one request per 64 bytes).  Two slots
 // of 64 KB; slot g + 1 is requested while the first half of slot g is multiplied.  Same MFMA sequence per output element, same epilogues.
 #include <type_traits>
+#ifndef F16R_ISSUE_ALL_L1
+#define F16R_ISSUE_ALL_L1 0      // 1: all eight pieces of the next slot in the first load interval of a slot (default: four there, four in the second)
+#endif
+#ifndef F16R_EPI_ISSUE
+#define F16R_EPI_ISSUE 1         // 1: the next tile's SECOND slot is requested at the head of the epilogue (ahead of its stores), so that the first wait of the
+#endif                           //    next tile can leave the stores in flight; 0: every slot is requested while its predecessor's first half is multiplied
+#ifndef F16R_EPI_SPLIT
+#define F16R_EPI_SPLIT 0         // 1: residual epilogue in two phases -- everything in front of the residual add for the whole tile, then add + store
+#endif
+#ifndef F16R_RES_PREFETCH
+#define F16R_RES_PREFETCH 0      // 1: the tile's residual lines are touched (one dword per line, result unused) while its last slot is multiplied
+#endif
 namespace wm {
 
 namespace f16r {
@@ -59,15 +71,14 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
     // ---- loader: per K64 slot this wave requests 4 A pieces and 4 W pieces of 8 rows x 128 B (FULL cache lines) ----------------
     const unsigned char* a_base = nullptr;
     const unsigned char* w_base = nullptr;
-    uint32_t a_lane[4], w_lane[4];
+    uint32_t a_lane[4], w_lane0;
     auto row_offset = [&](int gr) -> size_t {
         return p.a_rows > 0 ? (size_t)(gr / p.a_rows) * p.a_bstride + (size_t)(gr % p.a_rows) * p.lda : (size_t)gr * p.lda;
     };
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = (wid + NWAVE * q) * 8 + (lane >> 3);                        // row inside the 256-row part
+    {
+        const int r = wid * 8 + (lane >> 3);                                      // row inside the 256-row part (piece q: + 64 q rows, same swizzle)
         const int c = (lane & 7) ^ ((r >> 1) & 7);                                // source chunk for this LDS slot
-        w_lane[q] = (uint32_t)r * (uint32_t)p.K * 2u + c * 16;
+        w_lane0 = (uint32_t)r * (uint32_t)p.K * 2u + c * 16;
     }
     auto set_tile = [&](int t) {
         int tm, tn;
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
             unsigned char* dst = smem + load_slot + (wid + NWAVE * q) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lane[q]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_lane[q]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + (size_t)q * 64 * p.K * 2 + w_lane0),
                                              (__attribute__((address_space(3))) void*)(dst + A_PART), 16, 0, 0);
         }
         if (q0 == 2) {
@@ -103,11 +114,12 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
     };
     set_tile(0);
     issue_pair(0); issue_pair(2);                    // slot 0 <- the first K64 of the first tile
+    if (F16R_EPI_ISSUE) { issue_pair(0); issue_pair(2); }      // ... and slot 1 <- its second
 
     // ---- fragment addresses inside a slot (rows of 128 B; chunk c of row r at position c ^ ((r >> 1) & 7)) ---------------------
     const int sw = ((lane & 15) >> 1) & 7;
     const int a_off0 = (wr * 64 + (lane & 15)) * 128, b_off0 = A_PART + (wc * 128 + (lane & 15)) * 128;
-    const int ch0 = ((0 + g) ^ sw) << 4, ch1 = ((4 + g) ^ sw) << 4;
+    const int ch0 = (g ^ sw) << 4;                   // the second 64-byte half: ^ 64
 
     float4v acc[4][8];
     half8v af[4], bx[4];                             // A rows (4 blocks); W channels, first or second 64 of this wave (4 blocks)
@@ -127,6 +139,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
 
     uint32_t cons_slot = 0;                          // ring slot (byte offset) of the stage being multiplied
     int t = 0;
+    bool after_epilogue = false;                     // the first wait of the tile has this wave's epilogue stores behind the pieces it waits for
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -134,15 +147,27 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
             for (int j = 0; j < 8; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    auto stage = [&](auto half_tag) {
-        constexpr int HALF = decltype(half_tag)::value;          // which 64-byte half of the slot's rows
+    bool prefetch_now = false;
+    unsigned pf_dummy0 = 0, pf_dummy1 = 0;
+    auto res_prefetch = [&]() {                      // this wave's 64 rows x 256 B of the residual tile: lane = row, two lines per row
+        int tm, tn;
+        tile_of(j0 + t * per_xcd, tm, tn);
+        int row = tm * BM + wr * 64 + lane;
+        if (row > p.M - 1) row = p.M - 1;
+        const h16* src = p.residual + (size_t)row * p.ldr + tn * BN + wc * 128;
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:128" : "=&v"(pf_dummy0), "=&v"(pf_dummy1) : "v"(src) : "memory");
+    };
+    auto stage = [&](auto half_tag, auto first_tag) {
+        constexpr int HALF = decltype(half_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;      // the first slot of a tile: with F16R_EPI_ISSUE its successor was requested by the epilogue before          // which 64-byte half of the slot's rows
         const unsigned char* st = smem + cons_slot;
-        const int ch = HALF ? ch1 : ch0;
+        const int ch = HALF ? (ch0 ^ 64) : ch0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const half8v*)(st + a_off0 + ch + i * 2048);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off0 + ch + j * 2048);
-        if (HALF == 0) issue_pair(0);
+        if (HALF == 0 && !(FIRST && F16R_EPI_ISSUE)) { issue_pair(0); if (F16R_ISSUE_ALL_L1) issue_pair(2); }
+        if (HALF == 0 && F16R_RES_PREFETCH && SIMPLE) { if (prefetch_now) res_prefetch(); }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -156,8 +181,9 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off0 + ch + (4 + j) * 2048);
-        if (HALF == 0) issue_pair(2);
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the other slot (requested a sub-stage ago) has landed before the next barrier
+        if (HALF == 0) { if (!F16R_ISSUE_ALL_L1 && !(FIRST && F16R_EPI_ISSUE)) issue_pair(2); }
+        else if (FIRST && F16R_EPI_ISSUE && after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_STORES) : "memory");      // (the slot's pieces are OLDER than the stores)
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (F16R_RES_PREFETCH) asm volatile("" :: "v"(pf_dummy0), "v"(pf_dummy1)); }   // the other slot (requested a sub-stage ago) has landed before the next barrier
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -172,8 +198,13 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
         if (HALF == 1) cons_slot ^= SLOT;
     };
     for (;;) {
+        stage(std::integral_constant<int, 0>{}, std::true_type{}); stage(std::integral_constant<int, 1>{}, std::true_type{});
+        after_epilogue = false;
 #pragma unroll 1
-        for (int ks = 0; ks < nk; ++ks) { stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{}); }
+        for (int ks = 1; ks < nk; ++ks) {
+            if (F16R_RES_PREFETCH && SIMPLE) prefetch_now = (ks == nk - 1) && p.residual != nullptr;
+            stage(std::integral_constant<int, 0>{}, std::false_type{}); stage(std::integral_constant<int, 1>{}, std::false_type{});
+        }
 
         // Waves 4-7 run one barrier behind: their last barrier of the tile pairs with THIS one.  Without it (round 2) it paired with
         // waves 0-3's first barrier of the next tile, i.e. waves 4-7 sat behind their finished last multiply until waves 0-3 had
@@ -183,6 +214,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
         // lag back with an extra barrier at the start of the next tile (below), as at the start of the kernel.
         if (wid < 4) __builtin_amdgcn_s_barrier();
 
+        if (F16R_EPI_ISSUE) { issue_pair(0); issue_pair(2); __builtin_amdgcn_sched_barrier(0); }      // the slot just multiplied <- the next tile's second K64
         // ================================ epilogue (as gemm_f16.hip) =====================================================
         int tm, tn;
         tile_of(j0 + t * per_xcd, tm, tn);
@@ -320,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
             uint4 r8[RES ? 4 : 1][RES ? 4 : 1];
             if constexpr (RES) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < (F16R_EPI_SPLIT ? 2 : 4); ++i) {
                     const int row = row0 + wr * 64 + i * 16 + rl;
                     const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colx;
 #pragma unroll
@@ -366,6 +398,50 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
                 }
                 lo = __builtin_bit_cast(uint32_t, h0); hi = __builtin_bit_cast(uint32_t, h1);
             };
+            if constexpr (RES && F16R_EPI_SPLIT) {
+                // (r8 holds row blocks 0 and 1 only here: see the loads above)
+                uint4 ob[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        uint32_t a0, a1, b0, b1;
+                        block(i, 2 * jp, a0, a1);
+                        block(i, 2 * jp + 1, b0, b1);
+                        lane_rows_swap16(a0, b0);
+                        lane_rows_swap16(a1, b1);
+                        ob[i][jp] = make_uint4(a0, a1, b0, b1);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                uint4 r8b[2][4];
+#pragma unroll
+                for (int i = 2; i < 4; ++i) {
+                    const int row = row0 + wr * 64 + i * 16 + rl;
+                    const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colx;
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) r8b[i - 2][jp] = *(const uint4*)(rrow + jp * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + wr * 64 + i * 16 + rl;
+                    h16* crow = p.C + (size_t)(row < p.M ? row : p.M - 1) * p.ldc + colx;
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const half8v x = __builtin_bit_cast(half8v, ob[i][jp]), r = __builtin_bit_cast(half8v, i < 2 ? r8[i][jp] : r8b[i - 2][jp]);
+                        half8v y;
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const float2v tt = float2v{(float)x[e], (float)x[e + 1]} + float2v{(float)r[e], (float)r[e + 1]};
+                            const half2v h = __builtin_convertvector(tt, half2v);
+                            y[e] = h[0]; y[e + 1] = h[1];
+                        }
+                        if (row < p.M) *(uint4*)(crow + jp * 32) = __builtin_bit_cast(uint4, y);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + wr * 64 + i * 16 + rl;
@@ -404,6 +480,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
             if (p.residual) finish(std::true_type{}); else finish(std::false_type{});
         }
         // the store count the next stage wait adds is exact only for a tile without an M tail (rows past M skip their stores)
+        if (F16R_EPI_ISSUE) { if (row0 + BM <= p.M) after_epilogue = true; else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         if (++t == my_tiles) break;
         zero_acc();
         if (wid >= 4) __builtin_amdgcn_s_barrier();  // one barrier behind waves 0-3 again

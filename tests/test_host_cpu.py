@@ -368,8 +368,9 @@ def test_graft_entry_build_runs():
 
 
 def test_persistent_gemm_generated_code_matches_its_store_count():
-    """csrc/gemm_f16p.hip lets a tile's first stage wait leave the previous epilogue's stores in flight by COUNT (16 in the SIMPLE
-    kernels, 32 in the general ones); scripts/check_gemm_isa.py holds the generated code to the counts (hipcc -S, no GPU)."""
+    """csrc/gemm_f16p.hip's generated code (hipcc -S, no GPU; scripts/check_gemm_isa.py): the encoder layers' kernels store 16 bytes per
+    lane and instruction (16 per epilogue copy), none of them spills, and each holds the sixteen LDS-DMA requests of the two-slot
+    operand stream (a slot in front of the K loop, a slot per slot inside it)."""
     import shutil
     import subprocess
     import sys
