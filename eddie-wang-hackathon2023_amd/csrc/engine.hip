@@ -760,7 +760,7 @@ int self_attn_waves(int rows) {
     return w ? w : (rows <= small_path_max_rows() ? 4 : 1);
 }
 
-// rows (utterances) of a group the one-launch step serves: CHAIN_MAX_ROWS (2) unless WM_CHAIN_ROWS=1 keeps it to one (lab: A/B runs)
+// rows (utterances) of a group the one-launch step serves: CHAIN_MAX_ROWS (4) unless WM_CHAIN_ROWS=n keeps it to fewer (lab: A/B runs)
 int chain_max_rows() {
     static const int r = [] { const int v = lab_env_int("WM_CHAIN_ROWS", CHAIN_MAX_ROWS); return v < 1 ? 1 : (v > CHAIN_MAX_ROWS ? CHAIN_MAX_ROWS : v); }();
     return r;
@@ -839,7 +839,8 @@ struct GroupStep {
             // key-range pieces, fp16 cross K/V, the four-wave self-attention form; anything else takes the launch-per-kernel path
             chain_wgs = n_cu > 256 ? 256 : n_cu; chain_err = cd.err_dev; chain_cd = &cd;
             bool ok = gemv_chain_supports(C, e->dec[0].qkv.wcode, n_cu) && w.nsplit == 4 && !e->i8cross() && self_attn_waves(M) == 4 &&
-                      io->present_capacity <= 512 && M * (H + H * w.nsplit) <= chain_wgs;
+                      io->present_capacity <= 512 && !(M > 2 && e->dec[0].qkv.wcode == 4) &&
+                      M * H + (M > 2 ? (M * H * w.nsplit + 1) / 2 : M * H * w.nsplit) <= chain_wgs;      // (3, 4 rows: two cross-attention items per workgroup)
             for (int i = 0; ok && i < e->dims.n_text_layer; ++i)
                 ok = io->present[i] && io->cross[i] &&
                      (T == 0 ? io->n_past_dev == nullptr : (io->past[i] == io->present[i] && io->past_capacity == io->present_capacity));

@@ -80,13 +80,16 @@ __device__ __forceinline__ bool sweep_granules16(const unsigned long long* gran,
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
                          "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]), "+v"(val[12]), "+v"(val[13]), "+v"(val[14]), "+v"(val[15]),
                          "+v"(val[16]), "+v"(val[17]) :: "memory");
+        else if constexpr (NL == 16)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
+                         "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]), "+v"(val[12]), "+v"(val[13]), "+v"(val[14]), "+v"(val[15]) :: "memory");
         else if constexpr (NL == 9)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
                          "+v"(val[8]) :: "memory");
         else if constexpr (NL == 15)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]), "+v"(val[5]), "+v"(val[6]), "+v"(val[7]),
                          "+v"(val[8]), "+v"(val[9]), "+v"(val[10]), "+v"(val[11]), "+v"(val[12]), "+v"(val[13]), "+v"(val[14]) :: "memory");
-        else static_assert(NL == 1 || NL == 2 || NL == 3 || NL == 4 || NL == 6 || NL == 8 || NL == 9 || NL == 12 || NL == 15 || NL == 18, "sweep sizes of the chain");
+        else static_assert(NL == 1 || NL == 2 || NL == 3 || NL == 4 || NL == 6 || NL == 8 || NL == 9 || NL == 12 || NL == 15 || NL == 16 || NL == 18, "sweep sizes of the chain");
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) ok &= val[k].y == epoch && val[k].w == epoch;
@@ -110,17 +113,18 @@ enum ChainIn : int {
 template <int NR>
 __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, unsigned tag, h16 (*s_in)[CHAIN_MAX_IN + 8]);      // (below)
 
-// NR activation rows (1 | 2).  The MFMA's 16 A rows carry the activation rows alternately (A row = lane & 15, row = lane & (NR - 1)), so
-// a row's sums are the same chain of MFMA steps whatever NR is, and come out in accumulator element `row` of the first 16 lanes.
-// Where the rows of a stage's input sit in LDS (s_in is two arrays of CHAIN_MAX_IN + 8 halves):
+// NR activation rows (1 | 2 | 4: the kernel for 3 and 4 rows; p.rows says how many exist).  The MFMA's 16 A rows carry the activation rows
+// alternately (A row = lane & 15, row = lane & (NR - 1)), so a row's sums are the same chain of MFMA steps whatever NR is, and come out in
+// accumulator element `row` of the first 16 lanes.  (With 3 rows the fourth A row multiplies whatever LDS holds: its sums are never read.)
+// Where the rows of a stage's input sit in LDS (s_in is max(NR, 2) arrays of CHAIN_MAX_IN + 8 halves):
 //   NR == 1: s_in[slot] -- every slot keeps its own copy (no barrier between a slot's sweep and its reads)
-//   NR == 2: rows the whole workgroup shares (LayerNorm output, merged attention rows, the wide stage's hidden rows): s_in[row];
-//            rows a slot sweeps for itself (K <= 1536): four blocks of 1544 halves, block 2 * slot + row
+//   NR >= 2: rows the whole workgroup shares (LayerNorm output, merged attention rows, the wide stage's hidden rows): s_in[row];
+//            rows a slot sweeps for itself (K <= 1536): 2 NR blocks of 1544 halves, block NR * slot + row
 template <int NR, bool WIDE, bool SHARED>
 __device__ __forceinline__ h16* chain_in_row(h16 (*s_in)[CHAIN_MAX_IN + 8], int slot, int row) {
     if constexpr (NR == 1) return &s_in[slot][0];
     else if constexpr (WIDE || SHARED) return &s_in[row][0];
-    else return &s_in[0][0] + (2 * slot + row) * 1544;
+    else return &s_in[0][0] + (NR * slot + row) * 1544;
 }
 
 // gemv_small's LayerNorm of ONE row by one wave: the row in registers (a lane: pieces lane, lane + 64, lane + 128 of 8 halves), two-pass
@@ -204,6 +208,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     const int nb = has_group ? grp : st.n_blocks - 1;         // (idle slots re-read valid memory; nothing of theirs is stored)
     const int n_out = st.n_blocks * 16;                       // output channels of the stage = elements between the rows of its outputs
     const int row_a = NR == 1 ? 0 : rl & (NR - 1);            // the activation row this lane's A fragments carry
+    const int R = NR == 1 ? 1 : p.rows;                       // rows that exist (NR == 4: 3 or 4)
 
     // an idle slot (no group of this stage falls to it) only keeps the workgroup's barriers company: it touches no memory, so that
     // waves which carry LDS-DMA requests for a later stage (the cross-attention's K / V rows) are not made to wait for them here
@@ -249,7 +254,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         if constexpr (NR == 1) {
             if (wslot == 0) chain_ln_row(p, st, p.x, p.gran_x, epoch - 1, x_in_granules, chain_in_row<NR, WIDE, true>(s_in, slot, 0), lane);
         } else {
-            if (wid < NR) chain_ln_row(p, st, p.x + wid * st.K, p.gran_x + wid * (st.K >> 1), epoch - 1, x_in_granules, chain_in_row<NR, WIDE, true>(s_in, 0, wid), lane);
+            if (wid < R) chain_ln_row(p, st, p.x + wid * st.K, p.gran_x + wid * (st.K >> 1), epoch - 1, x_in_granules, chain_in_row<NR, WIDE, true>(s_in, 0, wid), lane);
         }
         __syncthreads();
 #pragma unroll
@@ -294,7 +299,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 #pragma unroll
             for (int r = 0; r < NR; ++r)
 #pragma unroll
-                for (int k = 0; k < NLR; ++k) first[(j * NR + r) * NLR + k] = r * in_stride + g0 + 2 * min(lane + 64 * k, max(n_ld[j] - 1, 0));
+                for (int k = 0; k < NLR; ++k) first[(j * NR + r) * NLR + k] = min(r, R - 1) * in_stride + g0 + 2 * min(lane + 64 * k, max(n_ld[j] - 1, 0));      // (a row that does not exist: the last one again)
         }
         const bool ok = any && sweep_granules16<NS * NR * NLR>(gran, first, tag, val, p.err, lane);      // (an absent slice re-reads granules of the stage's first tile)
         if (ok) {
@@ -372,7 +377,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     // ---- 4. epilogue of the slot (row 0 sits in the lanes of the first 16-lane group, element 0 of the accumulator; row 1 in element
     // 1): gemv_small's, the result published as granules for the stages behind it.  Wave r of the slot finishes row r: at two rows the
     // epilogues run side by side (one wave doing both in turn cost the two-row step ~ 2 us per layer, profiles/r5q_*_b2) ---------------
-    if (wslot < NR && has_group) {
+    if (wslot < R && has_group) {
         // (the slices' sums are READ first -- all in flight -- and added afterwards in slice order: read and added one by one they were up to
         // sixteen dependent LDS round trips: the wide stage's epilogue 0.85 -> 0.66 us, profiles/r5v_*)
         constexpr int MAXS = WIDE ? 16 : 4;
@@ -389,7 +394,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         const float bias = has_bias ? (float)bias_raw : 0.f;
         {
             const int r = NR == 1 ? 0 : wslot;                // (wave-uniform)
-            const float y = NR == 1 ? sum[0] : (wslot == 0 ? sum[0] : sum[1]);      // row r; the lanes beyond the first 16 hold rows that do not exist
+            const float y = NR == 1 ? sum[0] : (NR == 2 ? (wslot == 0 ? sum[0] : sum[1]) : (wslot < 2 ? (wslot == 0 ? sum[0] : sum[1]) : (wslot == 2 ? sum[2] : sum[3])));      // row r; the lanes beyond the first 16 hold rows that do not exist
             if (st.mode == 0) {
                 if (g == 0) {
                     p.out32[r * n_out + col] = y;             // raw sums for the attention kernel of the next launch
@@ -430,6 +435,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 // activations: their 96 KB fly while the chain's Linears run) instead of from memory through a register pipeline.
 constexpr int CHAIN_CROSS_KEYS = 1536;
 constexpr size_t CHAIN_DYN_LDS = 100 * 1024;      // K and V rows of a piece (beside ~ 60 KB of static LDS, of 160)
+constexpr size_t CHAIN_DYN_LDS4 = 64 * 1024;      // 3 and 4 rows: the self-attention's cached rows only (beside ~ 85 KB of static LDS)
 constexpr int CHAIN_MAX_LAYERS = 32;               // layers of a whole-step launch (their descriptors and tables sit in LDS; Whisper large has 32)
 // what the attention stages take per LAYER (kernel arguments for a one-layer launch, the two tables in a whole-step launch)
 struct ChainLayerArgs { const h16* cross_kv; const h16* cross_qbias; void* self_cache; const h16* self_bias; float self_kv_scale; };
@@ -622,6 +628,178 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     }
 }
 
+// The cross-attention stage of the 3- and 4-row step.  R x heads x 4 pieces are more items than the launch has workgroups, and four rows' K / V
+// (30.7 MB per layer) more than the LDS beside the Linears' buffers holds, so here an item is attn_cross_kernel<1>'s own shape -- FOUR waves --
+// two items per workgroup (waves 0-3 | 4-7; the last ceil(items / 2) workgroups of the launch), and the rows come from memory into
+// REGISTERS: a wave's share of a piece is 12 K and 12 V loads of 16 bytes per lane, all 24 requested at the head of the stage -- the
+// workgroups that carry items idle through the two Linear stages in front of it (out, cq), so the rows fly while q is still being made.
+// The arithmetic is attn_cross_kernel's, bit for bit: wave w of the item scores rows 32 w + 128 k ..., maxima and sums met in wave order,
+// P.V per lane over its rows in sequence, (max, sum, o[64]) left for the merge as tagged granules.
+__device__ __forceinline__ void chain_cross_stage4(const GemvChainParams& p, const ChainLayerArgs& la, unsigned epoch_q, int per_split,
+                                                   float* s_sc_all /* [2][768] */, float (*s_redc)[2] /* [8] */, float (*s_o)[64] /* [8] */, float (*s_q)[64] /* [2] */) {
+    constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
+    constexpr int STRIDE = 4 * RPI * UNR;          // 128 rows per iteration of an item's four waves
+    constexpr int KB = 3;                          // iterations of a piece (<= 384 keys)
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wid >> 2, wq = wid & 3, tl = tid & 255;
+    const int per_row = p.cross_heads * p.cross_nsplit, n_items = p.rows * per_row;
+    const int n_wgs = (n_items + 1) >> 1;
+    const int wg = (int)blockIdx.x - ((int)gridDim.x - n_wgs);
+    if (wg < 0) {                                  // (workgroup-uniform) no items here: the stage's four barriers, nothing requested
+        for (int b = 0; b < 4; ++b) __syncthreads();
+        return;
+    }
+    const int item = 2 * wg + half;
+    const bool has_item = item < n_items;
+    const int urow = has_item ? item / per_row : 0, rem = has_item ? item - urow * per_row : 0;
+    const int h = rem % p.cross_heads, sp = rem / p.cross_heads;
+    const int k_begin = sp * per_split, nkeys = has_item ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
+    const bool worker = has_item && nkeys > 0;
+    float* s_sc = s_sc_all + half * 768;
+    const unsigned long long* gran_q = p.gran_q + (size_t)urow * p.cross_heads * 64;
+    unsigned long long* gran_p = p.gran_p + (size_t)urow * p.cross_heads * 66 * 4;
+    const int sub = lane % LPR, rowi = lane / LPR;
+    const int first = wq * (RPI * UNR);
+    // ---- every row of this wave, K and V, requested now ------------------------------------------------------------------------------
+    u32x4 kv_k[KB][UNR], kv_v[KB][UNR];
+    {
+        const unsigned char* Kg = (const unsigned char*)la.cross_kv + (size_t)urow * p.cross_row_bytes + ((size_t)(0 * p.cross_heads + h) * p.cross_Tk + k_begin) * 128;
+        const unsigned char* Vg = (const unsigned char*)la.cross_kv + (size_t)urow * p.cross_row_bytes + ((size_t)(1 * p.cross_heads + h) * p.cross_Tk + k_begin) * 128;
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int rr = max(min(first + kk * STRIDE + u * RPI + rowi, nkeys - 1), 0);      // (no item: row 0 of item 0's K -- valid memory, never used)
+                kv_k[kk][u] = __builtin_nontemporal_load((const u32x4*)(Kg + (size_t)rr * 128 + sub * 16));
+            }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int rr = max(min(first + kk * STRIDE + u * RPI + rowi, nkeys - 1), 0);
+                kv_v[kk][u] = __builtin_nontemporal_load((const u32x4*)(Vg + (size_t)rr * 128 + sub * 16));
+            }
+    }
+    half8v qb8 = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const bool hb = worker && la.cross_qbias != nullptr;
+        const half8v raw = *(const half8v*)(hb ? la.cross_qbias + h * 64 + sub * DPL : (const h16*)p.st);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) qb8[e] = hb ? raw[e] : (h16)0.f;
+    }
+    if (wq == 0 && has_item) {                                                  // the head's 64 q sums, as the last Linear published them
+        int fst[1] = {h * 64 + 2 * min(lane, 31)};
+        u32x4 val[1];
+        if (sweep_granules16<1>(gran_q, fst, epoch_q, val, p.err, lane) && lane < 32) {
+            unsigned q0 = val[0].x, q1 = val[0].z;
+            asm volatile("" : "+v"(q0), "+v"(q1));
+            s_q[half][2 * lane] = __builtin_bit_cast(float, q0);
+            s_q[half][2 * lane + 1] = __builtin_bit_cast(float, q1);
+        }
+    }
+    __syncthreads();                                                           // (A) the q sums are in LDS
+    auto put = [&](int r, float v) {
+        __hip_atomic_store((chain_gu64*)(gran_p + ((size_t)h * 66 + r) * 4 + sp), ((unsigned long long)epoch_q << 32) | __builtin_bit_cast(unsigned, v),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (has_item && nkeys == 0) {
+        if (tl < 66) put(tl, (tl == 0) ? -INFINITY : 0.f);
+    }
+    const int nb = (nkeys + STRIDE - 1) / STRIDE;
+    float qf[DPL];
+    float mx = -INFINITY;
+    if (worker) {
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            const float x = s_q[half][sub * DPL + e];
+            float qa = 0.f;
+            qa += x + 0.f;
+            qa += 0.f + 0.f;
+            const float bs = (float)qb8[e];
+            qf[e] = r16(r16(qa + bs) * CHAIN_ATTN_SCALE);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            if (kk >= nb) break;                                               // wave-uniform
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = first + kk * STRIDE + u * RPI + rowi;
+                const half8v hv = __builtin_bit_cast(half8v, kv_k[kk][u]);
+                float ks[DPL];
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) ks[e] = r16((float)hv[e] * CHAIN_ATTN_SCALE);
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) acc = fmaf(qf[e], ks[e], acc);
+                acc += wave_dpp<0xB1>(acc);
+                acc += wave_dpp<0x4E>(acc);
+                acc += wave_dpp<0x141>(acc);
+                const float sc = r16(f32_as_is(acc));
+                if (r < nkeys) {
+                    if (sub == 0) s_sc[r] = sc;
+                    mx = fmaxf(mx, sc);
+                }
+            }
+        }
+        const float m = wave_max_nomfma(mx);
+        if (lane == 0) s_redc[wid][0] = m;
+    }
+    __syncthreads();                                                           // (B)
+    float gmax = 0.f, gsum = 0.f;
+    if (worker) {
+        gmax = fmaxf(fmaxf(s_redc[4 * half][0], s_redc[4 * half + 1][0]), fmaxf(s_redc[4 * half + 2][0], s_redc[4 * half + 3][0]));
+        float sm = 0.f;
+        for (int j = tl; j < nkeys; j += 256) {
+            const float e = __expf(s_sc[j] - gmax);
+            s_sc[j] = e;
+            sm += e;
+        }
+        sm = wave_sum_nomfma(sm);
+        if (lane == 0) s_redc[wid][1] = sm;
+    }
+    __syncthreads();                                                           // (C)
+    if (worker) {
+        gsum = s_redc[4 * half][1] + s_redc[4 * half + 1][1] + s_redc[4 * half + 2][1] + s_redc[4 * half + 3][1];
+        float o[DPL];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+        float pr[KB][UNR];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int r = first + kk * STRIDE + u * RPI + rowi;
+                pr[kk][u] = r < nkeys ? s_sc[min(r, nkeys - 1)] : 0.f;
+            }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            if (kk >= nb) break;                                               // wave-uniform
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const half8v hv = __builtin_bit_cast(half8v, kv_v[kk][u]);
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr[kk][u], (float)hv[e], o[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) asm volatile("" : "+v"(o[e]) : : "memory");
+        }
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] += wave_dpp<0x128>(o[e]);
+        wave_add_xor16_x8_nomfma(o);
+        wave_add_xor32_x8_nomfma(o);
+        if (rowi == 0) {
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) s_o[wid][sub * DPL + e] = o[e];
+        }
+    }
+    __syncthreads();                                                           // (D)
+    if (worker && tl < 64) {
+        const float v = s_o[4 * half][tl] + s_o[4 * half + 1][tl] + s_o[4 * half + 2][tl] + s_o[4 * half + 3][tl];
+        put(2 + tl, v);
+        if (tl == 0) { put(0, gmax); put(1, gsum); }
+    }
+}
+
 // The merge of the cross-attention's four key-range pieces when they were produced by THIS launch (tagged granules, p.gran_p):
 // attn_cross_combine_kernel's arithmetic -- m = max of the pieces' maxima, f_q = exp(m_q - m), den = sum_q l_q f_q and
 // num = sum_q o_q f_q in piece order, (h16)(num / den) -- with every lane holding all four (m, l) pairs itself instead of taking
@@ -636,7 +814,7 @@ __device__ __forceinline__ void chain_merge_tagged(const GemvChainParams& p, uns
     // chunk of the pair's eight (maximum, sum) values -- lanes 0-3 the four chunks, the others repeat them -- which are the same for every
     // lane and read across the wave (v_readlane): 3 loads per pair instead of 6 (15 per pass at two rows; 30 spilled 164 bytes per lane).
     constexpr int MH = NR == 1 ? 3 : 5;
-    const int n_pairs = NR * p.merge_heads;
+    const int n_pairs = (NR == 1 ? 1 : p.rows) * p.merge_heads;      // (NR == 4: 60 or 80 pairs, two passes)
     for (int i0 = wid; i0 < n_pairs; i0 += 8 * MH) {
         int first[3 * MH];
         u32x4 val[3 * MH];
@@ -928,7 +1106,7 @@ __device__ __forceinline__ void chain_self_stage(const GemvChainParams& p, const
 template <int WB, bool I8KV, int NR>
 __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     __shared__ __attribute__((aligned(16))) float s_red[16][64][4];
-    __shared__ __attribute__((aligned(16))) h16 s_in[2][CHAIN_MAX_IN + 8];
+    __shared__ __attribute__((aligned(16))) h16 s_in[NR > 2 ? NR : 2][CHAIN_MAX_IN + 8];
     __shared__ __attribute__((aligned(16))) h16 s_own[2 * NR][16];       // [slot][row]: the slot's 16 channels of the residual rows
     constexpr int KT = WB == 4 ? 128 : (WB == 8 ? 64 : 32);
     constexpr int TB = WB == 16 ? 10 : 5;
@@ -939,8 +1117,8 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char kv_lds[];      // the cross-attention stage's K and V rows (only then)
     __shared__ float s_sc[CHAIN_CROSS_KEYS];
     __shared__ float s_redc[8][2];
-    __shared__ float s_o[4][64];
-    __shared__ float s_q[64];
+    __shared__ float s_o[NR == 4 ? 8 : 4][64];
+    __shared__ float s_q[NR == 4 ? 2 : 1][64];
     // The WHOLE token step in one launch (p.n_layers > 0): the launch walks over the layers itself.  Per-layer pointers come from two
     // tables (the engine's: biases and the cache scale; the caller's, in the workspace: cross K/V and cache of each layer), the
     // descriptors are [qkv of layer 0] + 6 per layer, and "layer -1" is that first projection alone (its sums go out as granules,
@@ -968,15 +1146,19 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     // self-attention's heads to the ones before them: the first workgroups own the output groups of every n_state-wide Linear (and
     // both slots of the widest), the last ones idle through most stages -- and the four upper waves of a workgroup that carries
     // K / V rows in flight must not meet a stage's "everything of mine has landed" wait before those rows are due.
-    chain_cross_prefetch<NR>(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
-    const int n_cross_wgs = NR * p.cross_heads * p.cross_nsplit, n_self_wgs = NR * p.self_heads;      // one (row, head, piece) | (row, head) each
+    // (3 and 4 rows: the cross-attention's rows go from memory to registers inside its stage, two items per workgroup -- chain_cross_stage4)
+    if constexpr (NR <= 2) chain_cross_prefetch<NR>(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
+    const int R = NR == 1 ? 1 : p.rows;
+    const int n_cross_wgs = NR == 4 ? (R * p.cross_heads * p.cross_nsplit + 1) / 2 : NR * p.cross_heads * p.cross_nsplit;      // one (row, head, piece) each | two
+    const int n_self_wgs = R * p.self_heads;                                                                                   // one (row, head) each
+    const int kv_avail = NR == 4 ? (int)CHAIN_DYN_LDS4 - 1024 : 2 * per_split * 128;      // dynamic LDS the self-attention's cached rows may take
     const int self_base = max((int)gridDim.x - n_cross_wgs - n_self_wgs, 0);
     const int self_idx = (int)blockIdx.x - self_base;                    // this workgroup's self-attention (row, head), if 0 <= self_idx < rows x heads
     const bool self_wg = self_idx >= 0 && self_idx < n_self_wgs && (int)blockIdx.x < (int)gridDim.x - n_cross_wgs;
     const int self_h = self_wg ? self_idx % p.self_heads : 0, self_r = self_wg ? self_idx / p.self_heads : 0;
     const size_t self_row_off = (size_t)self_r * p.self_row_bytes;       // this row's share of a layer's cache
     int self_v_off = 0;                                                  // > 0: the head's cached rows of the NEXT self-attention stage are (on their way) in LDS
-    if (self_wg) self_v_off = chain_self_prefetch<I8KV>(p, (const unsigned char*)(whole ? s_lio[0].cache : p.self_cache) + self_row_off, T_now, self_h, kv_lds, 2 * per_split * 128);
+    if (self_wg) self_v_off = chain_self_prefetch<I8KV>(p, (const unsigned char*)(whole ? s_lio[0].cache : p.self_cache) + self_row_off, T_now, self_h, kv_lds, kv_avail);
     bool own_valid = false, x_in_granules = false;
     for (int l = whole ? -1 : 0; l < (whole ? p.n_layers : 1); ++l) {
         const unsigned epoch0 = gen | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);
@@ -995,7 +1177,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             const unsigned tag_s = (gen | ((unsigned)((l - 1) & 63) << 3)) + 6;     // the qkv stage (s = 5) of the layer before
             chain_self_stage<I8KV>(p, la, T_now, epoch0, tag_s, self_h, self_r, s_p, s_new, s_r2, s_o_flat, s_lut, kv_lds, self_v_off);
             // the NEXT layer's cached rows set out now (the stage's last barrier is behind every read of this layer's)
-            self_v_off = (whole && l + 1 < p.n_layers) ? chain_self_prefetch<I8KV>(p, (const unsigned char*)s_lio[l + 1].cache + self_row_off, T_now, self_h, kv_lds, 2 * per_split * 128) : 0;
+            self_v_off = (whole && l + 1 < p.n_layers) ? chain_self_prefetch<I8KV>(p, (const unsigned char*)s_lio[l + 1].cache + self_row_off, T_now, self_h, kv_lds, kv_avail) : 0;
         }
         const int s_first = l < 0 ? 5 : 0;
         const int s_end = !whole ? p.n_stages : (l < 0 ? 6 : (l + 1 < p.n_layers ? 6 : 5));
@@ -1022,9 +1204,13 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             else chain_stage<WB, false, false, NR>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
             if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
             if (l >= 0 && s == p.cross_at) {
-                chain_cross_stage<NR>(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q);
-                // the NEXT layer's K / V rows set out now: they have the rest of this layer to arrive
-                if (whole && l + 1 < p.n_layers) chain_cross_prefetch<NR>(p, s_lio[l + 1].cross_kv, kv_lds, per_split);
+                if constexpr (NR == 4) {
+                    chain_cross_stage4(p, la, epoch, per_split, s_sc, s_redc, s_o, s_q);
+                } else {
+                    chain_cross_stage<NR>(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q[0]);
+                    // the NEXT layer's K / V rows set out now: they have the rest of this layer to arrive
+                    if (whole && l + 1 < p.n_layers) chain_cross_prefetch<NR>(p, s_lio[l + 1].cross_kv, kv_lds, per_split);
+                }
             }
         }
     }
@@ -1052,6 +1238,13 @@ static int chain_set_lds_attribute() {
         return f(gemv_chain_kernel<16, true, 2>);
     };
     if (each_kernel([&](auto* k) -> int { WM_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_DYN_LDS)); return 0; })) return 2;
+    auto each_kernel4 = [&](auto&& f) -> int {       // 3 and 4 rows (8- and 16-bit weights)
+        if (int rc = f(gemv_chain_kernel<8, false, 4>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, true, 4>)) return rc;
+        if (int rc = f(gemv_chain_kernel<16, false, 4>)) return rc;
+        return f(gemv_chain_kernel<16, true, 4>);
+    };
+    if (each_kernel4([&](auto* k) -> int { WM_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_DYN_LDS4)); return 0; })) return 2;
     attr_set.fetch_or(bit, std::memory_order_release);
     return 0;
 }
@@ -1062,6 +1255,10 @@ static int chain_set_lds_attribute() {
 // every instantiation by its run-time selectors
 template <typename F>
 static auto chain_pick(int w8, bool i8, int rows, F&& f) {
+    if (rows > 2) {                                  // (4-bit weights: one or two rows only -- the callers check)
+        if (w8) return i8 ? f(gemv_chain_kernel<8, true, 4>) : f(gemv_chain_kernel<8, false, 4>);
+        return i8 ? f(gemv_chain_kernel<16, true, 4>) : f(gemv_chain_kernel<16, false, 4>);
+    }
     if (rows == 2) {
         if (w8 == 4) return i8 ? f(gemv_chain_kernel<4, true, 2>) : f(gemv_chain_kernel<4, false, 2>);
         if (w8) return i8 ? f(gemv_chain_kernel<8, true, 2>) : f(gemv_chain_kernel<8, false, 2>);
@@ -1075,9 +1272,10 @@ static auto chain_pick(int w8, bool i8, int rows, F&& f) {
 int gemv_chain_resident(int w8, int self_i8, int rows, int cross_Tk, int cross_nsplit, int n_wg, int n_cu, bool* ok, char* why, size_t why_cap) {
     *ok = false;
     WM_REQUIRE(cross_nsplit >= 1 && cross_Tk >= 1 && n_wg >= 1 && n_cu >= 1, "gemv_chain_resident: bad arguments");
-    WM_REQUIRE(rows == 1 || rows == 2, "gemv_chain_resident: rows=%d", rows);
+    WM_REQUIRE(rows >= 1 && rows <= CHAIN_MAX_ROWS && !(rows > 2 && w8 == 4), "gemv_chain_resident: rows=%d (w8=%d)", rows, w8);
     const int per_split = (((cross_Tk + cross_nsplit - 1) / cross_nsplit) + 7) & ~7;
-    const size_t dyn = (size_t)2 * per_split * 128 + 1024;
+    const size_t dyn = rows > 2 ? CHAIN_DYN_LDS4 : (size_t)2 * per_split * 128 + 1024;
+    if (rows > 2 && per_split > 384) { if (why) snprintf(why, why_cap, "cross-attention pieces of %d keys exceed the 3- and 4-row stage's 384", per_split); return 0; }
     if (dyn > CHAIN_DYN_LDS) { if (why) snprintf(why, why_cap, "cross-attention pieces of %d keys do not fit LDS", per_split); return 0; }
     if (chain_set_lds_attribute()) return 2;
     // What one workgroup takes of a CU, from the function's own attributes, against what a CU has: 512 threads = 8 waves = 2 per SIMD
@@ -1157,15 +1355,16 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs_all, int n_
     WM_REQUIRE(p.merge_nsplit == 4 && p.cross_nsplit == 4 && p.merge_heads == p.cross_heads, "gemv_chain: the attention pieces travel as [head][66][4]: 4 pieces");
     WM_REQUIRE(p.self_heads >= 1 && p.self_heads * 64 == hs[0].K && !hs[0].ln_g && (p.self_t_dev || (p.self_T >= 0 && p.self_T < p.self_cap)) && p.self_cap <= 512,
                "gemv_chain: self-attention stage: bad arguments");
-    WM_REQUIRE(p.rows == 1 || p.rows == 2, "gemv_chain: rows=%d (one or two activation rows)", p.rows);
-    WM_REQUIRE(p.rows == 1 || (p.cross_row_bytes > 0 && p.self_row_bytes > 0), "gemv_chain: two rows need the strides between their cross K/V and caches");
-    WM_REQUIRE(n_wg >= p.rows * (p.self_heads + p.cross_heads * p.cross_nsplit), "gemv_chain: %d workgroups for the attention stages of %d rows", n_wg, p.rows);
+    WM_REQUIRE(p.rows >= 1 && p.rows <= CHAIN_MAX_ROWS && !(p.rows > 2 && p.w8 == 4), "gemv_chain: rows=%d (one to four activation rows; 4-bit weights: one or two)", p.rows);
+    WM_REQUIRE(p.rows == 1 || (p.cross_row_bytes > 0 && p.self_row_bytes > 0), "gemv_chain: several rows need the strides between their cross K/V and caches");
+    const int cross_wgs = p.rows > 2 ? (p.rows * p.cross_heads * p.cross_nsplit + 1) / 2 : p.rows * p.cross_heads * p.cross_nsplit;      // (3, 4 rows: two items per workgroup)
+    WM_REQUIRE(n_wg >= p.rows * p.self_heads + cross_wgs, "gemv_chain: %d workgroups for the attention stages of %d rows", n_wg, p.rows);
     WM_REQUIRE(hs[p.cross_at].mode == 0 && p.cross_Tk >= 1 && p.cross_heads * 64 == hs[p.cross_at].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
     const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
     WM_REQUIRE(per_split <= CHAIN_CROSS_KEYS, "gemv_chain: %d keys per piece", per_split);
-    const size_t dyn = (size_t)2 * per_split * 128 + 1024;
-    WM_REQUIRE(dyn <= CHAIN_DYN_LDS, "gemv_chain: cross-attention pieces of %d keys do not fit LDS", per_split);
-    widest = widest > p.rows * p.cross_heads * p.cross_nsplit ? widest : p.rows * p.cross_heads * p.cross_nsplit;
+    const size_t dyn = p.rows > 2 ? CHAIN_DYN_LDS4 : (size_t)2 * per_split * 128 + 1024;
+    WM_REQUIRE(dyn <= CHAIN_DYN_LDS && (p.rows <= 2 || per_split <= 384), "gemv_chain: cross-attention pieces of %d keys do not fit", per_split);
+    widest = widest > cross_wgs ? widest : cross_wgs;
     WM_REQUIRE(n_wg >= widest, "gemv_chain: %d workgroups for stages that need %d", n_wg, widest);
     if (chain_set_lds_attribute()) return 2;
     chain_pick(p.w8, p.self_i8 != 0, p.rows, [&](auto* k) { hipLaunchKernelGGL(k, dim3(n_wg), dim3(512), dyn, stream, p); return 0; });

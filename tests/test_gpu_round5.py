@@ -247,6 +247,58 @@ def test_two_row_step_equals_the_launch_per_kernel_path(lib, tmp_path_factory, c
         del solo
 
 
+@pytest.mark.parametrize("rows", [3, 4])
+@pytest.mark.parametrize("model,weight_only,int8_kv", [("micro-fullvocab", False, False), ("micro-fullvocab", True, True), ("tiny", True, False),
+                                                        ("tiny", "int4", True), ("large-v2-6layer", True, True), ("large-v2-6layer", False, False)])
+def test_three_and_four_row_steps_equal_the_launch_per_kernel_path(lib, tmp_path_factory, chain_rearmed, model, weight_only, int8_kv, rows):
+    """Round 5: groups of THREE and FOUR rows take the one-launch forms (gemv_chain_kernel<.., NR = 4>: the Linear stages carry the rows
+    in the MFMA's A operand, the cross-attention's (row, head, piece) items run two per workgroup with their K / V rows in registers).
+    Token ids, log-probabilities and the whole KV cache are IDENTICAL to a launch per kernel in the three forms, eagerly and under
+    graph replay; no workgroup gave up a wait; each utterance's tokens are the ones it gets alone.  (4-bit weights keep the
+    launch-per-kernel path at three and four rows: asserted too.)"""
+    from test_gpu_model import build_engine
+    if model not in synthetic.DIMS:
+        pytest.skip(f"no synthetic model {model}")
+    tmp = tmp_path_factory.mktemp(f"chain{rows}")
+    dims = Dims(**synthetic.DIMS[model])
+    kv_scales = [0.05 + 0.01 * i for i in range(dims.n_text_layer)] if int8_kv else None
+    eng = build_engine(tmp, model, 3, weight_only, int8_kv, kv_scales)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(rows, 2 * dims.n_audio_ctx, dims.n_mels, 83).cuda())
+    takes_chain = weight_only != "int4"
+    outs = []
+    for on in (0, 1, 2):
+        lib.wm_set_decode_chain(on)
+        dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
+        dec.detect_language(xa)
+        for use_graphs in (False, True):
+            dec.use_graphs = use_graphs
+            for st in dec._state.values():
+                st['graphs'].clear()
+            before = native.chain_status()["launches"]
+            t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+            assert (native.chain_status()["launches"] > before) == (on > 0 and takes_chain), (on, use_graphs)
+            outs.append((on, use_graphs, t.cpu(), lp.cpu(), [c.clone() for c in dec._state[rows]['kv']]))
+        del dec
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"], st_
+    ref = outs[0]
+    for on, use_graphs, t, lp, kv in outs[1:]:
+        assert torch.equal(t, ref[2]), (on, use_graphs)
+        assert torch.equal(lp, ref[3]), (on, use_graphs)
+        for a, b in zip(kv, ref[4]):
+            assert torch.equal(a, b), (on, use_graphs)
+    assert len(set(ref[2][0, 3:].tolist())) > 3 and not torch.equal(ref[3][0], ref[3][rows - 1])      # (different utterances: different log-probabilities)
+    lib.wm_set_decode_chain(2)
+    for b in (0, rows - 1):                                                    # alone: the one-row launch
+        solo = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
+        xb = xa[b:b + 1].contiguous()
+        solo.detect_language(xb)
+        t1, lp1, _ = solo.main_loop(xb, ignore_eot=True)
+        assert torch.equal(t1[0].cpu(), ref[2][b]) and torch.equal(lp1[0].cpu(), ref[3][b]), b
+        del solo
+
+
 # ------------------------------------------------------------------------------------------ hardening
 def test_one_launch_step_is_declined_on_a_cu_masked_stream(lib, tmpdir_module, chain_rearmed):
     """A stream whose CU mask leaves it fewer CUs than the device has cannot hold the step's workgroups together: the library looks
