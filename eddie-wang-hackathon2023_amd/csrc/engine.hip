@@ -577,7 +577,8 @@ struct DecWs { h16 *x, *xn, *ctx, *hid; float* part; float* cross_ws; size_t par
 int cross_nsplit(int B, int H) {
     // Pieces the key range of the decode cross-attention is cut into (one workgroup per (utterance, head, piece), partial
     // softmaxes merged by attn_cross_combine_kernel).  TWO classes only, by the number of (utterance, head) pairs of the group:
-    // fewer than 160 pairs (8 utterances of large-v2) -> 4 pieces, otherwise the exact single pass without a merge launch.
+    // up to 160 pairs (8 utterances of large-v2; round 5: 8 included, so that the one-launch step of up to eight rows has ONE form of the
+    // cross-attention to reproduce -- r3au below: 2.15 / 2.13 ms with 1 / 4 pieces at 8 utterances) -> 4 pieces, otherwise the exact single pass without a merge launch.
     // Within a class a row's result does not depend on the batch it is in.  Rounds 1-3 used ceil(512 / pairs) <= 8 pieces
     // ("two workgroups per CU"): 8 different counts below 26 utterances, i.e. 8 different roundings of the merged softmax,
     // and no faster -- forced counts, token step in ms (profiles/r3au_cross_nsplit_forced.txt): 1 utterance 1.74 /
@@ -588,7 +589,7 @@ int cross_nsplit(int B, int H) {
     if (forced == -1) return B * H >= 512 ? 1 : 8;
     if (forced == -2) { int n = (512 + B * H - 1) / (B * H); return n < 1 ? 1 : (n > 8 ? 8 : n); }
     if (forced > 0) return forced > 8 ? 8 : forced;
-    return B * H < 160 ? 4 : 1;
+    return B * H <= 160 ? 4 : 1;
 }
 
 DecWs carve_decoder(const wm_engine* e, int B, int L, void* ws) {
@@ -760,7 +761,7 @@ int self_attn_waves(int rows) {
     return w ? w : (rows <= small_path_max_rows() ? 4 : 1);
 }
 
-// rows (utterances) of a group the one-launch step serves: CHAIN_MAX_ROWS (4) unless WM_CHAIN_ROWS=n keeps it to fewer (lab: A/B runs)
+// rows (utterances) of a group the one-launch step serves: CHAIN_MAX_ROWS (8) unless WM_CHAIN_ROWS=n keeps it to fewer (lab: A/B runs)
 int chain_max_rows() {
     static const int r = [] { const int v = lab_env_int("WM_CHAIN_ROWS", CHAIN_MAX_ROWS); return v < 1 ? 1 : (v > CHAIN_MAX_ROWS ? CHAIN_MAX_ROWS : v); }();
     return r;
@@ -840,7 +841,8 @@ struct GroupStep {
             chain_wgs = n_cu > 256 ? 256 : n_cu; chain_err = cd.err_dev; chain_cd = &cd;
             bool ok = gemv_chain_supports(C, e->dec[0].qkv.wcode, n_cu) && w.nsplit == 4 && !e->i8cross() && self_attn_waves(M) == 4 &&
                       io->present_capacity <= 512 && !(M > 2 && e->dec[0].qkv.wcode == 4) &&
-                      M * H + (M > 2 ? (M * H * w.nsplit + 1) / 2 : M * H * w.nsplit) <= chain_wgs;      // (3, 4 rows: two cross-attention items per workgroup)
+                      (M > 4 ? (M * H <= chain_wgs && M * H * w.nsplit <= 4 * chain_wgs)                   // (5-8 rows: two items per workgroup and round, <= 2 rounds, beside the self-attention's heads)
+                             : M * H + (M > 2 ? (M * H * w.nsplit + 1) / 2 : M * H * w.nsplit) <= chain_wgs);      // (3, 4 rows: two cross-attention items per workgroup)
             for (int i = 0; ok && i < e->dims.n_text_layer; ++i)
                 ok = io->present[i] && io->cross[i] &&
                      (T == 0 ? io->n_past_dev == nullptr : (io->past[i] == io->present[i] && io->past_capacity == io->present_capacity));

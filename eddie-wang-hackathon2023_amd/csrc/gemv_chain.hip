@@ -214,6 +214,10 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     // waves which carry LDS-DMA requests for a later stage (the cross-attention's K / V rows) are not made to wait for them here
     if (!has_group) {
         if (!LN && !WIDE && in_kind == CHAIN_IN_LDS && (int)blockIdx.x < st.n_blocks) chain_merge_tagged<NR>(p, tag, s_in);      // (all eight waves merge)
+        if constexpr (LN && NR == 8) {               // rows 4-7 are normalised by waves 4-7 -- this slot's, when the workgroup's other slot has a group
+            if ((int)blockIdx.x < st.n_blocks && wid < R)
+                chain_ln_row(p, st, p.x + wid * st.K, p.gran_x + wid * (st.K >> 1), epoch - 1, x_in_granules, chain_in_row<NR, WIDE, true>(s_in, 0, wid), lane);
+        }
         const int nbar = LN ? 3 : 2;
         for (int b = 0; b < nbar; ++b) __syncthreads();
         if (st.mode == 2) own_valid = true;
@@ -286,32 +290,40 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         // load of every pass re-read one granule 64 times)
         constexpr int NLR = (TB * KT / 4 <= 128) ? 2 : 3;                     // loads per lane, slice and row
         const int in_stride = st.K >> 1;                                      // granules between the rows of the stage's input
-        int first[NS * NR * NLR];
-        u32x4 val[NS * NR * NLR];
+        constexpr int RP = NR > 4 ? 4 : NR, NPASS = NR / RP;                  // rows per pass (NR == 8: two passes of four rows -- 16 loads in flight each)
         int n_ld[NS];
         bool any = false;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            const int n_in = (t_end[j] - t_begin[j]) * KT;                    // halves of this slice (0: absent)
-            const int g0 = t_begin[j] * KT / 2;                               // first granule
-            n_ld[j] = n_in / 4;                                               // 16-byte loads (4 halves each)
+            n_ld[j] = (t_end[j] - t_begin[j]) * KT / 4;                       // 16-byte loads (4 halves each) of this slice (0: absent)
             any |= n_ld[j] > 0;
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-#pragma unroll
-                for (int k = 0; k < NLR; ++k) first[(j * NR + r) * NLR + k] = min(r, R - 1) * in_stride + g0 + 2 * min(lane + 64 * k, max(n_ld[j] - 1, 0));      // (a row that does not exist: the last one again)
         }
-        const bool ok = any && sweep_granules16<NS * NR * NLR>(gran, first, tag, val, p.err, lane);      // (an absent slice re-reads granules of the stage's first tile)
-        if (ok) {
 #pragma unroll
-            for (int j = 0; j < NS; ++j)
+        for (int ps = 0; ps < NPASS; ++ps) {
+            if (ps * RP >= R) break;                                          // (uniform) rows that do not exist
+            int first[NS * RP * NLR];
+            u32x4 val[NS * RP * NLR];
 #pragma unroll
-                for (int r = 0; r < NR; ++r)
+            for (int j = 0; j < NS; ++j) {
+                const int g0 = t_begin[j] * KT / 2;                           // first granule
+#pragma unroll
+                for (int r = 0; r < RP; ++r)
 #pragma unroll
                     for (int k = 0; k < NLR; ++k)
-                        if (lane + 64 * k < n_ld[j])
-                            *(uint2*)(chain_in_row<NR, WIDE, false>(s_in, slot, r) + t_begin[j] * KT + (lane + 64 * k) * 4) =
-                                make_uint2(val[(j * NR + r) * NLR + k].x, val[(j * NR + r) * NLR + k].z);
+                        first[(j * RP + r) * NLR + k] = min(ps * RP + r, R - 1) * in_stride + g0 + 2 * min(lane + 64 * k, max(n_ld[j] - 1, 0));      // (a row that does not exist: the last one again)
+            }
+            const bool ok = any && sweep_granules16<NS * RP * NLR>(gran, first, tag, val, p.err, lane);      // (an absent slice re-reads granules of the stage's first tile)
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int r = 0; r < RP; ++r)
+#pragma unroll
+                        for (int k = 0; k < NLR; ++k)
+                            if (lane + 64 * k < n_ld[j])
+                                *(uint2*)(chain_in_row<NR, WIDE, false>(s_in, slot, ps * RP + r) + t_begin[j] * KT + (lane + 64 * k) * 4) =
+                                    make_uint2(val[(j * RP + r) * NLR + k].x, val[(j * RP + r) * NLR + k].z);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave's LDS writes before its reads
 #pragma unroll
@@ -377,7 +389,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
     // ---- 4. epilogue of the slot (row 0 sits in the lanes of the first 16-lane group, element 0 of the accumulator; row 1 in element
     // 1): gemv_small's, the result published as granules for the stages behind it.  Wave r of the slot finishes row r: at two rows the
     // epilogues run side by side (one wave doing both in turn cost the two-row step ~ 2 us per layer, profiles/r5q_*_b2) ---------------
-    if (wslot < R && has_group) {
+    if (wslot < (NR == 8 ? 4 : R) && has_group) {
         // (the slices' sums are READ first -- all in flight -- and added afterwards in slice order: read and added one by one they were up to
         // sixteen dependent LDS round trips: the wide stage's epilogue 0.85 -> 0.66 us, profiles/r5v_*)
         constexpr int MAXS = WIDE ? 16 : 4;
@@ -393,10 +405,12 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
             }
         const float bias = has_bias ? (float)bias_raw : 0.f;
         {
-            const int r = NR == 1 ? 0 : wslot;                // (wave-uniform)
+            // (NR <= 4: wave-uniform.  NR == 8: rows 4-7 sit in the second 16-lane group, same accumulator element: lanes 16-31 finish row wslot + 4)
+            const int r = NR == 1 ? 0 : (NR == 8 ? wslot + 4 * min(g, 1) : wslot);
+            const bool live = NR == 8 ? (g < 2 && r < R) : g == 0;
             const float y = NR == 1 ? sum[0] : (NR == 2 ? (wslot == 0 ? sum[0] : sum[1]) : (wslot < 2 ? (wslot == 0 ? sum[0] : sum[1]) : (wslot == 2 ? sum[2] : sum[3])));      // row r; the lanes beyond the first 16 hold rows that do not exist
             if (st.mode == 0) {
-                if (g == 0) {
+                if (live) {
                     p.out32[r * n_out + col] = y;             // raw sums for the attention kernel of the next launch
                     unsigned long long* gq = s == p.cross_at ? p.gran_q : p.gran_s;      // ... or of this launch's attention stages: cross (q) | self (q, k, v of the next layer)
                     if (gq)
@@ -409,14 +423,14 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
                 if (st.mode == 1) {
                     out = (h16)(p.gelu_kind == 2 ? gelu_tanh(y16) : gelu_erf(y16));
                 } else {                                      // mode 2: the residual stream, this slot's 16 channels
-                    const h16 xo = own_valid ? s_own[slot * NR + r][rl] : p.x[r * n_out + col];
+                    const h16 xo = own_valid ? s_own[slot * NR + r][rl] : p.x[(NR == 8 ? min(r, R - 1) : r) * n_out + col];
                     out = (h16)r16((float)xo + y16);
-                    if (g == 0) { s_own[slot * NR + r][rl] = out; p.x[r * n_out + col] = out; }
+                    if (live) { s_own[slot * NR + r][rl] = out; p.x[r * n_out + col] = out; }
                 }
                 // two channels per granule: the even lane stores {epoch, own | neighbour << 16}
                 const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, out);
                 const unsigned nb_bits = __shfl_xor(bits, 1);
-                if (g == 0 && (rl & 1) == 0) {
+                if (live && (rl & 1) == 0) {
                     unsigned long long* dst = (st.mode == 1 ? p.gran_h : p.gran_x) + r * (n_out >> 1) + (col >> 1);
                     __hip_atomic_store((chain_gu64*)dst, ((unsigned long long)epoch << 32) | (bits | (nb_bits << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -436,6 +450,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
 constexpr int CHAIN_CROSS_KEYS = 1536;
 constexpr size_t CHAIN_DYN_LDS = 100 * 1024;      // K and V rows of a piece (beside ~ 60 KB of static LDS, of 160)
 constexpr size_t CHAIN_DYN_LDS4 = 64 * 1024;      // 3 and 4 rows: the self-attention's cached rows only (beside ~ 85 KB of static LDS)
+constexpr size_t CHAIN_DYN_LDS8 = 24 * 1024;      // 5 to 8 rows: the same beside ~ 128 KB (longer caches are read from memory inside the stage)
 constexpr int CHAIN_MAX_LAYERS = 32;               // layers of a whole-step launch (their descriptors and tables sit in LDS; Whisper large has 32)
 // what the attention stages take per LAYER (kernel arguments for a one-layer launch, the two tables in a whole-step launch)
 struct ChainLayerArgs { const h16* cross_kv; const h16* cross_qbias; void* self_cache; const h16* self_bias; float self_kv_scale; };
@@ -643,13 +658,15 @@ __device__ __forceinline__ void chain_cross_stage4(const GemvChainParams& p, con
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wid >> 2, wq = wid & 3, tl = tid & 255;
     const int per_row = p.cross_heads * p.cross_nsplit, n_items = p.rows * per_row;
-    const int n_wgs = (n_items + 1) >> 1;
+    const int rounds = (n_items + 511) >> 9;       // items beyond two per workgroup of the launch: a second round (5-8 rows of large-v2: 7, 8)
+    const int n_wgs = (n_items + 2 * rounds - 1) / (2 * rounds);
     const int wg = (int)blockIdx.x - ((int)gridDim.x - n_wgs);
-    if (wg < 0) {                                  // (workgroup-uniform) no items here: the stage's four barriers, nothing requested
-        for (int b = 0; b < 4; ++b) __syncthreads();
+    if (wg < 0) {                                  // (workgroup-uniform) no items here: the stage's barriers, nothing requested
+        for (int b = 0; b < 5 * rounds - 1; ++b) __syncthreads();
         return;
     }
-    const int item = 2 * wg + half;
+    for (int rd = 0; rd < rounds; ++rd) {
+    const int item = 2 * (rd * n_wgs + wg) + half;
     const bool has_item = item < n_items;
     const int urow = has_item ? item / per_row : 0, rem = has_item ? item - urow * per_row : 0;
     const int h = rem % p.cross_heads, sp = rem / p.cross_heads;
@@ -797,6 +814,8 @@ __device__ __forceinline__ void chain_cross_stage4(const GemvChainParams& p, con
         const float v = s_o[4 * half][tl] + s_o[4 * half + 1][tl] + s_o[4 * half + 2][tl] + s_o[4 * half + 3][tl];
         put(2 + tl, v);
         if (tl == 0) { put(0, gmax); put(1, gsum); }
+    }
+    if (rd + 1 < rounds) __syncthreads();                                      // (E) s_sc / s_o / s_q are the next round's
     }
 }
 
@@ -1117,8 +1136,8 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char kv_lds[];      // the cross-attention stage's K and V rows (only then)
     __shared__ float s_sc[CHAIN_CROSS_KEYS];
     __shared__ float s_redc[8][2];
-    __shared__ float s_o[NR == 4 ? 8 : 4][64];
-    __shared__ float s_q[NR == 4 ? 2 : 1][64];
+    __shared__ float s_o[NR >= 4 ? 8 : 4][64];
+    __shared__ float s_q[NR >= 4 ? 2 : 1][64];
     // The WHOLE token step in one launch (p.n_layers > 0): the launch walks over the layers itself.  Per-layer pointers come from two
     // tables (the engine's: biases and the cache scale; the caller's, in the workspace: cross K/V and cache of each layer), the
     // descriptors are [qkv of layer 0] + 6 per layer, and "layer -1" is that first projection alone (its sums go out as granules,
@@ -1149,12 +1168,14 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     // (3 and 4 rows: the cross-attention's rows go from memory to registers inside its stage, two items per workgroup -- chain_cross_stage4)
     if constexpr (NR <= 2) chain_cross_prefetch<NR>(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
     const int R = NR == 1 ? 1 : p.rows;
-    const int n_cross_wgs = NR == 4 ? (R * p.cross_heads * p.cross_nsplit + 1) / 2 : NR * p.cross_heads * p.cross_nsplit;      // one (row, head, piece) each | two
+    const int cross_items = R * p.cross_heads * p.cross_nsplit, cross_rounds = (cross_items + 511) >> 9;
+    const int n_cross_wgs = NR >= 4 ? (cross_items + 2 * cross_rounds - 1) / (2 * cross_rounds) : NR * p.cross_heads * p.cross_nsplit;      // two items each (and round) | one
     const int n_self_wgs = R * p.self_heads;                                                                                   // one (row, head) each
-    const int kv_avail = NR == 4 ? (int)CHAIN_DYN_LDS4 - 1024 : 2 * per_split * 128;      // dynamic LDS the self-attention's cached rows may take
+    const int kv_avail = NR >= 4 ? (int)(NR == 4 ? CHAIN_DYN_LDS4 : CHAIN_DYN_LDS8) - 1024 : 2 * per_split * 128;      // dynamic LDS the self-attention's cached rows may take
     const int self_base = max((int)gridDim.x - n_cross_wgs - n_self_wgs, 0);
     const int self_idx = (int)blockIdx.x - self_base;                    // this workgroup's self-attention (row, head), if 0 <= self_idx < rows x heads
-    const bool self_wg = self_idx >= 0 && self_idx < n_self_wgs && (int)blockIdx.x < (int)gridDim.x - n_cross_wgs;
+    // (NR == 8: a workgroup may carry a self-attention head AND cross-attention items -- different stages; nothing of the latter lives in the dynamic LDS)
+    const bool self_wg = self_idx >= 0 && self_idx < n_self_wgs && (NR == 8 || (int)blockIdx.x < (int)gridDim.x - n_cross_wgs);
     const int self_h = self_wg ? self_idx % p.self_heads : 0, self_r = self_wg ? self_idx / p.self_heads : 0;
     const size_t self_row_off = (size_t)self_r * p.self_row_bytes;       // this row's share of a layer's cache
     int self_v_off = 0;                                                  // > 0: the head's cached rows of the NEXT self-attention stage are (on their way) in LDS
@@ -1204,7 +1225,7 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             else chain_stage<WB, false, false, NR>(p, st, s, epoch, own_valid, s_red, s_in, s_own, in_kind, gran, tag, x_in_granules);
             if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
             if (l >= 0 && s == p.cross_at) {
-                if constexpr (NR == 4) {
+                if constexpr (NR >= 4) {
                     chain_cross_stage4(p, la, epoch, per_split, s_sc, s_redc, s_o, s_q);
                 } else {
                     chain_cross_stage<NR>(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q[0]);
@@ -1245,6 +1266,13 @@ static int chain_set_lds_attribute() {
         return f(gemv_chain_kernel<16, true, 4>);
     };
     if (each_kernel4([&](auto* k) -> int { WM_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_DYN_LDS4)); return 0; })) return 2;
+    auto each_kernel8 = [&](auto&& f) -> int {       // 5 to 8 rows
+        if (int rc = f(gemv_chain_kernel<8, false, 8>)) return rc;
+        if (int rc = f(gemv_chain_kernel<8, true, 8>)) return rc;
+        if (int rc = f(gemv_chain_kernel<16, false, 8>)) return rc;
+        return f(gemv_chain_kernel<16, true, 8>);
+    };
+    if (each_kernel8([&](auto* k) -> int { WM_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_DYN_LDS8)); return 0; })) return 2;
     attr_set.fetch_or(bit, std::memory_order_release);
     return 0;
 }
@@ -1255,6 +1283,10 @@ static int chain_set_lds_attribute() {
 // every instantiation by its run-time selectors
 template <typename F>
 static auto chain_pick(int w8, bool i8, int rows, F&& f) {
+    if (rows > 4) {
+        if (w8) return i8 ? f(gemv_chain_kernel<8, true, 8>) : f(gemv_chain_kernel<8, false, 8>);
+        return i8 ? f(gemv_chain_kernel<16, true, 8>) : f(gemv_chain_kernel<16, false, 8>);
+    }
     if (rows > 2) {                                  // (4-bit weights: one or two rows only -- the callers check)
         if (w8) return i8 ? f(gemv_chain_kernel<8, true, 4>) : f(gemv_chain_kernel<8, false, 4>);
         return i8 ? f(gemv_chain_kernel<16, true, 4>) : f(gemv_chain_kernel<16, false, 4>);
@@ -1274,7 +1306,7 @@ int gemv_chain_resident(int w8, int self_i8, int rows, int cross_Tk, int cross_n
     WM_REQUIRE(cross_nsplit >= 1 && cross_Tk >= 1 && n_wg >= 1 && n_cu >= 1, "gemv_chain_resident: bad arguments");
     WM_REQUIRE(rows >= 1 && rows <= CHAIN_MAX_ROWS && !(rows > 2 && w8 == 4), "gemv_chain_resident: rows=%d (w8=%d)", rows, w8);
     const int per_split = (((cross_Tk + cross_nsplit - 1) / cross_nsplit) + 7) & ~7;
-    const size_t dyn = rows > 2 ? CHAIN_DYN_LDS4 : (size_t)2 * per_split * 128 + 1024;
+    const size_t dyn = rows > 4 ? CHAIN_DYN_LDS8 : (rows > 2 ? CHAIN_DYN_LDS4 : (size_t)2 * per_split * 128 + 1024);
     if (rows > 2 && per_split > 384) { if (why) snprintf(why, why_cap, "cross-attention pieces of %d keys exceed the 3- and 4-row stage's 384", per_split); return 0; }
     if (dyn > CHAIN_DYN_LDS) { if (why) snprintf(why, why_cap, "cross-attention pieces of %d keys do not fit LDS", per_split); return 0; }
     if (chain_set_lds_attribute()) return 2;
@@ -1357,12 +1389,14 @@ int launch_gemv_chain(const GemvChainParams& p, const ChainStage* hs_all, int n_
                "gemv_chain: self-attention stage: bad arguments");
     WM_REQUIRE(p.rows >= 1 && p.rows <= CHAIN_MAX_ROWS && !(p.rows > 2 && p.w8 == 4), "gemv_chain: rows=%d (one to four activation rows; 4-bit weights: one or two)", p.rows);
     WM_REQUIRE(p.rows == 1 || (p.cross_row_bytes > 0 && p.self_row_bytes > 0), "gemv_chain: several rows need the strides between their cross K/V and caches");
-    const int cross_wgs = p.rows > 2 ? (p.rows * p.cross_heads * p.cross_nsplit + 1) / 2 : p.rows * p.cross_heads * p.cross_nsplit;      // (3, 4 rows: two items per workgroup)
-    WM_REQUIRE(n_wg >= p.rows * p.self_heads + cross_wgs, "gemv_chain: %d workgroups for the attention stages of %d rows", n_wg, p.rows);
+    const int cross_items = p.rows * p.cross_heads * p.cross_nsplit, cross_rounds = (cross_items + 511) >> 9;
+    const int cross_wgs = p.rows > 2 ? (cross_items + 2 * cross_rounds - 1) / (2 * cross_rounds) : cross_items;      // (3 rows and more: two items per workgroup and round)
+    WM_REQUIRE(p.rows > 4 ? (n_wg >= p.rows * p.self_heads && n_wg >= cross_wgs) : n_wg >= p.rows * p.self_heads + cross_wgs,
+               "gemv_chain: %d workgroups for the attention stages of %d rows", n_wg, p.rows);
     WM_REQUIRE(hs[p.cross_at].mode == 0 && p.cross_Tk >= 1 && p.cross_heads * 64 == hs[p.cross_at].n_blocks * 16, "gemv_chain: cross-attention stage: bad arguments");
     const int per_split = (((p.cross_Tk + p.cross_nsplit - 1) / p.cross_nsplit) + 7) & ~7;
     WM_REQUIRE(per_split <= CHAIN_CROSS_KEYS, "gemv_chain: %d keys per piece", per_split);
-    const size_t dyn = p.rows > 2 ? CHAIN_DYN_LDS4 : (size_t)2 * per_split * 128 + 1024;
+    const size_t dyn = p.rows > 4 ? CHAIN_DYN_LDS8 : (p.rows > 2 ? CHAIN_DYN_LDS4 : (size_t)2 * per_split * 128 + 1024);
     WM_REQUIRE(dyn <= CHAIN_DYN_LDS && (p.rows <= 2 || per_split <= 384), "gemv_chain: cross-attention pieces of %d keys do not fit", per_split);
     widest = widest > cross_wgs ? widest : cross_wgs;
     WM_REQUIRE(n_wg >= widest, "gemv_chain: %d workgroups for stages that need %d", n_wg, widest);

@@ -75,7 +75,7 @@ int launch_gemv_small(const GemvSmallParams& p, hipStream_t stream);
 // A chain of gemv_small Linears at ONE activation row in one launch (batch 1): stage inputs / outputs between the stages travel
 // as {epoch, value} granules, the first stage reads plain memory, mode-0 results and the residual row go back to plain memory.
 constexpr int CHAIN_MAX_STAGES = 6;
-constexpr int CHAIN_MAX_ROWS = 4;            // activation rows one launch serves (gemv_chain.hip: kernels for 1, 2 and 3-4 rows)
+constexpr int CHAIN_MAX_ROWS = 8;            // activation rows one launch serves (gemv_chain.hip: kernels for 1, 2, 3-4 and 5-8 rows)
 constexpr int DECODE_CHAIN_DEFAULT = 2;      // one-row groups: 0 a launch per kernel, 1 one launch per decoder layer, 2 one per token step
 struct ChainStage {                                           // (an engine keeps its layers' stages in DEVICE memory: a chain's
     const void* Wt; const h16* scale; const h16* bias;         // arguments stay small -- by value they were 330 bytes, and the runtime

@@ -503,7 +503,7 @@ class WhisperDecoding:
             n_audio, dev = audio_features.shape[0], audio_features.device
             cfg = self.decoder_config
             st = self._fast_state(n_audio, dev)
-            one_row = any(hi - lo <= 4 for lo, hi in self._groups(n_audio)[1])      # groups of up to four rows may run as ONE launch per step
+            one_row = any(hi - lo <= 8 for lo, hi in self._groups(n_audio)[1])      # groups of up to eight rows may run as ONE launch per step
             if one_row and native.chain_status()["error_pending"]:                  # (a peek at a host word: no synchronisation)
                 self._chain_gave_up("found before the language pass")               # somebody else's give-up: acknowledged, not ours to repeat
             cross = self._cross_persistent(audio_features, st)
@@ -833,7 +833,7 @@ class WhisperDecoding:
         cfg = self.decoder_config
         V, cap = cfg['vocab_size'], cfg['num_text_ctx']
         st = self._fast_state(n_batch, dev)
-        one_row = any(hi - lo <= 4 for lo, hi in self._groups(n_batch)[1])      # groups of up to four rows may run as ONE launch per token step
+        one_row = any(hi - lo <= 8 for lo, hi in self._groups(n_batch)[1])      # groups of up to eight rows may run as ONE launch per token step
         if one_row and not _retry and native.chain_status()["error_pending"]:   # (a peek at a host word: no synchronisation)
             self._chain_gave_up("found before the decode loop")                 # somebody else's give-up: acknowledged, not ours to repeat
         if self.options.temperature != 0:     # a fresh seed per call from torch's generator: torch.manual_seed makes a run repeatable

@@ -247,15 +247,16 @@ def test_two_row_step_equals_the_launch_per_kernel_path(lib, tmp_path_factory, c
         del solo
 
 
-@pytest.mark.parametrize("rows", [3, 4])
+@pytest.mark.parametrize("rows", [3, 4, 5, 7, 8])
 @pytest.mark.parametrize("model,weight_only,int8_kv", [("micro-fullvocab", False, False), ("micro-fullvocab", True, True), ("tiny", True, False),
                                                         ("tiny", "int4", True), ("large-v2-6layer", True, True), ("large-v2-6layer", False, False)])
-def test_three_and_four_row_steps_equal_the_launch_per_kernel_path(lib, tmp_path_factory, chain_rearmed, model, weight_only, int8_kv, rows):
-    """Round 5: groups of THREE and FOUR rows take the one-launch forms (gemv_chain_kernel<.., NR = 4>: the Linear stages carry the rows
-    in the MFMA's A operand, the cross-attention's (row, head, piece) items run two per workgroup with their K / V rows in registers).
+def test_three_to_eight_row_steps_equal_the_launch_per_kernel_path(lib, tmp_path_factory, chain_rearmed, model, weight_only, int8_kv, rows):
+    """Round 5: groups of THREE to EIGHT rows take the one-launch forms (gemv_chain_kernel<.., NR = 4 | 8>: the Linear stages carry the
+    rows in the MFMA's A operand, the cross-attention's (row, head, piece) items run two per workgroup -- in two rounds at 7 and 8 rows
+    of a 20-head model -- with their K / V rows in registers).
     Token ids, log-probabilities and the whole KV cache are IDENTICAL to a launch per kernel in the three forms, eagerly and under
-    graph replay; no workgroup gave up a wait; each utterance's tokens are the ones it gets alone.  (4-bit weights keep the
-    launch-per-kernel path at three and four rows: asserted too.)"""
+    graph replay; no workgroup gave up a wait; up to four rows each utterance's tokens are the ones it gets alone.  (4-bit weights keep the
+    launch-per-kernel path from three rows on: asserted too.)"""
     from test_gpu_model import build_engine
     if model not in synthetic.DIMS:
         pytest.skip(f"no synthetic model {model}")
@@ -290,7 +291,9 @@ def test_three_and_four_row_steps_equal_the_launch_per_kernel_path(lib, tmp_path
             assert torch.equal(a, b), (on, use_graphs)
     assert len(set(ref[2][0, 3:].tolist())) > 3 and not torch.equal(ref[3][0], ref[3][rows - 1])      # (different utterances: different log-probabilities)
     lib.wm_set_decode_chain(2)
-    for b in (0, rows - 1):                                                    # alone: the one-row launch
+    # alone: the one-row launch.  (Up to four rows: from five on the 3-token prefill -- 3 x rows activation rows -- and the vocabulary projection
+    # leave the <= 16-row kernels whose per-row arithmetic does not depend on the batch, on EVERY path: a different class)
+    for b in ((0, rows - 1) if rows <= 4 else ()):
         solo = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
         xb = xa[b:b + 1].contiguous()
         solo.detect_language(xb)
