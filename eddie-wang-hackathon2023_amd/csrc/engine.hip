@@ -883,6 +883,7 @@ struct GroupStep {
         p.x = w.x; p.gran_x = w.gran_x; p.gran_h = w.gran_h; p.err = chain_err;
         p.generation = w.generation;
         p.rows = M;                                   // (L == 1: one row per utterance; the utterances' buffers are slices of [B, 2, H, T, 64])
+        p.live = io->live_rows;                       // rows still decoding (optional): the others' attention stages read and append nothing
         p.cross_row_bytes = (long)2 * H * d.n_audio_ctx * 64 * 2;
         p.self_row_bytes = (long)2 * H * io->present_capacity * 64 * (e->i8kv() ? 1 : 2);
     }

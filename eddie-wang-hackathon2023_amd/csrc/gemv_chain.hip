@@ -458,7 +458,7 @@ constexpr float CHAIN_ATTN_SCALE = 0.35355339059327373f;    // 64^-0.25 (attn_de
 constexpr unsigned CHAIN_EPOCH_LIVE = 0x80000000u;
 
 template <int NR>
-__device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, const void* cross_kv, unsigned char* kv_lds, int per_split) {
+__device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, const void* cross_kv, unsigned char* kv_lds, int per_split, unsigned dead) {
     // waves 4-7: this workgroup's piece of K, then of V, as 1 KiB pieces (8 rows of 128 B) into LDS, linear
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per_row = p.cross_heads * p.cross_nsplit, n_items = NR * per_row;
@@ -467,7 +467,7 @@ __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, c
     const int urow = NR == 1 ? 0 : item / per_row, rem = NR == 1 ? item : item - urow * per_row;
     const int h = rem % p.cross_heads, sp = rem / p.cross_heads;
     const int k_begin = sp * per_split, nkeys = max(0, min(p.cross_Tk, k_begin + per_split) - k_begin);
-    if (nkeys == 0) return;
+    if (nkeys == 0 || ((dead >> urow) & 1)) return;      // (a finished row's K / V stay where they are)
     const int n_pieces = (nkeys + 7) >> 3;
     for (int m = 0; m < 2; ++m) {
         const unsigned char* src = (const unsigned char*)cross_kv + (size_t)urow * p.cross_row_bytes + ((size_t)(m * p.cross_heads + h) * p.cross_Tk + k_begin) * 128;
@@ -481,7 +481,7 @@ __device__ __forceinline__ void chain_cross_prefetch(const GemvChainParams& p, c
 
 template <int NR>
 __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, const ChainLayerArgs& la, unsigned epoch_q, const unsigned char* kv_lds, int per_split,
-                                                  float* s_sc, float (*s_redc)[2] /* [8] */, float (*s_o)[64], float* s_q) {
+                                                  float* s_sc, float (*s_redc)[2] /* [8] */, float (*s_o)[64], float* s_q, unsigned dead) {
     constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
     constexpr int STRIDE = 4 * RPI * UNR;
     constexpr int KB = 3, KB2 = 2;                 // iterations whose rows are requested together (P.V | scores, a wave's share)
@@ -491,7 +491,8 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
     const bool has_item = item >= 0;
     const int urow = (has_item && NR > 1) ? item / per_row : 0, rem = item - urow * per_row;
     const int h = has_item ? rem % p.cross_heads : 0, sp = has_item ? rem / p.cross_heads : 0;
-    const int k_begin = sp * per_split, nkeys = has_item ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
+    const bool dead_item = has_item && ((dead >> urow) & 1);                                       // a finished row: nothing read, zeros published
+    const int k_begin = sp * per_split, nkeys = (has_item && !dead_item) ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
     const unsigned long long* gran_q = p.gran_q + (size_t)urow * p.cross_heads * 64;              // this row's q sums
     unsigned long long* gran_p = p.gran_p + (size_t)urow * p.cross_heads * 66 * 4;               // ... and its pieces' partial results
     const int sub = lane % LPR, rowi = lane / LPR;
@@ -505,7 +506,8 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
         for (int e = 0; e < DPL; ++e) qb8[e] = hb ? raw[e] : (h16)0.f;
     }
     if (wid >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's K / V pieces have landed
-    if (wid == 0 && has_item) {                                               // the head's 64 q sums, as the last Linear published them
+    if (wid == 0 && has_item) {                                               // the head's 64 q sums, as the last Linear published them (a finished row waits
+                                                                              // for them too: its zeros must not replace the last layer's pieces before those are read)
         int fst[1] = {h * 64 + 2 * min(lane, 31)};
         u32x4 val[1];
         if (sweep_granules16<1>(gran_q, fst, epoch_q, val, p.err, lane) && lane < 32) {
@@ -523,7 +525,8 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     if (has_item && nkeys == 0) {                                              // an empty piece: the neutral element (attn_cross_kernel)
-        if (tid < 66) put(tid, (tid == 0) ? -INFINITY : 0.f);
+        // (a finished row: maximum 0, sum 1 in piece 0 and 0 elsewhere, o = 0 -- the merge then yields a FINITE zero row)
+        if (tid < 66) put(tid, dead_item ? ((tid == 1 && sp == 0) ? 1.f : 0.f) : ((tid == 0) ? -INFINITY : 0.f));
     }
     const unsigned char* K = kv_lds;
     const unsigned char* V = kv_lds + (size_t)per_split * 128;
@@ -651,7 +654,7 @@ __device__ __forceinline__ void chain_cross_stage(const GemvChainParams& p, cons
 // The arithmetic is attn_cross_kernel's, bit for bit: wave w of the item scores rows 32 w + 128 k ..., maxima and sums met in wave order,
 // P.V per lane over its rows in sequence, (max, sum, o[64]) left for the merge as tagged granules.
 __device__ __forceinline__ void chain_cross_stage4(const GemvChainParams& p, const ChainLayerArgs& la, unsigned epoch_q, int per_split,
-                                                   float* s_sc_all /* [2][768] */, float (*s_redc)[2] /* [8] */, float (*s_o)[64] /* [8] */, float (*s_q)[64] /* [2] */) {
+                                                   float* s_sc_all /* [2][768] */, float (*s_redc)[2] /* [8] */, float (*s_o)[64] /* [8] */, float (*s_q)[64] /* [2] */, unsigned dead) {
     constexpr int DPL = 8, LPR = 8, RPI = 8, UNR = 4;
     constexpr int STRIDE = 4 * RPI * UNR;          // 128 rows per iteration of an item's four waves
     constexpr int KB = 3;                          // iterations of a piece (<= 384 keys)
@@ -670,7 +673,8 @@ __device__ __forceinline__ void chain_cross_stage4(const GemvChainParams& p, con
     const bool has_item = item < n_items;
     const int urow = has_item ? item / per_row : 0, rem = has_item ? item - urow * per_row : 0;
     const int h = rem % p.cross_heads, sp = rem / p.cross_heads;
-    const int k_begin = sp * per_split, nkeys = has_item ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
+    const bool dead_item = has_item && ((dead >> urow) & 1);                   // a finished row: nothing read, zeros published
+    const int k_begin = sp * per_split, nkeys = (has_item && !dead_item) ? max(0, min(p.cross_Tk, k_begin + per_split) - k_begin) : 0;
     const bool worker = has_item && nkeys > 0;
     float* s_sc = s_sc_all + half * 768;
     const unsigned long long* gran_q = p.gran_q + (size_t)urow * p.cross_heads * 64;
@@ -704,7 +708,7 @@ __device__ __forceinline__ void chain_cross_stage4(const GemvChainParams& p, con
 #pragma unroll
         for (int e = 0; e < DPL; ++e) qb8[e] = hb ? raw[e] : (h16)0.f;
     }
-    if (wq == 0 && has_item) {                                                  // the head's 64 q sums, as the last Linear published them
+    if (wq == 0 && has_item) {                                                  // the head's 64 q sums, as the last Linear published them (a finished row waits too)
         int fst[1] = {h * 64 + 2 * min(lane, 31)};
         u32x4 val[1];
         if (sweep_granules16<1>(gran_q, fst, epoch_q, val, p.err, lane) && lane < 32) {
@@ -719,8 +723,8 @@ __device__ __forceinline__ void chain_cross_stage4(const GemvChainParams& p, con
         __hip_atomic_store((chain_gu64*)(gran_p + ((size_t)h * 66 + r) * 4 + sp), ((unsigned long long)epoch_q << 32) | __builtin_bit_cast(unsigned, v),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    if (has_item && nkeys == 0) {
-        if (tl < 66) put(tl, (tl == 0) ? -INFINITY : 0.f);
+    if (has_item && nkeys == 0) {                  // an empty piece: the neutral element; a finished row: maximum 0, sum 1 in piece 0, o = 0 (a finite zero row)
+        if (tl < 66) put(tl, dead_item ? ((tl == 1 && sp == 0) ? 1.f : 0.f) : ((tl == 0) ? -INFINITY : 0.f));
     }
     const int nb = (nkeys + STRIDE - 1) / STRIDE;
     float qf[DPL];
@@ -1165,9 +1169,23 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     // self-attention's heads to the ones before them: the first workgroups own the output groups of every n_state-wide Linear (and
     // both slots of the widest), the last ones idle through most stages -- and the four upper waves of a workgroup that carries
     // K / V rows in flight must not meet a stage's "everything of mine has landed" wait before those rows are due.
-    // (3 and 4 rows: the cross-attention's rows go from memory to registers inside its stage, two items per workgroup -- chain_cross_stage4)
-    if constexpr (NR <= 2) chain_cross_prefetch<NR>(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split);
     const int R = NR == 1 ? 1 : p.rows;
+    // rows that have finished (p.live: the list of the ones still decoding): their attention stages read nothing, append nothing to their
+    // cache and publish zeros; one vector load, the words handed round the wave
+    unsigned dead = 0;
+    if (p.live) {
+        const int lv = p.live[min((int)(threadIdx.x & 63), R)];
+        const int n_live = __builtin_amdgcn_readlane(lv, 0);
+        unsigned alive = 0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int idx = __builtin_amdgcn_readlane(lv, 1 + i);
+            if (i < n_live && i < R) alive |= 1u << (idx & 31);
+        }
+        dead = ~alive & ((1u << R) - 1u);
+    }
+    // (3 and more rows: the cross-attention's rows go from memory to registers inside its stage, two items per workgroup -- chain_cross_stage4)
+    if constexpr (NR <= 2) chain_cross_prefetch<NR>(p, whole ? s_lio[0].cross_kv : p.cross_kv, kv_lds, per_split, dead);
     const int cross_items = R * p.cross_heads * p.cross_nsplit, cross_rounds = (cross_items + 511) >> 9;
     const int n_cross_wgs = NR >= 4 ? (cross_items + 2 * cross_rounds - 1) / (2 * cross_rounds) : NR * p.cross_heads * p.cross_nsplit;      // two items each (and round) | one
     const int n_self_wgs = R * p.self_heads;                                                                                   // one (row, head) each
@@ -1179,7 +1197,8 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
     const int self_h = self_wg ? self_idx % p.self_heads : 0, self_r = self_wg ? self_idx / p.self_heads : 0;
     const size_t self_row_off = (size_t)self_r * p.self_row_bytes;       // this row's share of a layer's cache
     int self_v_off = 0;                                                  // > 0: the head's cached rows of the NEXT self-attention stage are (on their way) in LDS
-    if (self_wg) self_v_off = chain_self_prefetch<I8KV>(p, (const unsigned char*)(whole ? s_lio[0].cache : p.self_cache) + self_row_off, T_now, self_h, kv_lds, kv_avail);
+    const bool self_dead = self_wg && ((dead >> self_r) & 1);            // the head's row has finished: no cache append, no attention, zeros published
+    if (self_wg && !self_dead) self_v_off = chain_self_prefetch<I8KV>(p, (const unsigned char*)(whole ? s_lio[0].cache : p.self_cache) + self_row_off, T_now, self_h, kv_lds, kv_avail);
     bool own_valid = false, x_in_granules = false;
     for (int l = whole ? -1 : 0; l < (whole ? p.n_layers : 1); ++l) {
         const unsigned epoch0 = gen | ((unsigned)(whole ? (l & 63) : p.launch_id) << 3);
@@ -1189,7 +1208,21 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             la.cross_kv = (const h16*)li.cross_kv; la.cross_qbias = ls.cq_bias;
             la.self_cache = li.cache; la.self_bias = ls.qkv_bias; la.self_kv_scale = ls.kv_scale;
         }
-        if (l >= 0 && self_wg) {                         // (workgroup-uniform) LDS: the Linears' buffers, not in use now
+        if (l >= 0 && self_dead) {                       // (workgroup-uniform) the head's 64 outputs as zeros, tagged like the stage's own
+            const int lane_ = threadIdx.x;
+            // ... behind the wait the stage itself begins with (the row's q sums of the qkv stage in front): published at once, the zeros of
+            // layer l could replace layer l - 1's outputs before the out projection has read them
+            bool go = true;
+            if (p.gran_s && lane_ < 64) {
+                const unsigned tag_s = (gen | ((unsigned)((l - 1) & 63) << 3)) + 6;
+                int fst[1] = {self_r * 3 * p.self_heads * 64 + self_h * 64 + 2 * min(lane_, 31)};
+                u32x4 val[1];
+                go = sweep_granules16<1>(p.gran_s, fst, tag_s, val, p.err, lane_);
+            }
+            if (go && lane_ < 64 && (lane_ & 1) == 0)
+                __hip_atomic_store((chain_gu64*)(p.gran_c + ((self_r * p.self_heads * 64 + self_h * 64 + lane_) >> 1)), (unsigned long long)epoch0 << 32,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (l >= 0 && self_wg) {                  // (workgroup-uniform) LDS: the Linears' buffers, not in use now
             float* s_p = &s_red[0][0][0];
             h16 (*s_new)[64] = (h16 (*)[64])(&s_red[8][0][0]);
             float (*s_r2)[4] = (float (*)[4])(&s_red[12][0][0]);
@@ -1226,11 +1259,11 @@ __global__ __launch_bounds__(512) void gemv_chain_kernel(GemvChainParams p) {
             if (st.mode == 2) x_in_granules = true;               // the residual row of the stages behind: this launch's granules
             if (l >= 0 && s == p.cross_at) {
                 if constexpr (NR >= 4) {
-                    chain_cross_stage4(p, la, epoch, per_split, s_sc, s_redc, s_o, s_q);
+                    chain_cross_stage4(p, la, epoch, per_split, s_sc, s_redc, s_o, s_q, dead);
                 } else {
-                    chain_cross_stage<NR>(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q[0]);
+                    chain_cross_stage<NR>(p, la, epoch, kv_lds, per_split, s_sc, s_redc, s_o, s_q[0], dead);
                     // the NEXT layer's K / V rows set out now: they have the rest of this layer to arrive
-                    if (whole && l + 1 < p.n_layers) chain_cross_prefetch<NR>(p, s_lio[l + 1].cross_kv, kv_lds, per_split);
+                    if (whole && l + 1 < p.n_layers) chain_cross_prefetch<NR>(p, s_lio[l + 1].cross_kv, kv_lds, per_split, dead);
                 }
             }
         }

@@ -114,6 +114,10 @@ struct GemvChainParams {
     // a batch).  A row's arithmetic does not depend on rows (the MFMA's A rows carry the activation rows alternately).  Two rows put
     // 2 x (heads + heads x pieces) attention workgroups in the launch; the Linear stages cost what they cost at one row.
     int rows; long cross_row_bytes, self_row_bytes;
+    // optional list of the rows still decoding (wm_decoder_io::live_rows: count, then ascending indices): a finished row's attention stages
+    // read nothing and append nothing to its cache -- they publish zeros -- so the step's bytes follow the live rows; a live row's result
+    // does not depend on the list (the Linear stages carry every row regardless)
+    const int32_t* live;
     unsigned* err;                                            // set non-zero when a bounded wait gives up
     const unsigned* generation; int launch_id;                // epochs: (*generation << 10) | (layer or launch_id << 3), + stage + 1 (generation: one per decoder call)
 };

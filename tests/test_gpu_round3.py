@@ -63,12 +63,13 @@ def test_step_finish_builds_the_live_list(lib, n):
 
 
 @pytest.mark.parametrize("small_rows", [0, 8])
-@pytest.mark.parametrize("batch", [6, 40])
+@pytest.mark.parametrize("batch", [2, 4, 6, 8, 40])
 def test_decoder_step_with_live_rows(tmpdir_module, lib, batch, small_rows):
     """One decode step with a list of live rows: their logits and cache rows are bit-identical to the step that runs every
     row (a row's result never depends on which other rows are live), the other rows' KV caches are not touched.  Batch 6
     runs the key-split cross-attention + merge (and, with small_rows = 8, the fused small-batch path), batch 40 the
-    one-workgroup-per-head kernel."""
+    one-workgroup-per-head kernel.  Round 5: with small_rows = 8 the batches up to 8 take the ONE-LAUNCH step (2, 4 and 6 / 8 rows: its three
+    multi-row kernels), whose attention stages skip the finished rows the same way."""
     prev = lib.wm_set_small_batch_rows(small_rows)
     try:
         dims = Dims(**synthetic.DIMS["micro"])
