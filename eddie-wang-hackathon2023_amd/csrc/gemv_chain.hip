@@ -1,5 +1,5 @@
-// The decoder of a ONE-ROW group -- the reference's own operating point, batch 1 (W/run.py:43-46, W/decoding.py:785-821) -- as the
-// stages of one launch: a decoder layer is
+// The decoder of a group of ONE TO EIGHT rows (utterances with one new token each; one row is the reference's own operating point,
+// batch 1: W/run.py:43-46, W/decoding.py:785-821) as the stages of one launch: a decoder layer is
 //
 //     self-attention (cache append included)  ->  out projection + residual  ->  LayerNorm + cross-attention query projection  ->
 //     cross-attention over 4 key-range pieces  ->  merge of the pieces + cross-attention out projection + residual  ->
@@ -34,6 +34,9 @@
 // The attention stages sit on workgroups that idle through most Linear stages: a self-attention head on each of the 20 before
 // the last 80, a cross-attention (head, piece) on each of the last 80 -- their upper four waves carry the DMA requests.
 // Every wait is bounded: a wave that gives up sets *err and the rest of the launch falls through (the host checks the word).
+// Rows (template NR): 1 and 2 rows as above, both utterances' K / V pieces in LDS; NR = 4 (3-4 rows) and 8 (5-8 rows, 8- and 16-bit
+// weights) keep the cross-attention's rows in registers, two (row, head, piece) items of four waves per workgroup (chain_cross_stage4),
+// and carry rows 4-7 in the second lane group of the MFMA's output; rows that have finished (p.live) read and append nothing.
 #include <atomic>
 
 #include <type_traits>

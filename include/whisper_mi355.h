@@ -292,7 +292,8 @@ int wm_set_self_attn_waves(int waves);
  * default.  Returns the previous value.  Both forms add an output element's products in the same order and share the
  * epilogue arithmetic: the results are bit-identical, a clip's encoder output does not depend on the batch it is in.     */
 int wm_set_gemm_small_tiles(int tiles);
-/* Batch 1 (one activation row: the reference's own operating point, W/run.py:43-46): the decoder's kernels run as STAGES of one
+/* Batch 1 to 8 (one new token for each of up to eight utterances; batch 1 is the reference's own operating point, W/run.py:43-46;
+ * 4-bit weights: one or two utterances): the decoder's kernels run as STAGES of one
  * launch (csrc/gemv_chain.hip: the stages hand the activation row over as tagged 8-byte granules -- no fences, no flags, no
  * barriers between workgroups; a stage's weights are requested before its input is waited for).  Same arithmetic as one launch
  * per kernel, bit for bit.  Modes:
@@ -302,6 +303,9 @@ int wm_set_gemm_small_tiles(int tiles);
  *      the pieces + cross-attention out + residual, LayerNorm + mlp1 + GELU, mlp2 + residual, LayerNorm + qkv of the next layer
  *   2  the launch walks over the layers itself: ONE launch per token step besides the embedding and the vocabulary
  *      projection (default).  The per-layer cross K/V and cache pointers reach it through a table in the workspace.
+ *      Rows: one and two utterances keep their cross-attention K / V pieces in LDS (requested a layer ahead); three to eight keep them in
+ *      registers, requested at the head of the stage, two (row, head, piece) items per workgroup.  `live_rows` is honoured: a finished
+ *      row's attention stages read nothing and append nothing to its cache.  A row's result is the launch-per-kernel path's, bit for bit.
  * Both need the in-place cache (past[i] == present[i], equal capacities <= 512), fp16 cross K/V and <= 32 layers for mode 2, and
  * a step that runs alone (wm_decoder_step, or wm_decoder_step_multi with one group: the launch needs all of its workgroups
  * resident together -- one per CU: do not issue such a step on a stream whose CU mask leaves it fewer CUs than the device has,
