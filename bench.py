@@ -719,7 +719,7 @@ def main():
                 b = in_situ_probe(dec, lib, last["xa"], B, n_micro, algo_bytes, beside=(enc, mel, args.encoder_cus))
                 roofline["in_situ_beside_encoder"] = {k.replace("in_situ_", ""): v for k, v in b.items() if k != "in_situ_note"}
         else:
-            # one-row utterance groups: the cross-attention is a stage of the one-launch token step (gemv_chain.hip), no launch of the
+            # utterance groups of up to eight rows: the cross-attention is a stage of the one-launch token step (gemv_chain.hip), no launch of the
             # K/V kernel exists to sample.  The token step as a whole is the unit then (decode_step_* below): achieved = its bytes / its time
             chain_traffic, chain_src = None, None        # HBM bytes per launch from the newest committed PMC pass of the same command (by round name)
             try:
@@ -734,9 +734,9 @@ def main():
                                  "not measured in this run; FETCH_SIZE KB x 1024 x 2)")
             except OSError:
                 pass
-            roofline = {"kernel": "gemv_chain_kernel (one-row decode step: every layer's self-attention, Linears, cross-attention pieces and merge as stages of ONE launch)",
+            roofline = {"kernel": "gemv_chain_kernel (the one-launch decode step of a group of 1-8 utterances: every layer's self-attention, Linears, cross-attention pieces and merge as stages of ONE launch)",
                         "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": chain_traffic, "traffic_source": chain_src,
-                        "note": "batch-1 groups: achieved / frac are the whole token step's (decode_step_bytes.total over decode_step_ms), "
+                        "note": "groups of 1-8 utterances: achieved / frac are the whole token step's (decode_step_bytes.total over decode_step_ms), "
                                 "a latency-bound chain of dependent stages, not a streaming kernel"}
         if roofline is not None:
             H, Tk = dims["n_text_head"], dims["n_audio_ctx"]

@@ -293,7 +293,7 @@ __device__ __forceinline__ void chain_stage(const GemvChainParams& p, const Chai
         // load of every pass re-read one granule 64 times)
         constexpr int NLR = (TB * KT / 4 <= 128) ? 2 : 3;                     // loads per lane, slice and row
         const int in_stride = st.K >> 1;                                      // granules between the rows of the stage's input
-        constexpr int RP = NR > 4 ? 4 : NR, NPASS = NR / RP;                  // rows per pass (NR == 8: two passes of four rows -- 16 loads in flight each)
+        constexpr int RP = (NR > 4 && WIDE) ? 4 : NR, NPASS = NR / RP;        // rows per pass: 16 loads in flight at most (NR == 8: the wide stage takes two passes of four rows)
         int n_ld[NS];
         bool any = false;
 #pragma unroll
