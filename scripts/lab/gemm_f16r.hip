@@ -12,6 +12,9 @@
 #ifndef F16R_EPI_SPLIT
 #define F16R_EPI_SPLIT 0         // 1: residual epilogue in two phases -- everything in front of the residual add for the whole tile, then add + store
 #endif
+#ifndef F16R_RES_EARLY
+#define F16R_RES_EARLY 0         // n = 1..4: the first n (of 4) row blocks of the tile's residual rows are REQUESTED (into the epilogue's own registers) while the
+#endif                           //    tile's last slot is multiplied, instead of at the head of the epilogue
 #ifndef F16R_RES_PREFETCH
 #define F16R_RES_PREFETCH 0      // 1: the tile's residual lines are touched (one dword per line, result unused) while its last slot is multiplied
 #endif
@@ -148,6 +151,21 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
     };
     zero_acc();
     bool prefetch_now = false;
+    uint4 r8e[F16R_RES_EARLY ? F16R_RES_EARLY : 1][4];
+    auto res_early = [&]() {                         // (same addresses as finish_simple's loads)
+        int tm, tn;
+        tile_of(j0 + t * per_xcd, tm, tn);
+        const int ge_ = lane >> 4, rl_ = lane & 15, odd_ = ge_ & 1;
+        const int colx_ = tn * BN + wc * 128 + 4 * (ge_ - odd_) + 16 * odd_;
+#pragma unroll
+        for (int i = 0; i < (F16R_RES_EARLY ? F16R_RES_EARLY : 1); ++i) {
+            const int row = tm * BM + wr * 64 + i * 16 + rl_;
+            const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colx_;
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) r8e[i][jp] = *(const uint4*)(rrow + jp * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     unsigned pf_dummy0 = 0, pf_dummy1 = 0;
     auto res_prefetch = [&]() {                      // this wave's 64 rows x 256 B of the residual tile: lane = row, two lines per row
         int tm, tn;
@@ -168,6 +186,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
         for (int j = 0; j < 4; ++j) bx[j] = *(const half8v*)(st + b_off0 + ch + j * 2048);
         if (HALF == 0 && !(FIRST && F16R_EPI_ISSUE)) { issue_pair(0); if (F16R_ISSUE_ALL_L1) issue_pair(2); }
         if (HALF == 0 && F16R_RES_PREFETCH && SIMPLE) { if (prefetch_now) res_prefetch(); }
+        if (HALF == 0 && F16R_RES_EARLY && SIMPLE && ACT == 0) { if (prefetch_now) res_early(); }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
         after_epilogue = false;
 #pragma unroll 1
         for (int ks = 1; ks < nk; ++ks) {
-            if (F16R_RES_PREFETCH && SIMPLE) prefetch_now = (ks == nk - 1) && p.residual != nullptr;
+            if ((F16R_RES_PREFETCH || F16R_RES_EARLY) && SIMPLE) prefetch_now = (ks == nk - 1) && p.residual != nullptr;
             stage(std::integral_constant<int, 0>{}, std::false_type{}); stage(std::integral_constant<int, 1>{}, std::false_type{});
         }
 
@@ -356,7 +375,10 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
                     const int row = row0 + wr * 64 + i * 16 + rl;
                     const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colx;
 #pragma unroll
-                    for (int jp = 0; jp < 4; ++jp) r8[i][jp] = *(const uint4*)(rrow + jp * 32);
+                    for (int jp = 0; jp < 4; ++jp) {
+                        if (i < F16R_RES_EARLY) r8[i][jp] = r8e[i][jp];      // (requested while the last slot was multiplied)
+                        else r8[i][jp] = *(const uint4*)(rrow + jp * 32);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
