@@ -533,15 +533,16 @@ def test_prefetched_encoder_pass_is_bit_identical_whenever_the_budget_is_release
         enc.session.encoder_forward_range(mel, out, s, 0, 2, 1)
 
 
-def test_two_row_step_with_rows_that_finish_at_different_times(lib, tmpdir_module, chain_rearmed):
-    """Per-row completion in a group of two rows: one row ends (its `row_limit`) long before the other.  The launch-per-kernel path drops
-    the finished row from the attention kernels; the one-launch step keeps computing it (a two-row group is stepped while either row
-    decodes; what the finished row's slots compute nobody reads) -- tokens and log-probabilities of both rows are the same in both
-    forms and equal to what each utterance gets alone with its own limit."""
+@pytest.mark.parametrize("rows", [2, 4, 7])
+def test_multi_row_step_with_rows_that_finish_at_different_times(lib, tmpdir_module, chain_rearmed, rows):
+    """Per-row completion in a group of two / four / seven rows (the three multi-row kernels): the rows end (their `row_limit`) at different
+    steps.  Both forms drop a finished row from the attention work (the one-launch step reads the list of live rows at the head of every
+    launch, under graph replay too) -- tokens and log-probabilities of every row are the same in both forms and, up to four rows, equal to
+    what each utterance gets alone with its own limit."""
     eng, dims = _small_engine(tmpdir_module)
     enc = WhisperEncoding(eng)
-    xa = enc.get_audio_features(synthetic_mel(2, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
-    limits = torch.tensor([3, 14], dtype=torch.int32)
+    xa = enc.get_audio_features(synthetic_mel(rows, 2 * dims.n_audio_ctx, dims.n_mels, 81).cuda())
+    limits = torch.tensor([3, 14, 7, 1, 12, 5, 9][:rows], dtype=torch.int32)
     outs = {}
     for mode in (0, 2):
         lib.wm_set_decode_chain(mode)
@@ -552,11 +553,14 @@ def test_two_row_step_with_rows_that_finish_at_different_times(lib, tmpdir_modul
         assert (native.chain_status()["launches"] > before) == (mode > 0)
         outs[mode] = (t.cpu(), lp.cpu())
         del dec
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"], st_
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
     eot = 50257
     t = outs[2][0]
-    assert int((t[0, 3:] != eot).sum()) == 3 and int((t[1, 3:] != eot).sum()) == 14
-    for b in (0, 1):
+    for b in range(rows):
+        assert int((t[b, 3:] != eot).sum()) == int(limits[b]), b
+    for b in (range(rows) if rows <= 4 else ()):
         solo = WhisperDecoding(eng, options=DecodingOptions(sample_len=16))
         xb = xa[b:b + 1].contiguous()
         solo.detect_language(xb)
