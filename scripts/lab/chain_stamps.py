@@ -8,7 +8,9 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def build():
+def build(coarse=False):
+    """coarse: the stage-boundary stamps and the Linear stages' inner ones only (the 3-8-row kernels' attention stages have other markers);
+    builds build/lab/libwm_cstamps<wg>.so for wg = 0 and 250"""
     s = open(os.path.join(ROOT, "eddie-wang-hackathon2023_amd/csrc/gemv_chain.hip")).read()
 
     def ins_before(s, marker, text):
@@ -48,6 +50,17 @@ extern "C" int wm_lab_chain_stamps2(unsigned long long* host) { return (int)hipM
     s = ins_before(s, '                // the NEXT layer\'s K / V rows set out now', '                STAMP(8);\n')
     s = ins_before(s, '            if (wide) chain_stage<WB, true, false, NR>(p, st, s, epoch, own_valid', '            if (STAMP_ON) s_cur_stage = s;\n')
     s = ins_after(s, '        chain_merge_tagged<NR>(p, tag, s_in);\n', '        STAMP(9);\n')           # (the merge runs inside the stage since round 5)
+    if coarse:
+        s = s.replace('constexpr size_t CHAIN_DYN_LDS = 100 * 1024;', 'constexpr size_t CHAIN_DYN_LDS = 97 * 1024;      // (lab: room for the stamps)', 1)
+        s = s.replace('constexpr size_t CHAIN_DYN_LDS8 = 24 * 1024;', 'constexpr size_t CHAIN_DYN_LDS8 = 22 * 1024;      // (lab: room for the stamps)', 1)
+        out = os.path.join(ROOT, "build/lab")
+        os.makedirs(out, exist_ok=True)
+        open(os.path.join(out, "gemv_chain_cstamps.hip"), "w").write(s)
+        for wg in (0, 250):
+            env = dict(os.environ, SRC=os.path.join(out, "gemv_chain_cstamps.hip"))
+            r = subprocess.run([os.path.join(ROOT, "scripts/lab/build_variant.sh"), f"cstamps{wg}", "gemv_chain.hip", f"-DWM_STAMP_WG={wg}"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            print(r.stdout.strip().splitlines()[-1])
+        return
     a = s.index('__device__ __forceinline__ void chain_cross_stage(')
     b = s.index('__device__ __forceinline__ void chain_merge_tagged(', a)
     body = s[a:b]
@@ -156,4 +169,7 @@ def read():
 
 
 if __name__ == "__main__":
-    build() if len(sys.argv) > 1 and sys.argv[1] == "build" else read()
+    if len(sys.argv) > 1 and sys.argv[1] in ("build", "build-coarse"):
+        build(coarse=sys.argv[1] == "build-coarse")
+    else:
+        read()
