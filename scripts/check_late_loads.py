@@ -11,10 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "eddie-wang-hackathon2023_amd", "csrc")
 # kernel-name pattern -> allowed sites, why
 ALLOWED = [
-    (r"gemv_chain_kernelILi(8|16)ELb[01]ELi8E", 18, "the 5-8-row kernels: the 3-4-row kernel's sites + the second sweep pass's polls of the error word (rows 4-7, once per stage form that sweeps), the LayerNorm of rows 4-7 on an idle slot's waves (its first residual read of a launch) and the cross-attention stage's second round"),
-    (r"gemv_chain_kernelILi(8|16)ELb[01]ELi4E", 12, "the 3-4-row kernels: the one-row kernel's sites (the cross-attention stage's K / V rows are requested at its head, ahead of the wait for q)"),
-    (r"gemv_chain_kernelILi(4|8|16)ELb[01]ELi2E", 16, "the two-row kernels: the one-row kernel's sites + the first residual read of a launch for the second row (p.x, once per stage form; only the first mode-2 stage of a launch takes it, later ones read the workgroup's own copy in LDS)"),
-    (r"gemv_chain_kernelILi(4|8|16)ELb[01]ELi1E", 12, "seven polls of the error word inside bounded waits (every 64th spin), the first residual read of a launch (p.x: twice, once per stage form), the self-attention's K block beyond 64 cached keys, the qkv sums read back from LDS through a flat pointer"),
+    (r"gemv_chain_kernelILi(8|16)ELb[01]ELi8E", 20, "the 5-8-row kernels: the 3-4-row kernel's sites + the second sweep pass's polls of the error word (rows 4-7, once per stage form that sweeps), the LayerNorm of rows 4-7 on an idle slot's waves (its first residual read of a launch) and the cross-attention stage's second round"),
+    (r"gemv_chain_kernelILi(8|16)ELb[01]ELi4E", 14, "the 3-4-row kernels: the one-row kernel's sites (the cross-attention stage's K / V rows are requested at its head, ahead of the wait for q)"),
+    (r"gemv_chain_kernelILi(4|8|16)ELb[01]ELi2E", 18, "the two-row kernels: the one-row kernel's sites + the first residual read of a launch for the second row (p.x, once per stage form; only the first mode-2 stage of a launch takes it, later ones read the workgroup's own copy in LDS)"),
+    (r"gemv_chain_kernelILi(4|8|16)ELb[01]ELi1E", 14, "the list of live rows read at the head of the launch (one vector load, waited for at once: everything behind needs it), a finished row's bounded wait for its qkv sums (one more poll of the error word), seven polls of the error word inside bounded waits (every 64th spin), the first residual read of a launch (p.x: twice, once per stage form), the self-attention's K block beyond 64 cached keys, the qkv sums read back from LDS through a flat pointer"),
     (r"gemv_small_kernelILi(4|8|16)ELi1E", 1, "M <= 16 forms: the fp16 logits form's single fragment load"),
     (r"gemv_small_kernelILi(4|8|16)ELi2E", 16, "17-32-row forms (not used: the small path serves <= 16 rows)"),
     (r"gemm_rows_kernel", 0, ""),
