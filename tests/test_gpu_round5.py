@@ -571,9 +571,10 @@ def test_multi_row_step_with_rows_that_finish_at_different_times(lib, tmpdir_mod
         del solo
 
 
-def test_best_of_two_candidates_of_one_utterance_take_the_two_row_step(lib, tmpdir_module, chain_rearmed):
-    """`best_of = 2` on ONE utterance: two candidate rows that share the clip's audio (their own copies of its cross K/V) -- a group of
-    two rows, i.e. the two-row one-launch step with the draw inside the greedy kernel.  The run is repeatable under torch.manual_seed,
+@pytest.mark.parametrize("best_of", [2, 5])
+def test_best_of_candidates_of_one_utterance_take_the_multi_row_step(lib, tmpdir_module, chain_rearmed, best_of):
+    """`best_of = 2 | 5` (the reference's default when sampling: W/decoding.py:113) on ONE utterance: candidate rows that share the clip's audio (their own copies of its
+    cross K/V) -- a group of two / five rows, i.e. the two-row / 5-8-row one-launch step with the draw inside the greedy kernel.  The run is repeatable under torch.manual_seed,
     identical to the launch-per-kernel path (the draws are keyed on seed, global row, position and token: not on the decode form), the
     candidates differ from each other, and the language pass and the loop share ONE buffer set (no re-allocation between them)."""
     eng, dims = _small_engine(tmpdir_module, "micro-fullvocab", True, True)
@@ -582,14 +583,14 @@ def test_best_of_two_candidates_of_one_utterance_take_the_two_row_step(lib, tmpd
     outs = {}
     for mode in (0, 2):
         lib.wm_set_decode_chain(mode)
-        dec = WhisperDecoding(eng, options=DecodingOptions(temperature=0.8, best_of=2, sample_len=10))
+        dec = WhisperDecoding(eng, options=DecodingOptions(temperature=0.8, best_of=best_of, sample_len=10))
         languages, _ = dec.detect_language(xa)
-        assert len(languages) == 1 and list(dec._state.keys()) == [2]            # the pass ran over the candidates' rows: the loop's buffer set
-        state = dec._state[2]
+        assert len(languages) == 1 and list(dec._state.keys()) == [best_of]            # the pass ran over the candidates' rows: the loop's buffer set
+        state = dec._state[best_of]
         before = native.chain_status()["launches"]
         torch.manual_seed(11)
         t, lp, nsp = dec.main_loop(xa)
-        assert dec._state[2] is state and t.shape[0] == 2
+        assert dec._state[best_of] is state and t.shape[0] == best_of
         assert (native.chain_status()["launches"] > before) == (mode > 0)
         torch.manual_seed(11)
         t_again, lp_again, _ = dec.main_loop(xa)
