@@ -12,6 +12,9 @@
 #ifndef F16R_EPI_SPLIT
 #define F16R_EPI_SPLIT 0         // 1: residual epilogue in two phases -- everything in front of the residual add for the whole tile, then add + store
 #endif
+#ifndef F16R_FULL_LINE_EPI
+#define F16R_FULL_LINE_EPI 0     // 1: the SIMPLE epilogue's stores (and residual loads) cover WHOLE 128-byte lines: 8 rows x 128 B per instruction instead of
+#endif                           //    16 rows x 64 B -- the two 16-byte chunks a lane holds of a row are exchanged with lane ^ 8 (DPP row_ror:8) first
 #ifndef F16R_RES_EARLY
 #define F16R_RES_EARLY 0         // n = 1..4: the first n (of 4) row blocks of the tile's residual rows are REQUESTED (into the epilogue's own registers) while the
 #endif                           //    tile's last slot is multiplied, instead of at the head of the epilogue
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
             uint4 r8[RES ? 4 : 1][RES ? 4 : 1];
             if constexpr (RES) {
 #pragma unroll
-                for (int i = 0; i < (F16R_EPI_SPLIT ? 2 : 4); ++i) {
+                for (int i = 0; i < (F16R_FULL_LINE_EPI ? 0 : (F16R_EPI_SPLIT ? 2 : 4)); ++i) {
                     const int row = row0 + wr * 64 + i * 16 + rl;
                     const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colx;
 #pragma unroll
@@ -420,6 +423,73 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
                 }
                 lo = __builtin_bit_cast(uint32_t, h0); hi = __builtin_bit_cast(uint32_t, h1);
             };
+            if constexpr (F16R_FULL_LINE_EPI != 0) {
+                // lane (rl, ge) holds, of row rl of a row block, the 16-byte chunks A (channel block pair 2 m) and B (2 m + 1).  Lanes rl and rl ^ 8
+                // exchange one of them, so that instruction 1 carries rows 0-7 (lanes rl < 8: their A = the first 64 bytes of the row's 128, lanes
+                // rl >= 8: B of row rl - 8 = the second 64) and instruction 2 rows 8-15 (lanes rl >= 8: their B, lanes rl < 8: A of row rl + 8).
+                const int lo8 = rl < 8;
+                const int colq = col0 + wc * 128 + 4 * (ge - odd) + 16 * odd + (rl >> 3) * 32;      // + 64 m: first channel of this lane's chunk in either instruction
+                auto ror8 = [&](uint4 x) {
+                    uint4 y;
+                    y.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.x, 0x128, 0xf, 0xf, false);
+                    y.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.y, 0x128, 0xf, 0xf, false);
+                    y.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.z, 0x128, 0xf, 0xf, false);
+                    y.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.w, 0x128, 0xf, 0xf, false);
+                    return y;
+                };
+                auto add_res = [&](uint4 o, uint4 rr) {
+                    const half8v x = __builtin_bit_cast(half8v, o), r = __builtin_bit_cast(half8v, rr);
+                    half8v y;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float2v tt = float2v{(float)x[e], (float)x[e + 1]} + float2v{(float)r[e], (float)r[e + 1]};
+                        const half2v h = __builtin_convertvector(tt, half2v);
+                        y[e] = h[0]; y[e + 1] = h[1];
+                    }
+                    return __builtin_bit_cast(uint4, y);
+                };
+                uint4 rq[RES ? 4 : 1][RES ? 2 : 1][RES ? 2 : 1];      // [row block][m][instruction]
+                if constexpr (RES) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int row = row0 + wr * 64 + i * 16 + 8 * k + (rl & 7);
+                            const h16* rrow = p.residual + (size_t)(row < p.M ? row : p.M - 1) * p.ldr + colq;
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) rq[i][m][k] = *(const uint4*)(rrow + m * 64);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        uint32_t a0, a1, b0, b1, c0, c1, d0, d1;
+                        block(i, 4 * m, a0, a1);
+                        block(i, 4 * m + 1, b0, b1);
+                        lane_rows_swap16(a0, b0);
+                        lane_rows_swap16(a1, b1);
+                        block(i, 4 * m + 2, c0, c1);
+                        block(i, 4 * m + 3, d0, d1);
+                        lane_rows_swap16(c0, d0);
+                        lane_rows_swap16(c1, d1);
+                        const uint4 A = make_uint4(a0, a1, b0, b1), B = make_uint4(c0, c1, d0, d1);      // channel block pairs 2 m | 2 m + 1 of row rl
+                        const uint4 give = lo8 ? B : A;
+                        const uint4 got = ror8(give);                                                        // lane rl ^ 8's
+                        uint4 o1 = lo8 ? A : got, o2 = lo8 ? got : B;
+                        if constexpr (RES) { o1 = add_res(o1, rq[i][m][0]); o2 = add_res(o2, rq[i][m][1]); }
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int row = row0 + wr * 64 + i * 16 + 8 * k + (rl & 7);
+                            h16* crow = p.C + (size_t)(row < p.M ? row : p.M - 1) * p.ldc + colq;
+                            if (row < p.M) *(uint4*)(crow + m * 64) = k ? o2 : o1;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
             if constexpr (RES && F16R_EPI_SPLIT) {
                 // (r8 holds row blocks 0 and 1 only here: see the loads above)
                 uint4 ob[4][4];
