@@ -79,6 +79,7 @@ def parse():
                     help="do not run the rocprofv3 --pmc FETCH_SIZE pass of the dominant kernel (roofline.traffic then comes from the committed pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager-loop", action="store_true", help="lab: the decode loop with eager launches instead of replayed graphs (A/B runs of launch-level experiments)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank (self-test)")
     return ap.parse_args()
 
@@ -439,6 +440,8 @@ def main():
         dist.barrier()
     enc, dec = WhisperEncoding(eng_dir), WhisperDecoding(eng_dir)
     dec.sample_len = args.decode_steps
+    if args.eager_loop:
+        dec.use_graphs = False
     if args.groups > 0:
         dec.micro_batches = args.groups
     dims = synthetic.DIMS[args.model]
