@@ -168,32 +168,36 @@ def test_full_depth_batch1_one_launch_step_matches_oracle_and_the_launch_per_ker
             assert torch.equal(a, b), (mode, use_graphs)
     assert len(set(r[2][0, 3:].tolist())) > 3                      # a real decode, not one token repeated
 
-    # ---- (d) TWO utterances (round 5: the one-launch step serves groups of two rows): the same three forms at full depth, and each
-    # utterance's tokens are the ones it gets alone (rows do not see each other) --------------------------------------------------
-    mel2 = torch.cat([mel, synthetic_mel(1, 3000, 80, 777).cuda()])
-    xa2 = enc.get_audio_features(mel2)
-    outs2 = []
-    for mode in (0, 2):
-        lib.wm_set_decode_chain(mode)
-        dec = WhisperDecoding(Path(out), options=DecodingOptions(sample_len=10))
-        dec.detect_language(xa2)
-        for use_graphs in (False, True):
-            dec.use_graphs = use_graphs
-            for st in dec._state.values():
-                st['graphs'].clear()
-            before = native.chain_status()["launches"]
-            t, lp, _ = dec.main_loop(xa2, ignore_eot=True)
-            assert (native.chain_status()["launches"] > before) == (mode > 0), (mode, use_graphs)
-            outs2.append((mode, use_graphs, t.cpu(), lp.cpu(), [c.clone() for c in dec._state[2]['kv']]))
-        del dec
-    for mode, use_graphs, t, lp, kv in outs2[1:]:
-        assert torch.equal(t, outs2[0][2]) and torch.equal(lp, outs2[0][3]), (mode, use_graphs)
-        for a, b in zip(kv, outs2[0][4]):
-            assert torch.equal(a, b), (mode, use_graphs)
-    assert torch.equal(outs2[0][2][0], r[2][0])                     # utterance 0 beside another one == utterance 0 alone
-    assert not torch.equal(outs2[0][2][0], outs2[0][2][1])
-    st_ = native.chain_status()
-    assert not st_["error_pending"] and not st_["declined"], st_
+    # ---- (d) TWO, FOUR and EIGHT utterances (round 5: the one-launch step serves groups of up to eight rows -- three more kernels): the
+    # launch-per-kernel form and the one-launch step at full depth, eager and replayed, and (two and four rows) each utterance's tokens are the
+    # ones it gets alone (rows do not see each other) -------------------------------------------------------------------------------------
+    mel8 = torch.cat([mel] + [synthetic_mel(1, 3000, 80, 777 + k).cuda() for k in range(7)])
+    xa8 = enc.get_audio_features(mel8)
+    for rows in (2, 4, 8):
+        xa_r = xa8[:rows].contiguous()
+        outs2 = []
+        for mode in (0, 2):
+            lib.wm_set_decode_chain(mode)
+            dec = WhisperDecoding(Path(out), options=DecodingOptions(sample_len=10))
+            dec.detect_language(xa_r)
+            for use_graphs in (False, True):
+                dec.use_graphs = use_graphs
+                for st in dec._state.values():
+                    st['graphs'].clear()
+                before = native.chain_status()["launches"]
+                t, lp, _ = dec.main_loop(xa_r, ignore_eot=True)
+                assert (native.chain_status()["launches"] > before) == (mode > 0), (rows, mode, use_graphs)
+                outs2.append((mode, use_graphs, t.cpu(), lp.cpu(), [c.clone() for c in dec._state[rows]['kv']]))
+            del dec
+        for mode, use_graphs, t, lp, kv in outs2[1:]:
+            assert torch.equal(t, outs2[0][2]) and torch.equal(lp, outs2[0][3]), (rows, mode, use_graphs)
+            for a, b in zip(kv, outs2[0][4]):
+                assert torch.equal(a, b), (rows, mode, use_graphs)
+        if rows <= 4:
+            assert torch.equal(outs2[0][2][0], r[2][0])                 # utterance 0 beside others == utterance 0 alone
+        assert not torch.equal(outs2[0][3][0], outs2[0][3][1])
+        st_ = native.chain_status()
+        assert not st_["error_pending"] and not st_["declined"], (rows, st_)
 
 
 # ------------------------------------------------------------------------------------------ two rows in one launch
