@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         int tm, tn;
         tile_of(j0 + t * per_xcd, tm, tn);
         const int row0 = tm * BM, col0 = tn * BN;
-        const int hs_b0 = !SIMPLE && p.out_mode == 1 ? row0 / p.hs_T : 0, hs_t0 = !SIMPLE && p.out_mode == 1 ? row0 - hs_b0 * p.hs_T : 0;     // wave-uniform
+        const int hs_b0 = (!SIMPLE || ACT == 0) && p.out_mode == 1 ? row0 / p.hs_T : 0, hs_t0 = (!SIMPLE || ACT == 0) && p.out_mode == 1 ? row0 - hs_b0 * p.hs_T : 0;     // wave-uniform
         // every lane-dependent quantity of the epilogue is derived from `le`, which the compiler cannot see through: nothing
         // of the epilogue's address arithmetic is hoisted out of the tile loop into registers the K loop needs
         int le = lane;
@@ -361,8 +361,12 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
         // K = 1280 tile's 84 000 with two waves per SIMD in it together, 32 000 with a residual (from the shapes' rates: 160 S + E
         // and 40 S + E cycles per tile at K = 5120 / 1280).  Here: bias to fp32 ONCE per tile (32 values per lane), packed adds,
         // one conversion per output where nothing sits between the Linear's rounding and the store.
-        auto finish_simple = [&](auto res_tag, auto scale_tag) {
+        auto finish_simple = [&](auto res_tag, auto scale_tag, auto hs_tag) {
             constexpr bool RES = decltype(res_tag)::value, SCALE = decltype(scale_tag)::value;
+            // HS (round 5): the head-split output [B, 2, H, T, 64] of the cross-K/V projection (whisper/model.py:519) through the same 16-byte stores -- a
+            // lane's 8 consecutive channels never leave a head (8 | 64), so only the address changes (the general form wrote 8 bytes per lane:
+            // 1 012 against 1 104 TFLOP/s for the plain row-major output of the same shape)
+            constexpr bool HS = decltype(hs_tag)::value;
             // 16-BYTE accesses.  In the accumulator layout a lane owns 4 consecutive channels of a row (8 bytes) per 16-channel block,
             // the lane 16 places on the next 4: every store instruction wrote 16 rows x 32 bytes, and the CU's store path, which
             // works segment by segment, needed 3.5 us for a wave's 32 of them (time stamps inside the kernel: a ~600-instruction
@@ -444,17 +448,29 @@ __global__ __launch_bounds__(512) void gemm_f16p_kernel(GemmBigParams p) {
                         }
                         o = __builtin_bit_cast(uint4, y);
                     }
-                    if (row < p.M) *(uint4*)(crow + jp * 32) = o;
+                    if constexpr (HS) {
+                        const int HC = p.hs_H * 64;
+                        int bb = hs_b0, tt = hs_t0 + (row - row0);
+                        if (p.hs_T >= BM) { if (tt >= p.hs_T) { tt -= p.hs_T; ++bb; } }       // at most one utterance boundary inside a tile
+                        else { bb = row / p.hs_T; tt = row - bb * p.hs_T; }                   // (tiny models: several utterances per tile)
+                        const int col = colx + jp * 32;
+                        const int kv = p.hs_kv < 0 ? (p.N == 2 * HC ? (col >= HC ? 1 : 0) : col / HC) : p.hs_kv, cc = p.hs_kv < 0 ? col - kv * HC : col;
+                        const size_t off = ((((size_t)bb * 2 + kv) * p.hs_H + (cc >> 6)) * p.hs_T + tt) * 64 + (cc & 63);
+                        if (row < p.M) *(uint4*)(p.C + off) = o;
+                    } else {
+                        if (row < p.M) *(uint4*)(crow + jp * 32) = o;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         if constexpr (SIMPLE && ACT != 0) {
-            finish_simple(std::false_type{}, std::false_type{});                         // (the launcher sends GELU + residual / column scale to the general form)
+            finish_simple(std::false_type{}, std::false_type{}, std::false_type{});      // (the launcher sends GELU + residual / column scale / head-split to the general form)
         } else if constexpr (SIMPLE) {     // (wave-uniform branches, once per tile)
-            if (p.residual) finish_simple(std::true_type{}, std::false_type{});          // no encoder GEMM has both a residual and a column scale
-            else if (scale_cols) finish_simple(std::false_type{}, std::true_type{});
-            else finish_simple(std::false_type{}, std::false_type{});
+            if (p.out_mode == 1) finish_simple(std::false_type{}, std::false_type{}, std::true_type{});      // head-split (the launcher: no residual, no column scale with it)
+            else if (p.residual) finish_simple(std::true_type{}, std::false_type{}, std::false_type{});      // no encoder GEMM has both a residual and a column scale
+            else if (scale_cols) finish_simple(std::false_type{}, std::true_type{}, std::false_type{});
+            else finish_simple(std::false_type{}, std::false_type{}, std::false_type{});
         } else {
             if (p.residual) finish(std::true_type{}); else finish(std::false_type{});
         }
@@ -503,7 +519,8 @@ int launch_gemm_f16p(const GemmBigParams& p, hipStream_t stream) {
     if (max_wgs > 0 && max_wgs < grid) grid = max_wgs >= 8 ? (max_wgs / 8) * 8 : 8;
     const int need = ((n_tiles + 7) / 8) * 8;        // never more workgroups than a band has tiles
     if (grid > need) grid = need;
-    const bool simple = p.out_mode == 0 && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f && !(p.residual && p.colscale_n > 0) &&
+    const bool head_split_fast = p.out_mode == 1 && p.act == 0 && !p.residual && p.colscale_n <= 0 && p.hs_T > 0 && p.hs_H > 0;      // (16-byte stores into [B, 2, H, T, 64])
+    const bool simple = (p.out_mode == 0 || head_split_fast) && p.c_rows == 0 && p.res_mod == 0 && p.q8_inv_scale <= 0.f && !(p.residual && p.colscale_n > 0) &&
                         (p.act == 0 || (!p.residual && p.colscale_n <= 0)) &&
                         p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));      // 16-byte epilogue accesses
     static const int lab_rows = lab_env_int("WM_GEMM_TILE_ROWS", 0);    // A/B runs (WM_LAB=1): 1 = the plain row-major tile order
