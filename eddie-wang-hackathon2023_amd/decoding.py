@@ -915,7 +915,12 @@ class WhisperDecoding:
                         counter = torch.zeros(1, dtype=torch.int32, device=dev)
                         streams[slot].synchronize()
                         graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph, stream=streams[slot]):
+                        # capture_error_mode "thread_local" + CAPTURE_LOCK: the encoder of the NEXT batch may be in flight on a helper thread
+                        # (WhisperEncoding.prefetch), which waits for events and issues launches on its own stream.  Under the default
+                        # "global" mode such a call from ANY thread while this capture is open invalidates it (hipErrorStreamCaptureInvalidated
+                        # -- seen once in ~ 25 bench runs: the window is three captures of a millisecond or two against one event wait per
+                        # encoder layer); the lock keeps the helper out of the driver for the length of the capture as well
+                        with native.CAPTURE_LOCK, torch.cuda.graph(graph, stream=streams[slot], capture_error_mode="thread_local"):
                             sess.decoder_step(gr['tokens'], pos, gr['cross'], gr['kv'], cap, gr['kv'], cap,
                                               gr['logits'], 1, sm, slot=slot, n_past_dev=counter, n_new=1, live_rows=gr['live'])
                             self._greedy(st, lo, hi, gr['logits'].data_ptr(), V, 0, sm, n_past_dev=counter)

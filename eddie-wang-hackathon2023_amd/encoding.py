@@ -13,6 +13,7 @@ from collections import OrderedDict
 
 import torch
 
+import native
 from build import get_engine_name
 from session import Session, TensorInfo, str_dtype_to_trt, trt_dtype_to_torch, logger
 
@@ -121,34 +122,45 @@ class WhisperEncoding:
 
         def work():
             try:
-                torch.cuda.set_device(device)
+                with native.CAPTURE_LOCK:
+                    torch.cuda.set_device(device)
                 with torch.cuda.stream(side):
-                    if timed:
-                        box["t0"] = torch.cuda.Event(enable_timing=True); box["t0"].record()
-                    m16 = mel.type(torch.float16).contiguous()
-                    d = self.session.dims
-                    out = torch.empty((m16.shape[0], d['n_audio_ctx'], d['n_audio_state']), dtype=torch.float16, device=m16.device)
+                    with native.CAPTURE_LOCK:
+                        if timed:
+                            box["t0"] = torch.cuda.Event(enable_timing=True); box["t0"].record()
+                        m16 = mel.type(torch.float16).contiguous()
+                        d = self.session.dims
+                        out = torch.empty((m16.shape[0], d['n_audio_ctx'], d['n_audio_state']), dtype=torch.float16, device=m16.device)
                     if not release:
-                        self.session.encoder_forward(m16, out, side.cuda_stream, cu_budget)
+                        with native.CAPTURE_LOCK:
+                            self.session.encoder_forward(m16, out, side.cuda_stream, cu_budget)
                     else:
                         # layers per issue: a layer of B clips takes ~ 0.23 ms x B on a 96-CU budget and the helper thread needs ~ 0.1 ms to
                         # wake up and issue one -- small batches go in chunks of several layers (B = 1: two chunks; from 20 clips on: one layer)
                         budget, done, chunk = cu_budget, [], max(1, -(-20 // int(m16.shape[0])))
+                        import time
                         for i in range(0, n_layer, chunk):
-                            if done:
-                                done[-1].synchronize()             # a layer is issued when the one before it has finished: the look below is fresh
-                                                                   # (the GPU idles for the ~0.1 ms the host needs to issue a layer's 7 launches,
-                                                                   # 0.1-0.2 % of a 45-135 ms layer; two layers queued ahead cost a short loop
-                                                                   # 180 ms of budget-confined work behind its end: profiles/r5h_*)
-                            ev = box["loop_done"]
-                            if budget > 0 and ev is not None and ev.query():
-                                budget, box["released_at"] = 0, i  # the loop has ended: the whole chip for what is left
-                            self.session.encoder_forward_range(m16, out, side.cuda_stream, budget, i, min(n_layer, i + chunk))
-                            e = torch.cuda.Event(); e.record()
+                            # a layer is issued when the one before it has finished: the look at the loop's event below is fresh (the GPU
+                            # idles for the ~0.1-0.3 ms the host needs to notice and to issue a layer's 7 launches, 0.1-0.3 % of a 45-135 ms
+                            # layer; two layers queued ahead cost a short loop 180 ms of budget-confined work behind its end: profiles/r5h_*).
+                            # The wait POLLS, and every call into the runtime is made under native.CAPTURE_LOCK: the main thread may be
+                            # capturing a decode step's graph, and a runtime call from this thread inside that window can invalidate it
+                            while done:
+                                with native.CAPTURE_LOCK:
+                                    if done[-1].query():
+                                        break
+                                time.sleep(0.0002)
+                            with native.CAPTURE_LOCK:
+                                ev = box["loop_done"]
+                                if budget > 0 and ev is not None and ev.query():
+                                    budget, box["released_at"] = 0, i  # the loop has ended: the whole chip for what is left
+                                self.session.encoder_forward_range(m16, out, side.cuda_stream, budget, i, min(n_layer, i + chunk))
+                                e = torch.cuda.Event(); e.record()
                             done.append(e)
-                    box["xa"] = stamp_generation(out)
-                    if timed:
-                        box["t1"] = torch.cuda.Event(enable_timing=True); box["t1"].record()
+                    with native.CAPTURE_LOCK:
+                        box["xa"] = stamp_generation(out)
+                        if timed:
+                            box["t1"] = torch.cuda.Event(enable_timing=True); box["t1"].record()
             except BaseException as exc:                       # re-raised by collect()
                 box["error"] = exc
 

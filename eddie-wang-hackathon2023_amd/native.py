@@ -82,7 +82,12 @@ EXPORTS = (
 )
 
 
-ABI_VERSION = 7          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
+ABI_VERSION = 7
+
+# Held by WhisperDecoding.main_loop for the length of a stream capture and by WhisperEncoding.prefetch's helper thread around every call
+# it makes into the HIP runtime (event queries, launches): a runtime call from another thread while a capture is open can invalidate it.
+import threading as _threading
+CAPTURE_LOCK = _threading.RLock()          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
 
 
 class WmError(RuntimeError):

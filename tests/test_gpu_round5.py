@@ -537,6 +537,62 @@ def test_prefetched_encoder_pass_is_bit_identical_whenever_the_budget_is_release
         enc.session.encoder_forward_range(mel, out, s, 0, 2, 1)
 
 
+def test_graph_capture_survives_an_encoder_pass_on_the_helper_thread(lib, tmpdir_module, chain_rearmed):
+    """The pipelined schedule captures the decode step's graphs while the NEXT batch's encoder is being issued layer by layer by
+    WhisperEncoding.prefetch's helper thread (event queries, launches, allocations on its own stream).  Under the default "global"
+    capture mode a runtime call from that thread inside the capture window invalidated the capture (hipErrorStreamCaptureInvalidated: seen
+    once in ~ 25 bench runs).  Forty fresh captures, each beside a pass in flight (a small model: the helper is in the runtime almost all
+    the time): every loop returns the tokens of the run without a pass beside it, every pass the features of the plain call."""
+    eng, dims = _small_engine(tmpdir_module, "tiny", True, False)
+    enc = WhisperEncoding(eng)
+    mel = synthetic_mel(12, 2 * dims.n_audio_ctx, dims.n_mels, 5).cuda()
+    xa = enc.get_audio_features(mel).clone()
+    lib.wm_set_decode_chain(0)                                     # (12 rows: a launch per kernel anyway; the graphs are what is under test)
+    dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=6))
+    dec.detect_language(xa)
+    t_ref, lp_ref, _ = dec.main_loop(xa, ignore_eot=True)
+    t_ref, lp_ref = t_ref.cpu(), lp_ref.cpu()
+    for it in range(40):
+        for st in dec._state.values():
+            st['graphs'].clear()                                   # capture again
+        enc.prefetch(mel, 64)
+        t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+        enc.loop_ended()
+        xa2 = enc.collect()
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), t_ref) and torch.equal(lp.cpu(), lp_ref), it
+        assert torch.equal(xa2.view(torch.int16), xa.view(torch.int16)), it
+    # ... and beside a thread that does NOT take the library's lock and never leaves the runtime (event record / synchronize / query, a
+    # small allocation and a kernel on its own stream): what protects the capture here is its thread-local error mode alone
+    import threading
+    stop, errors = threading.Event(), []
+
+    def hammer():
+        try:
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                while not stop.is_set():
+                    x = torch.empty(257, device="cuda").fill_(1.0)
+                    ev = torch.cuda.Event(); ev.record()
+                    ev.synchronize()
+                    assert ev.query() and float(x[0]) == 1.0
+        except BaseException as exc:                                   # noqa: BLE001
+            errors.append(exc)
+    th = threading.Thread(target=hammer, daemon=True)
+    th.start()
+    try:
+        for it in range(30):
+            for st in dec._state.values():
+                st['graphs'].clear()
+            t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+            assert torch.equal(t.cpu(), t_ref) and torch.equal(lp.cpu(), lp_ref), it
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    del dec
+
+
 @pytest.mark.parametrize("rows", [2, 4, 7])
 def test_multi_row_step_with_rows_that_finish_at_different_times(lib, tmpdir_module, chain_rearmed, rows):
     """Per-row completion in a group of two / four / seven rows (the three multi-row kernels): the rows end (their `row_limit`) at different
