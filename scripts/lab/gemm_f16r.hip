@@ -15,6 +15,9 @@
 #ifndef F16R_FULL_LINE_EPI
 #define F16R_FULL_LINE_EPI 0     // 1: the SIMPLE epilogue's stores (and residual loads) cover WHOLE 128-byte lines: 8 rows x 128 B per instruction instead of
 #endif                           //    16 rows x 64 B -- the two 16-byte chunks a lane holds of a row are exchanged with lane ^ 8 (DPP row_ror:8) first
+#ifndef F16R_NT_EPI
+#define F16R_NT_EPI 0            // bit 0: the epilogue's C stores non-temporal; bit 1: its residual loads non-temporal (both are touched once by this kernel)
+#endif
 #ifndef F16R_RES_EARLY
 #define F16R_RES_EARLY 0         // n = 1..4: the first n (of 4) row blocks of the tile's residual rows are REQUESTED (into the epilogue's own registers) while the
 #endif                           //    tile's last slot is multiplied, instead of at the head of the epilogue
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
 #pragma unroll
                     for (int jp = 0; jp < 4; ++jp) {
                         if (i < F16R_RES_EARLY) r8[i][jp] = r8e[i][jp];      // (requested while the last slot was multiplied)
+                        else if (F16R_NT_EPI & 2) r8[i][jp] = __builtin_bit_cast(uint4, __builtin_nontemporal_load((const u32x4*)(rrow + jp * 32)));
                         else r8[i][jp] = *(const uint4*)(rrow + jp * 32);
                     }
                 }
@@ -557,7 +561,10 @@ __global__ __launch_bounds__(512) void gemm_f16r_kernel(GemmBigParams p) {
                         }
                         o = __builtin_bit_cast(uint4, y);
                     }
-                    if (row < p.M) *(uint4*)(crow + jp * 32) = o;
+                    if (row < p.M) {
+                        if (F16R_NT_EPI & 1) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), (u32x4*)(crow + jp * 32));
+                        else *(uint4*)(crow + jp * 32) = o;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
