@@ -19,6 +19,10 @@
  *   - fp16 = IEEE binary16.  Tensors are dense row-major unless a leading dimension is given.
  *   - re-entrant for distinct (engine, stream, workspace); one host thread per GPU in the
  *     data-parallel design.  The only global state is the error string and WM_SYNC_CHECK.
+ *     A caller that CAPTURES calls of this library into a hipGraph while another of its threads is inside the HIP runtime (the Python host
+ *     issues the next batch's encoder from a helper thread) must capture with hipStreamCaptureModeThreadLocal or keep that thread out of
+ *     the runtime for the length of the capture: in the global mode any thread's runtime call invalidates the capture (the Python host
+ *     does both: decoding.py, encoding.py, native.CAPTURE_LOCK).
  */
 #ifndef WHISPER_MI355_H
 #define WHISPER_MI355_H
