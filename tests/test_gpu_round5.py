@@ -537,6 +537,34 @@ def test_prefetched_encoder_pass_is_bit_identical_whenever_the_budget_is_release
         enc.session.encoder_forward_range(mel, out, s, 0, 2, 1)
 
 
+@pytest.mark.parametrize("rows,int8_kv", [(1, False), (2, True), (4, False), (8, False), (8, True)])
+def test_one_launch_step_over_a_long_decode(lib, tmpdir_module, chain_rearmed, rows, int8_kv):
+    """The one-launch step from an empty cache to the end of the decoder's context (n_text_ctx = 448 positions): the self-attention stage
+    takes its cached rows from LDS (set out a layer ahead) while they fit the kernel's dynamic LDS -- 96 KB at one and two rows, 64 KB at
+    3-4, 24 KB at 5-8 rows: 384 / 255 / 92 positions with an fp16 cache -- and from memory beyond: every kernel crosses its limit here.
+    Tokens and log-probabilities of all ~ 440 steps equal the launch-per-kernel path's."""
+    eng, dims = _small_engine(tmpdir_module, "tiny", True, int8_kv)
+    enc = WhisperEncoding(eng)
+    xa = enc.get_audio_features(synthetic_mel(rows, 2 * dims.n_audio_ctx, dims.n_mels, 85).cuda())
+    n = dims.n_text_ctx - 8
+    outs = {}
+    for mode in (0, 2):
+        lib.wm_set_decode_chain(mode)
+        dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=n))
+        dec.detect_language(xa)
+        before = native.chain_status()["launches"]
+        t, lp, _ = dec.main_loop(xa, ignore_eot=True)
+        assert (native.chain_status()["launches"] > before) == (mode > 0)
+        assert t.shape[1] >= n
+        outs[mode] = (t.cpu(), lp.cpu(), [c.clone() for c in dec._state[rows]['kv']])
+        del dec
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"], st_
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    for a, b in zip(outs[0][2], outs[2][2]):
+        assert torch.equal(a, b)
+
+
 def test_graph_capture_survives_an_encoder_pass_on_the_helper_thread(lib, tmpdir_module, chain_rearmed):
     """The pipelined schedule captures the decode step's graphs while the NEXT batch's encoder is being issued layer by layer by
     WhisperEncoding.prefetch's helper thread (event queries, launches, allocations on its own stream).  Under the default "global"
