@@ -1,4 +1,4 @@
-"""Debug (tests-side tool: uses the oracle package for synthetic inputs only): one decode step with a live-row list, chain modes 0 / 2, batch B: which rows / layers differ from the full step."""
+"""Debug: one decode step with a live-row list, chain modes 0 / 2, batch B: which rows / layers differ from the full step."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "eddie-wang-hackathon2023_amd"), os.path.join(ROOT, "tests")]
@@ -6,14 +6,15 @@ import tempfile
 from pathlib import Path
 import torch
 import native, synthetic
-from oracle.whisper_oracle import Dims, synthetic_mel
+from synthetic import synthetic_mel
 from test_gpu_model import build_engine
 from encoding import WhisperEncoding
 from decoding import WhisperDecoding
 lib = native.load_library()
 lib.wm_set_small_batch_rows(8)
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-dims = Dims(**synthetic.DIMS["micro"])
+from types import SimpleNamespace
+dims = SimpleNamespace(**synthetic.DIMS["micro"])
 eng = build_engine(Path(tempfile.mkdtemp()), "micro", 7, True, True, [0.05, 0.06])
 enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
 mel = synthetic_mel(batch, 2 * dims.n_audio_ctx, dims.n_mels, 5).cuda()

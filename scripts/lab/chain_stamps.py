@@ -104,11 +104,12 @@ def read():
     import native, synthetic, bench
     from decoding import WhisperDecoding
     from encoding import WhisperEncoding
-    from oracle.whisper_oracle import Dims, synthetic_mel
+    from types import SimpleNamespace
+    from synthetic import synthetic_mel
     lib = native.load_library()
     model = "large-v2"
     n_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    dims = Dims(**synthetic.DIMS[model])
+    dims = SimpleNamespace(**synthetic.DIMS[model])
     sys.argv = ["bench.py", "--model", model]
     args = bench.parse()
     eng_dir = Path(args.engine_cache) / f"{args.model}-{args.config}-seed{args.seed}"

@@ -1,4 +1,4 @@
-"""Diagnostic (not a test): per-config, per-step engine-vs-oracle differences on the micro model."""
+"""Diagnostic (not a test; lives under tests/ because it calls the oracle, which only test code may): per-config, per-step engine-vs-oracle differences on the micro model."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "eddie-wang-hackathon2023_amd"), os.path.join(ROOT, "tests")]

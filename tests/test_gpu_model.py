@@ -13,7 +13,7 @@ Tolerance accounting (fp16 storage everywhere, logits of std ~1.5):
   * with the int8 KV cache the bound is 6e-2: a cached value that sits within fp16 noise of a
     rounding boundary lands on the neighbouring int8 code (measured: < 0.5 % of the entries, never
     more than 1 LSB), and one LSB is kv_scale = amax/127 ~ 0.06 here -- a discrete jump that the
-    oracle's own fp16-vs-fp32 runs show as well (scripts/diag_model.py: 0.03-0.056).
+    oracle's own fp16-vs-fp32 runs show as well (tests/diag_model.py: 0.03-0.056).
     Measured engine-vs-oracle maxima on this model: fp16 0.006, weight-only 0.011, int8-KV 0.019,
     both 0.031.
 """
