@@ -1172,7 +1172,7 @@ int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t str
         return 0;
     }
     GroupStep g;
-    if (int rc = g.init(e, io, s)) return rc;
+    if (int rc = g.init(e, io, s, !(io && io->not_alone))) return rc;
     if (g.begin(s)) return 2;
     for (int i = 0; i < e->dims.n_text_layer; ++i) {
         if (g.pre_cross(i, s)) return 2;
@@ -1190,7 +1190,7 @@ int wm_decoder_step_multi(const wm_engine* e, int n_groups, const wm_decoder_io*
     GroupStep g[8];
     for (int k = 0; k < n_groups; ++k) {
         WM_REQUIRE(light_streams[k] && light_streams[k] != heavy_stream, "wm_decoder_step_multi: group %d needs its own stream", k);
-        if (int rc = g[k].init(e, ios[k], (hipStream_t)light_streams[k], n_groups == 1)) return rc;
+        if (int rc = g[k].init(e, ios[k], (hipStream_t)light_streams[k], n_groups == 1 && !(ios[k] && ios[k]->not_alone))) return rc;
     }
     const int n_layer = e->dims.n_text_layer;
     for (int k = 0; k < n_groups; ++k)

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import json
 import os
+import weakref
 import zlib
 from collections import OrderedDict
 from dataclasses import dataclass, field
@@ -263,6 +264,7 @@ class WhisperDecoding:
         self.skip_finished_rows = True
         self._streams = []
         self._no_dedicated_queues = False
+        WhisperDecoding._instances.add(self)      # (weak: a give-up of a one-launch step drops the graphs of EVERY instance, _chain_gave_up)
 
     # ---- configuration / sessions -----------------------------------------------------------------
     def get_config(self, engine_dir):
@@ -404,6 +406,12 @@ class WhisperDecoding:
         ok = self.decoder_session.run(inputs=inputs, outputs=outputs, stream=stream.cuda_stream)
         assert ok, 'Engine execution failed'
         stream.synchronize()
+        # a first call of one token for up to eight utterances (the language pass) may have run as ONE launch (gemv_chain.hip): this path
+        # has synchronised, so a look at the give-up word is free -- and nobody else would look (the caller decoded on from garbage)
+        if x.is_cuda and input_len == 1 and x.shape[0] <= 8 and self._chain_gave_up("decode()"):
+            ok = self.decoder_session.run(inputs=inputs, outputs=outputs, stream=stream.cuda_stream)     # launch per kernel now
+            assert ok, 'Engine execution failed'
+            stream.synchronize()
         return outputs['output'], [outputs['present_key_value_' + str(i)] for i in range(n_layer)]
 
     # ---- language detection ---------------------------------------------------------------------------
@@ -464,7 +472,10 @@ class WhisperDecoding:
         if self.options.language is None or self.options.task == "lang_id":
             single = audio_features.ndim == 2
             if single:
+                gen = getattr(audio_features, 'wm_generation', None)
                 audio_features = audio_features.unsqueeze(0)
+                if gen is not None:          # the view is the same encoder output: it keeps the stamp (_features_key; else the cross K/V
+                    audio_features.wm_generation = gen      # of one clip would be projected twice, once per view)
             n_audio, dev = audio_features.shape[0], audio_features.device
             cfg = self.decoder_config
             if self.n_group > 1 and self.device_sampling and audio_features.is_cuda:
@@ -498,37 +509,38 @@ class WhisperDecoding:
 
     def _detect_language_rows(self, audio_features, single, _retry):
         """The pass itself over the rows of `audio_features` [n, n_audio_ctx, C] (detect_language)."""
-        if True:
-            languages, language_probs = None, None
-            n_audio, dev = audio_features.shape[0], audio_features.device
-            cfg = self.decoder_config
-            st = self._fast_state(n_audio, dev)
-            one_row = any(hi - lo <= 8 for lo, hi in self._groups(n_audio)[1])      # groups of up to eight rows may run as ONE launch per step
-            if one_row and native.chain_status()["error_pending"]:                  # (a peek at a host word: no synchronisation)
-                self._chain_gave_up("found before the language pass")               # somebody else's give-up: acknowledged, not ours to repeat
-            cross = self._cross_persistent(audio_features, st)
-            if 'lang_logits' not in st:
-                st['lang_logits'] = torch.empty((n_audio, 1, cfg['vocab_size']), dtype=torch.float16, device=dev)
-                st['sot'] = torch.full((n_audio, 1), self.tokenizer.sot, dtype=torch.int32, device=dev)
-            n_micro, bounds = self._groups(n_audio)
-            main = torch.cuda.current_stream()
-            streams = self._group_streams(n_micro, dev)
-            cap = cfg['num_text_ctx']
-            for g, (lo, hi) in enumerate(bounds):
-                streams[g].wait_stream(main)
-                if self.lang_id_sequential and g > 0:
-                    streams[g].wait_stream(streams[g - 1])     # one group at a time: kernels are timed un-shared (bench.py)
-                self.decoder_session.decoder_step(st['sot'][lo:hi], self.positional_embedding[0:1],
-                                                  [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
-                                                  st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g)
-                main.wait_stream(streams[g])
-            language_tokens, language_probs, languages = self._language_from_logits(
-                st['lang_logits'][:, 0].float(), n_audio, single)                # (brings the logits to the host: the pass has finished)
-            if one_row and not _retry and self._chain_gave_up("language pass"):
-                return self._detect_language_rows(audio_features, single, True)
-            if self.options.language is None:
-                self.tokens = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
-                self.tokens[:, self.sot_index + 1] = language_tokens.cpu()        # write language tokens
+        languages, language_probs = None, None
+        n_audio, dev = audio_features.shape[0], audio_features.device
+        cfg = self.decoder_config
+        st = self._fast_state(n_audio, dev)
+        n_micro_, bounds_ = self._groups(n_audio)   # groups of up to eight rows stepped one at a time may run as ONE launch per step
+        one_row = (n_micro_ == 1 or self.lang_id_sequential) and any(hi - lo <= 8 for lo, hi in bounds_)
+        if one_row and native.chain_status()["error_pending"]:                  # (a peek at a host word: no synchronisation)
+            self._chain_gave_up("found before the language pass", foreign=True)  # somebody else's give-up: said loudly, acknowledged, not ours to repeat
+        cross = self._cross_persistent(audio_features, st)
+        if 'lang_logits' not in st:
+            st['lang_logits'] = torch.empty((n_audio, 1, cfg['vocab_size']), dtype=torch.float16, device=dev)
+            st['sot'] = torch.full((n_audio, 1), self.tokenizer.sot, dtype=torch.int32, device=dev)
+        n_micro, bounds = self._groups(n_audio)
+        main = torch.cuda.current_stream()
+        streams = self._group_streams(n_micro, dev)
+        cap = cfg['num_text_ctx']
+        for g, (lo, hi) in enumerate(bounds):
+            streams[g].wait_stream(main)
+            if self.lang_id_sequential and g > 0:
+                streams[g].wait_stream(streams[g - 1])     # one group at a time: kernels are timed un-shared (bench.py)
+            self.decoder_session.decoder_step(st['sot'][lo:hi], self.positional_embedding[0:1],
+                                              [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
+                                              st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g,
+                                              not_alone=n_micro > 1 and not self.lang_id_sequential)
+            main.wait_stream(streams[g])
+        language_tokens, language_probs, languages = self._language_from_logits(
+            st['lang_logits'][:, 0].float(), n_audio, single)                # (brings the logits to the host: the pass has finished)
+        if one_row and not _retry and self._chain_gave_up("language pass"):
+            return self._detect_language_rows(audio_features, single, True)
+        if self.options.language is None:
+            self.tokens = torch.tensor([self.initial_tokens]).repeat(n_audio, 1)
+            self.tokens[:, self.sot_index + 1] = language_tokens.cpu()        # write language tokens
         return languages, language_probs
 
     def torch_detect_language(self, model, audio_features):
@@ -749,19 +761,28 @@ class WhisperDecoding:
             st['cross_key'], st['cross_xa'] = key, xa
         return st['cross']
 
-    def _chain_gave_up(self, where: str) -> bool:
-        """Did a one-launch decode step (csrc/gemv_chain.hip: batch-1 groups) give up waiting for its workgroups since the last look?
+    def _chain_gave_up(self, where: str, foreign: bool = False) -> bool:
+        """Did a one-launch decode step (csrc/gemv_chain.hip: groups of up to eight rows) give up waiting for its workgroups since the last look?
         The launch needs its workgroups resident together; another tenant holding CUs or LDS while it is dispatched makes its bounded
         waits expire, and everything decoded from that step is invalid.  The library then stops using the one-launch forms on this
         device (wm_decode_chain_error: acknowledged, the device takes a launch per kernel from now on); graphs captured with chain
-        launches are dropped.  Returns True when the caller has to decode again."""
+        launches are dropped -- those of EVERY WhisperDecoding of the process (another instance would go on replaying chain launches on
+        a device the library has taken off the form).  Returns True when the caller has to decode again.
+        `foreign`: the word was found set BEFORE this call issued anything -- an earlier call on this device (another instance, a
+        Session.run, a C caller) produced an invalid step and never looked.  That is said at error level EVERY time: acknowledging clears
+        the word, and the earlier caller's results stay wrong without anybody else being told."""
         err = C.c_int(0)
         native.check(native.load_library().wm_decode_chain_error(C.byref(err)), "wm_decode_chain_error")
         if not err.value:
             return False
-        for st in self._state.values():
-            st['graphs'].clear()
-        if not WhisperDecoding._chain_warned:
+        for inst in list(WhisperDecoding._instances):
+            for st in inst._state.values():
+                st['graphs'].clear()
+        if foreign:
+            logger.error("whisper_mi355: a one-launch decode step issued BEFORE this call (%s) gave up waiting for its workgroups and nobody "
+                         "looked: whatever that earlier call returned on this device is INVALID (decode it again).  Acknowledged here; the "
+                         "device takes a launch per kernel from now on (wm_set_decode_chain re-arms the one-launch step)", where)
+        elif not WhisperDecoding._chain_warned:
             WhisperDecoding._chain_warned = True
             logger.warning("whisper_mi355: a one-launch decode step gave up waiting for its workgroups (%s; the GPU was not free to hold them "
                            "together): decoding again with a launch per kernel, which this device uses from now on "
@@ -769,6 +790,7 @@ class WhisperDecoding:
         return True
 
     _chain_warned = False
+    _instances = weakref.WeakSet()
 
     def _live_list(self, st, n_micro, slot, lo, hi):
         """The group's list of rows still decoding (int32 [1 + n]: count, indices relative to the group), reset to
@@ -833,9 +855,10 @@ class WhisperDecoding:
         cfg = self.decoder_config
         V, cap = cfg['vocab_size'], cfg['num_text_ctx']
         st = self._fast_state(n_batch, dev)
-        one_row = any(hi - lo <= 8 for lo, hi in self._groups(n_batch)[1])      # groups of up to eight rows may run as ONE launch per token step
+        n_micro_, bounds_ = self._groups(n_batch)       # groups of up to eight rows stepped one at a time may run as ONE launch per token step
+        one_row = (n_micro_ == 1 or self.groups_sequential) and any(hi - lo <= 8 for lo, hi in bounds_)
         if one_row and not _retry and native.chain_status()["error_pending"]:   # (a peek at a host word: no synchronisation)
-            self._chain_gave_up("found before the decode loop")                 # somebody else's give-up: acknowledged, not ours to repeat
+            self._chain_gave_up("found before the decode loop", foreign=True)   # somebody else's give-up: said loudly, acknowledged, not ours to repeat
         if self.options.temperature != 0:     # a fresh seed per call from torch's generator: torch.manual_seed makes a run repeatable
             if not _retry:
                 st['seed'].copy_(torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32))
@@ -870,6 +893,9 @@ class WhisperDecoding:
         steps_done = 0
         lib = native.load_library()
         use_graph = self.use_graphs and self.decoder_session.qkv_amax is None
+        # stream-parallel groups: the steps of two groups are in flight at once, so none of them may take a one-launch form (two 256-workgroup
+        # launches side by side can each hold half of the chip and wait for the other half: ADVICE r5, whisper_mi355.h `not_alone`)
+        shared = n_micro > 1 and not self.groups_sequential
 
         def finish_step(gr, counter):
             # end of a group's step: advance its device step counter (graph replay) and, with per-row completion,
@@ -893,7 +919,7 @@ class WhisperDecoding:
                 gkey = (n_micro, slot, use_live)
                 if i == 0:
                     sess.decoder_step(gr['tokens'][:, :L0], pos[0:L0], gr['cross'], None, cap, gr['kv'], cap,
-                                      gr['logits'], 0, sm, slot=slot, live_rows=gr['live'])
+                                      gr['logits'], 0, sm, slot=slot, live_rows=gr['live'], not_alone=shared)
                     self._greedy(st, lo, hi, gr['logits'].data_ptr() + (L0 - 1) * V * 2, L0 * V, cur, sm)
                     finish_step(gr, None)
                 elif use_graph and gkey in st['graphs']:
@@ -906,7 +932,7 @@ class WhisperDecoding:
                         st['graphs'][gkey].replay()
                 else:
                     sess.decoder_step(gr['tokens'][:, cur - 1:cur], pos[cur - 1:cur], gr['cross'], gr['kv'], cap,
-                                      gr['kv'], cap, gr['logits'], cur - 1, sm, slot=slot, live_rows=gr['live'])
+                                      gr['kv'], cap, gr['logits'], cur - 1, sm, slot=slot, live_rows=gr['live'], not_alone=shared)
                     self._greedy(st, lo, hi, gr['logits'].data_ptr(), V, cur, sm)
                     finish_step(gr, None)
                     if use_graph:
@@ -922,7 +948,8 @@ class WhisperDecoding:
                         # encoder layer); the lock keeps the helper out of the driver for the length of the capture as well
                         with native.CAPTURE_LOCK, torch.cuda.graph(graph, stream=streams[slot], capture_error_mode="thread_local"):
                             sess.decoder_step(gr['tokens'], pos, gr['cross'], gr['kv'], cap, gr['kv'], cap,
-                                              gr['logits'], 1, sm, slot=slot, n_past_dev=counter, n_new=1, live_rows=gr['live'])
+                                              gr['logits'], 1, sm, slot=slot, n_past_dev=counter, n_new=1, live_rows=gr['live'],
+                                              not_alone=shared)
                             self._greedy(st, lo, hi, gr['logits'].data_ptr(), V, 0, sm, n_past_dev=counter)
                             finish_step(gr, counter)
                         st['graphs'][gkey], st['counters'][gkey] = graph, counter
@@ -956,6 +983,7 @@ class WhisperDecoding:
             main.wait_stream(s_)
         out = self._finish_main_loop(st, cur, L0, n_batch, ignore_eot,
                                      nsp_dev if self.tokenizer.no_speech is not None else None)
+        self._rep_cache = None        # the candidates' repeated features (best_of): the language pass and this loop have both used them
         if one_row and not _retry and self._chain_gave_up("decode loop"):
             # one-row groups run the token step as ONE launch whose workgroups wait for each other with bounded spins; a wait that was
             # given up invalidates the step and every token after it.  The utterance is decoded again, in this process, on the

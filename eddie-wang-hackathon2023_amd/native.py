@@ -82,12 +82,12 @@ EXPORTS = (
 )
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
 
 # Held by WhisperDecoding.main_loop for the length of a stream capture and by WhisperEncoding.prefetch's helper thread around every call
 # it makes into the HIP runtime (event queries, launches): a runtime call from another thread while a capture is open can invalidate it.
 import threading as _threading
-CAPTURE_LOCK = _threading.RLock()          # WM_ABI_VERSION of include/whisper_mi355.h this binding was written against
+CAPTURE_LOCK = _threading.RLock()
 
 
 class WmError(RuntimeError):
@@ -136,6 +136,7 @@ class WmDecoderIO(C.Structure):
         ("n_past_dev", C.c_void_p),
         ("live_rows", C.c_void_p),
         ("workspace_id", C.c_uint64),
+        ("not_alone", C.c_int32),
     ]
 
 

@@ -213,7 +213,7 @@ class Session(object):
                         present: Sequence[torch.Tensor], present_capacity: int, logits: torch.Tensor,
                         n_past: int, qkv_amax: Optional[torch.Tensor] = None, slot: int = 0,
                         n_past_dev: Optional[torch.Tensor] = None, n_new: Optional[int] = None,
-                        live_rows: Optional[torch.Tensor] = None) -> WmDecoderIO:
+                        live_rows: Optional[torch.Tensor] = None, not_alone: bool = False) -> WmDecoderIO:
         """The wm_decoder_io of one call.  tokens int32 [B, L] (any row stride: a column window of a wider
         buffer works); past/present per layer [B,2,H,capacity,64]; present may be the same tensors as past
         (in-place append).  The struct keeps its pointer arrays alive (`io._keep`)."""
@@ -250,13 +250,14 @@ class Session(object):
         if live_rows is not None:      # int32 [1 + B]: count, then the rows still decoding (wm_step_finish keeps it current)
             assert live_rows.dtype == torch.int32 and live_rows.numel() >= 1 + b and live_rows.is_contiguous()
         io.live_rows = live_rows.data_ptr() if live_rows is not None else None
+        io.not_alone = 1 if not_alone else 0      # other groups' steps in flight beside this one: never a one-launch form (whisper_mi355.h)
         io._keep = (past_arr, present_arr, cross_arr, ws, live_rows)
         return io
 
     def decoder_step(self, tokens, pos, cross, past, past_capacity, present, present_capacity, logits, n_past,
-                     stream: int, qkv_amax=None, slot: int = 0, n_past_dev=None, n_new=None, live_rows=None):
+                     stream: int, qkv_amax=None, slot: int = 0, n_past_dev=None, n_new=None, live_rows=None, not_alone: bool = False):
         io = self.make_decoder_io(tokens, pos, cross, past, past_capacity, present, present_capacity, logits, n_past,
-                                  qkv_amax, slot, n_past_dev, n_new, live_rows)
+                                  qkv_amax, slot, n_past_dev, n_new, live_rows, not_alone)
         check(self._engine.lib.wm_decoder_step(self._engine.handle, C.byref(io), stream), "wm_decoder_step")
 
     def decoder_step_multi(self, ios: Sequence[WmDecoderIO], light_streams: Sequence[int], heavy_stream: int):

@@ -59,8 +59,9 @@ typedef struct wm_dims {
  *   6  (round 4) wm_set_decode_chain / wm_decode_chain_error; wm_decoder_io gains `workspace_id` (appended)
  *   7  (round 5) the decoder workspace needs NO initialisation by the caller any more (the library clears the state it keeps there,
  *      on the stream of the call); a one-launch step that gave up makes the NEXT wm_decoder_step fail (rc 1) until
- *      wm_decode_chain_error has been called; wm_decode_chain_status, wm_debug_occupy                                            */
-#define WM_ABI_VERSION 7
+ *      wm_decode_chain_error has been called; wm_decode_chain_status, wm_debug_occupy
+ *   8  (round 6) wm_decoder_io gains `not_alone` (appended): the caller says when other decoder steps may run beside this one          */
+#define WM_ABI_VERSION 8
 int wm_version(void);
 const char* wm_last_error(void);
 int wm_device_count(int* out);
@@ -157,6 +158,12 @@ typedef struct wm_decoder_io {
      * initialised the state under this (address, id) before, the graph carries the initialisation and every replay repeats it --
      * issue one eager call first (as WhisperDecoding.main_loop does) to keep it out of the graph. */
     uint64_t workspace_id;
+    /* (ABI 8) non-zero: steps of OTHER utterance groups may be in flight on this device while this one runs (stream-parallel groups, as
+     * WhisperDecoding.main_loop issues them from 16 utterances up).  The one-launch forms of a group of up to eight rows need their 256
+     * workgroups resident TOGETHER; two such launches dispatched side by side can each hold half of the chip and wait for the other
+     * half until the bounded waits give up -- so a step that is not alone always takes a launch per kernel.  0 = the caller issues one
+     * decoder step at a time on this device (the reference's own schedule, W/decoding.py:785-821).  */
+    int32_t not_alone;
 } wm_decoder_io;
 size_t wm_decoder_workspace_bytes(const wm_engine* e, int batch, int n_new);
 int wm_decoder_step(const wm_engine* e, const wm_decoder_io* io, wm_stream_t stream);

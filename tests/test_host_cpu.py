@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/whisper_mi355.h but not exported"
     assert declared == set(native.EXPORTS)
-    assert lib.wm_version() == native.ABI_VERSION == 7
+    assert lib.wm_version() == native.ABI_VERSION == 8
 
 
 def test_struct_layouts_match_header(tmp_path):
