@@ -81,6 +81,13 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager-loop", action="store_true", help="lab: the decode loop with eager launches instead of replayed graphs (A/B runs of launch-level experiments)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank (self-test)")
+    ap.add_argument("--scatter-inputs", action="store_true",
+                    help="rank 0 draws the GLOBAL batch and scatters it over RCCL (the round-1..5 input path: 2.2 GB at 8 x 576 clips); default: every "
+                         "rank draws its own shard from (seed, rank).  The time either takes is reported (inputs.ms), outside the timed region")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the ranks of a multi-rank job to their GPU's NUMA cores (dp.pin_rank_to_gpu_numa)")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="tests/test_dp_gloo.py: the whole control flow of main() -- barriers, input shards, timed steps, gather, per-rank times, the one "
+                         "JSON line -- on CPU over gloo with stand-in engines (no GPU, no HIP library); never a measurement")
     return ap.parse_args()
 
 
@@ -402,6 +409,109 @@ def launch_ranks(args) -> int:
     return proc.returncode or 1
 
 
+class _HostEvent:
+    """What main() needs of an event when there is no GPU (--stub-engine): a host time stamp."""
+    def record(self, *_):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class _GpuRuntime:
+    """The few device services main()'s control flow uses, so that the same flow runs over gloo on CPU with stand-ins (_StubRuntime)."""
+    backend = "nccl"
+
+    def device(self, local_rank):
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def generator(self, dev, seed):
+        return torch.Generator(device=dev).manual_seed(seed)
+
+    def memory(self, dev):
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        return int(torch.cuda.memory_allocated(dev)), int(total_b - free_b)
+
+
+class _StubRuntime(_GpuRuntime):
+    backend = "gloo"
+
+    def device(self, local_rank):
+        return torch.device("cpu")
+
+    def sync(self):
+        pass
+
+    def event(self):
+        return _HostEvent()
+
+    def memory(self, dev):
+        return 0, 0
+
+
+class _StubEngines:
+    """Stand-ins for WhisperEncoding / WhisperDecoding with the surface main() drives (--stub-engine).  "Audio features" are the per-clip
+    mean of the mel, a token row is a function of its clip alone -- so the gathered result says whether every rank's rows arrived in order."""
+    class _Sess:
+        class engine:
+            weight_bytes = 0
+    session = decoder_session = cross_attn_session = _Sess
+    time_prefetch, prefetch_events, last_release_layer = False, [], None
+    use_graphs, micro_batches, sample_len, initial_token_length, sample_begin = True, None, 8, 3, 3
+    lang_id_sequential = groups_sequential = False
+
+    class tokenizer:
+        eot = 50257
+
+    def __init__(self):
+        self._pending = None
+
+    # encoder side
+    def get_audio_features_async(self, mel):
+        return mel.float().mean(dim=(1, 2))
+
+    def prefetch(self, mel, cus):
+        self._pending = self.get_audio_features_async(mel)
+
+    def collect(self):
+        xa, self._pending = self._pending, None
+        return xa
+
+    def loop_ended(self):
+        pass
+
+    # decoder side
+    def detect_language(self, xa):
+        return ["en"] * xa.shape[0], None
+
+    def _groups(self, n):
+        return 1, [(0, n)]
+
+    def balanced_order(self, n):
+        return list(range(n))
+
+    @staticmethod
+    def token_rows(xa, n_tokens):
+        base = (xa * 1e6).round().to(torch.int64).abs() % 40000
+        return base[:, None] + torch.arange(n_tokens, dtype=torch.int64)[None, :]
+
+    def main_loop(self, xa, ignore_eot=False, row_limit=None):
+        n = xa.shape[0]
+        t = self.token_rows(xa, self.initial_token_length + self.sample_len)
+        if row_limit is not None:
+            cut = self.initial_token_length + row_limit.to(torch.int64)[:, None]
+            t = torch.where(torch.arange(t.shape[1])[None, :] >= cut, torch.full_like(t, self.tokenizer.eot), t)
+        return t, -xa.float(), [0.0] * n
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -413,32 +523,56 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a different GPU count", file=sys.stderr)
         sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; before anything initialises the GPU
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # stdout carries ONE line, the JSON: RCCL prints a version banner on the C-level stdout when its communicator is torn down (five
+    # lines BEHIND the JSON line in profiles/r5z_bench_force_dist.json -- a driver that reads the last line of stdout would have read
+    # "Librccl path : ..."), and any other library may do the like.  File descriptor 1 is pointed at stderr for the life of the process;
+    # the line goes to the saved descriptor.  (Not under --stub-engine: the test captures sys.stdout.)
+    json_fd = None
+    if not args.stub_engine:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+    import dp
+    rt = _StubRuntime() if args.stub_engine else _GpuRuntime()
+    if args.stub_engine:            # the control-flow test: nothing below may touch a GPU, the probes are off
+        args.no_roofline = args.no_cpu_baseline = args.no_measure_traffic = True
+    # host placement BEFORE the first GPU call (the runtime's and torch's threads inherit the mask): every rank of a multi-rank job on the
+    # CPUs next to its GPU, ranks that share a NUMA node on disjoint slices of it.  One rank alone is left where the OS put it (nothing to
+    # keep apart -- and the cpu_baseline leg of a one-rank run wants every core)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    affinity = (dp.pin_rank_to_gpu_numa(local_rank, local_world) if world > 1 and not args.no_pin
+                else {"pinned": False, "how": "one rank: left to the OS" if world == 1 else "--no-pin"})
+    dev = rt.device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.stub_engine:
+            dist.init_process_group(rt.backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(rt.backend, rank=rank, world_size=world, device_id=dev)
 
-    import native
-    import dp
     import synthetic
-    from decoding import WhisperDecoding
-    from encoding import WhisperEncoding
-    lib = native.load_library()
+    if args.stub_engine:
+        native = lib = None
+    else:
+        import native
+        from decoding import WhisperDecoding
+        from encoding import WhisperEncoding
+        lib = native.load_library()
 
     # ---- engines: rank 0 builds once per box, everybody loads its own replica ----------------------
     eng_dir = Path(args.engine_cache) / f"{args.model}-{args.config}-seed{args.seed}"
     build_s = 0.0
-    if rank == 0 and not (eng_dir / "decoder_config.json").exists():
+    if rank == 0 and not args.stub_engine and not (eng_dir / "decoder_config.json").exists():
         eng_dir.parent.mkdir(parents=True, exist_ok=True)
         build_s = build_engines(args, eng_dir)
     if use_dist:
         dist.barrier()
-    enc, dec = WhisperEncoding(eng_dir), WhisperDecoding(eng_dir)
+    if args.stub_engine:
+        enc = dec = _StubEngines()
+    else:
+        enc, dec = WhisperEncoding(eng_dir), WhisperDecoding(eng_dir)
     dec.sample_len = args.decode_steps
     if args.eager_loop:
         dec.use_graphs = False
@@ -447,14 +581,27 @@ def main():
     dims = synthetic.DIMS[args.model]
     B, T = args.batch, args.decode_steps
 
-    # ---- inputs: rank 0 draws the global batch, shards it (scatter over RCCL), resident before timing --
+    # ---- inputs, resident before timing.  Default: every rank draws ITS OWN shard, N(0, 0.5) clipped to [-0.5, 1.5] like
+    # synthetic.synthetic_mel, from (seed 1234, rank) on its own device -- utterances are independent, nothing has to travel (rank 0
+    # keeps seed 1234 itself: a one-rank job draws what it always drew).  --scatter-inputs: the round-1..5 path, rank 0 draws the
+    # global batch (2.2 GB at 8 x 576 clips) and scatters it over RCCL -- what a job that reads its audio on one rank would do.
     n_total = B * world
-    mels = None
-    if rank == 0:     # N(0, 0.5) clipped to [-0.5, 1.5] like synthetic.synthetic_mel, drawn on the GPU (n_total can be 1024 clips)
-        g = torch.Generator(device=dev).manual_seed(1234)
-        mels = (torch.randn((n_total, dims["n_mels"], 2 * dims["n_audio_ctx"]), generator=g, device=dev) * 0.5).clamp_(-0.5, 1.5).half()
-    mel = dp.scatter_utterances(mels, n_total, (dims["n_mels"], 2 * dims["n_audio_ctx"]), torch.float16, dev).contiguous()
-    del mels
+    feat = (dims["n_mels"], 2 * dims["n_audio_ctx"])
+
+    def draw(n, seed):
+        g = rt.generator(dev, seed)
+        return (torch.randn((n, *feat), generator=g, device=dev) * 0.5).clamp_(-0.5, 1.5).half()
+    t_in = time.perf_counter()
+    if args.scatter_inputs:
+        mels = draw(n_total, 1234) if rank == 0 else None
+        mel = dp.scatter_utterances(mels, n_total, feat, torch.float16, dev).contiguous()
+        del mels
+    else:
+        lo_, hi_ = dp.shard_bounds(n_total, rank, world)
+        mel = draw(hi_ - lo_, dp.rank_seed(1234, rank))
+    rt.sync()
+    inputs = {"mode": "scatter from rank 0" if args.scatter_inputs else "every rank draws its own shard from (seed, rank)",
+              "ms": round((time.perf_counter() - t_in) * 1e3, 1), "bytes_per_rank": int(mel.numel() * mel.element_size())}
     width = dec.initial_token_length + T
 
     loop_events = []            # (start, end) of every decode loop: torch events on the current stream, which main_loop
@@ -467,7 +614,7 @@ def main():
     # the MFMA-bound encoder of batch n + 1 runs beside it on a budget of CUs (WhisperEncoding.prefetch).  Every step's
     # encoder runs inside the region that is timed: the first one in the open, the last decode loop with nothing beside it.
     def mark():
-        e = torch.cuda.Event(enable_timing=True)
+        e = rt.event()
         e.record()
         return e
 
@@ -498,19 +645,27 @@ def main():
         out = step(k + 1 < args.warmup)
     if use_dist:                    # (the timed region runs the product's default schedule: no sampler, no group-by-group pass)
         dist.barrier()
-    torch.cuda.synchronize()
+    rt.sync()
     loop_events.clear()
     stage_events.clear()
     enc.prefetch_events = []
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = step(k + 1 < args.steps)
-    torch.cuda.synchronize()
+    rt.sync()
     if use_dist:
         dist.barrier()
     my_elapsed = time.perf_counter() - t0
     elapsed = dp.max_over_ranks(my_elapsed, dev)
     per_rank_ms = dp.all_ranks(my_elapsed / args.steps * 1e3, dev)       # every rank's own ms per step: imbalance shows at a glance
+    per_rank_cpus = dp.all_ranks(float(affinity.get("cpus") or 0), dev)
+    per_rank_first = dp.all_ranks(float(affinity.get("first_cpu") if affinity.get("first_cpu") is not None else -1), dev)
+    per_rank_input_ms = dp.all_ranks(inputs["ms"], dev)
+    gathered = None
+    if rank == 0 and out is not None:      # what the last step's gather brought to rank 0: rows of every rank, in utterance order
+        g_tok, g_lp = out
+        gathered = {"rows": int(g_tok.shape[0]), "width": int(g_tok.shape[1]),
+                    "token_checksum": int(g_tok.to(torch.int64).sum().item() % (1 << 31)), "rows_expected": int(n_total)}
 
     # ---- where a step's time goes (GPU events of the timed steps; the review's "make the line tell the truth about the schedule") ----
     def _mean(xs):
@@ -588,13 +743,13 @@ def main():
         def ragged_step(limits):
             xa_r = enc.get_audio_features_async(mel)
             dec.detect_language(xa_r)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = rt.event(), rt.event()
             e0.record()
             tokens, sum_lp, _ = dec.main_loop(xa_r, row_limit=torch.as_tensor(limits, dtype=torch.int32))
             e1.record()
             return tokens, e0, e1
         tokens_r, _, _ = ragged_step(batches[0])
-        torch.cuda.synchronize()
+        rt.sync()
         eot = dec.tokenizer.eot
         got = (tokens_r[:, dec.sample_begin:] != eot).sum(dim=1).cpu().numpy()
         if use_dist:
@@ -604,7 +759,7 @@ def main():
         for limits in batches:
             _, e0, e1 = ragged_step(limits)
             loops.append((e0, e1))
-        torch.cuda.synchronize()
+        rt.sync()
         if use_dist:
             dist.barrier()
         r_elapsed = dp.max_over_ranks(time.perf_counter() - t_r, dev)
@@ -615,7 +770,7 @@ def main():
         if args.encoder_cus > 0:
             if use_dist:
                 dist.barrier()
-            torch.cuda.synchronize()
+            rt.sync()
             t_p = time.perf_counter()
             xa_p = enc.get_audio_features_async(mel)
             for i, limits in enumerate(batches):
@@ -627,7 +782,7 @@ def main():
                 if i + 1 < len(batches):
                     xa_p = enc.collect()
                     released.append(enc.last_release_layer)
-            torch.cuda.synchronize()
+            rt.sync()
             if use_dist:
                 dist.barrier()
             rp_elapsed = dp.max_over_ranks(time.perf_counter() - t_p, dev)
@@ -666,8 +821,7 @@ def main():
     decode_loop_ms = float(np.mean(alone)) if alone else None
     decode_loop_shared_ms = float(np.mean(shared)) if shared else None
     weight_bytes = sum(sess.engine.weight_bytes for sess in (enc.session, dec.decoder_session, dec.cross_attn_session))
-    torch_bytes = torch.cuda.memory_allocated(dev)
-    free_b, total_b = torch.cuda.mem_get_info(dev)
+    torch_bytes, device_in_use = rt.memory(dev)
     roofline = None
     if not args.no_roofline:
         avg_ms, n_samples = kernel_ms.get("in_loop") or (None, 0)
@@ -756,14 +910,23 @@ def main():
                 lin_bytes = Lt * 14 * Ct * Ct * (0.5 if wo_cfg == "int4" else 1 if wo_cfg else 2)      # per layer: qkv 3 + out 1, cross q 1 + out 1, mlp 8 (x C^2; the cross k / v projections live in their own engine): 734.0 MB int8 at large-v2
                 logit_bytes = V * Ct * 2
                 self_bytes = B * Lt * 2 * Ct * (dec.initial_token_length + T / 2.0) * (1 if i8kv_cfg else 2)
-                all_bytes = n_micro * (lin_bytes + logit_bytes) + cross_bytes + self_bytes
+                # SURVEY 8d counts W_dec + W_logits ONCE per step whatever the schedule; the stream-parallel groups each stream them again --
+                # bytes that move but are not useful work, so they are NOT in the fraction (rounds 1-5 multiplied the
+                # weights by the group count and so credited the re-reads); the re-read factor and the as-streamed total stand beside it
+                all_bytes = (lin_bytes + logit_bytes) + cross_bytes + self_bytes
+                streamed_bytes = n_micro * (lin_bytes + logit_bytes) + cross_bytes + self_bytes
                 roofline.update({"decode_loop_ms": round(decode_loop_ms, 2), "decode_step_ms": round(step_ms, 3),
                                  "decode_step_frac": round(all_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "decode_step_bytes": {"linear_weights": int(lin_bytes), "logits_matrix": int(logit_bytes), "utterance_groups": n_micro,
-                                                       "cross_kv": int(cross_bytes), "self_kv_mean": int(self_bytes), "total": int(all_bytes)},
+                                 "decode_step_bytes": {"linear_weights": int(lin_bytes), "logits_matrix": int(logit_bytes),
+                                                       "cross_kv": int(cross_bytes), "self_kv_mean": int(self_bytes), "total": int(all_bytes),
+                                                       "utterance_groups": n_micro, "weight_reread_factor": n_micro,
+                                                       "total_as_streamed": int(streamed_bytes)},
+                                 "decode_step_frac_as_streamed": round(streamed_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "decode_step_frac_cross_kv_only": round(cross_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "decode_step_note": "SURVEY 8d bytes of one token step -- (Linear weights + logits matrix) x utterance groups + cross K/V of the "
-                                                     "whole batch + self-attention cache at the loop's mean length -- / (decode loop time / tokens) / 8 TB/s"
+                                 "decode_step_note": "SURVEY 8d bytes of one token step -- Linear weights + logits matrix ONCE + cross K/V of the "
+                                                     "whole batch + self-attention cache at the loop's mean length -- / (decode loop time / tokens) / 8 TB/s; "
+                                                     "every utterance group streams the weights again (weight_reread_factor): those bytes are in "
+                                                     "total_as_streamed / decode_step_frac_as_streamed only"
                                                      + ("; decode loops with nothing beside them (the last step's)" if shared else "")})
                 if roofline["achieved"] is None:
                     roofline["achieved"] = round(all_bytes / (step_ms * 1e-3) / 1e9, 1)
@@ -804,27 +967,41 @@ def main():
                        "parallelism": f"dp{world} (utterance sharding, no "
                                                                             f"data-path collective)"},
             "engine_build_s": round(build_s, 1),
+            # multi-rank hygiene: how the inputs reached the ranks (outside the timed region), where each rank's process sits on the host,
+            # what the last gather delivered, and whether a one-launch decode step was declined or gave up during this run
+            "inputs": dict(inputs, ms_per_rank=[round(x, 1) for x in per_rank_input_ms]),
+            "affinity": dict(affinity, cpus_per_rank=[int(x) for x in per_rank_cpus], first_cpu_per_rank=[int(x) for x in per_rank_first]),
+            "gathered": gathered,
+            "decode_chain": (None if native is None else {k: v for k, v in native.chain_status().items() if k != "footprint"}),
             # what sits in HBM while the job runs: engine weights (hipMalloc'ed by the library: weight-only encoder / cross-K/V
             # matrices are resident ONCE, as their fp16 expansion), everything torch allocated for the path (mel, encoder output,
             # KV cache, cross K/V, logits, workspaces), and the device-level figure the reference's memory chart reports
             # (README.md:178-180: 9.3-11.3 GB at batch 1 on an A10)
             "hbm_bytes_resident": {"engine_weights": int(weight_bytes), "buffers": int(torch_bytes),
-                                   "device_in_use": int(total_b - free_b), "batch_per_gpu": B},
+                                   "device_in_use": int(device_in_use), "batch_per_gpu": B},
             "pipeline": pipeline,
             "roofline": roofline,
             "second_figure": ragged,
             # arithmetic-order / scheduling knobs read from the environment, echoed when set (defaults otherwise)
             "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("WM_")} or None,
             # what the package did to the HIP runtime's environment (and whether in time), the lab knobs the LIBRARY honoured (WM_LAB=1 only)
-            "runtime": native.runtime_report(),
+            "runtime": native.runtime_report() if native is not None else None,
             "hip_runtime_knobs": {k: os.environ[k] for k in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "GPU_MAX_HW_QUEUES", "AMD_OPT_FLUSH") if k in os.environ},
         }
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(args, T)
-        print(json.dumps(result), flush=True)
+    # every rank is done with the GPU and with its peers BEFORE rank 0 starts anything long on the host: the last barrier and the process
+    # group's teardown come first, the cpu_baseline leg (one rank only: ~ 150 s of host work) and the line afterwards -- no rank ever sits
+    # in a collective waiting for rank 0's CPU work
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(args, T)
+        if json_fd is None:
+            print(json.dumps(result), flush=True)
+        else:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(result) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -240,6 +240,24 @@ def woq_reference_matmul(x: np.ndarray, q_in_out: np.ndarray, scales: np.ndarray
     return (ref * scales.astype(np.float32)[None, :]).astype(np.float16)
 
 
+def woq_gemv_reference(x: np.ndarray, q_in_out: np.ndarray, scales: np.ndarray) -> np.ndarray:
+    """The reference's OWN M = 1 kernel, restated (int8_weight_only_gemv_interleave,
+    R/cpp/tensorrt_llm/kernels/weightOnlyMatrixVectorMultiplication.cu:136-205; the plugin takes it exactly when the activation
+    has one row, weightOnlyQuantMatmulPlugin.cpp:182-197):
+        w16 = fp16(fp16(q) * scale)                        (:44-53 `halves[i] *= scale`)
+        p   = fp16(x * w16)              PER ELEMENT       (:187 `__hmul`: every product is rounded to fp16 ...)
+        y   = fp16(sum_fp32(p))                            (:187 `v += __half2float(..)`, :190-193 shuffles, :198-203 `__float2half_rn`)
+    The M > 1 path of the same plugin (CUTLASS fpA_intB, default_fpA_intB_traits.h:30-109) multiplies the same w16 on tensor cores:
+    EXACT fp16 x fp16 products into an fp32 accumulator -- so the reference disagrees with itself between M = 1 and M > 1 by the
+    rounding of every product.  x [K] or [1, K] fp16, q [K, N] int8, scales [N] fp16 -> [1, N] fp16.
+    (The order of the fp32 additions -- 16 elements per lane and stride, then four shuffles -- is not restated: numpy's pairwise
+    fp32 sum differs from it by fp32 summation order only, ~1e-7 relative, four orders below the product rounding.)"""
+    x = np.asarray(x, dtype=np.float16).reshape(-1)
+    w16 = (q_in_out.astype(np.float16) * np.asarray(scales, dtype=np.float16)[None, :]).astype(np.float16)      # [K, N]
+    p = (x[:, None] * w16).astype(np.float16)          # numpy multiplies halves in fp32 (exact) and rounds once: = __hmul
+    return p.astype(np.float32).sum(axis=0, dtype=np.float32).astype(np.float16)[None, :]
+
+
 def woq_colwise_atol(ref: np.ndarray) -> np.ndarray:
     """Tolerance the reference accepts (R/tests/quantization/_utils.py:66-88):
     per column 1.5 * max(col) / 128 for M > 1, one global bound for M == 1."""
@@ -290,6 +308,11 @@ class OracleConfig:
     # of the dequantised K / V: scores = r16(qh . (code_k * t * d^-0.25)), out = r16(w . (code_v * t))).
     int8_cross_kv: bool = False
     cross_kv_scales: Optional[List[float]] = None   # t per decoder layer: max(|K|, |V|) / 127 of that layer's cross K/V
+    # The reference's weight-only plugin takes its GEMV kernel when the activation has ONE row, and that kernel rounds every product
+    # to fp16 before the fp32 sum (woq_gemv_reference above); with more rows it takes CUTLASS: exact products.  False (default): the
+    # CUTLASS contract at every M -- what the engine's Linears compute (DESIGN.md section 2 "M = 1").  True: weight-only Linears
+    # whose input is one row use the GEMV kernel's arithmetic, as the reference's engines do at batch 1 after the prefill.
+    gemv_fp16_products: bool = False
 
 
 def _gelu(x: torch.Tensor, kind: str) -> torch.Tensor:
@@ -330,6 +353,15 @@ class OracleModel:
 
     # -- primitives --------------------------------------------------------------------
     def _linear(self, x, wkey, bkey=None):
+        if self.cfg.gemv_fp16_products and wkey in self.q and x.numel() == x.shape[-1] and self.cfg.act == "float16":
+            # one activation row through a weight-only Linear: the reference's GEMV kernel (fp16-rounded products, fp32 sum); the
+            # bias is added to the fp16 result by a separate element-wise layer (quantization/layer.py:311-312): a second rounding
+            w16 = self.p[wkey]                                        # [N, K], fp16-representable (dequantize_int8)
+            prod = (x.reshape(1, -1) * w16).half().float()            # exact fp32 products of fp16 values, each rounded to fp16
+            y = prod.sum(dim=1, dtype=torch.float32).half().float().reshape(*x.shape[:-1], -1)
+            if bkey is not None:
+                y = y + self.p[bkey]
+            return _r(y, self.cfg.act)
         y = x @ self.p[wkey].t()
         if bkey is not None:
             y = y + self.p[bkey]

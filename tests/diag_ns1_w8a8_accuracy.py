@@ -10,10 +10,10 @@ do to the M = 1500 x batch GEMMs it could serve -- the encoder blocks' Linears a
 
 against the W8A16 oracle (same int8 weights), on the tiny.en-shaped 2 + 2 layer model of tests/golden (384 wide, 1500 audio
 positions) and on the micro model.  Prints max |d| of the encoder output, of the cross K/V and of teacher-forced logits, and
-greedy-id agreement.   usage: python scripts/experiments/ns1_w8a8_accuracy.py
+greedy-id agreement.   usage: python tests/diag_ns1_w8a8_accuracy.py
 """
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -154,3 +154,86 @@ def test_summarize_rank_sharded_path_world2_gloo(tmp_path):
     ret = mgr.dict()
     mp.spawn(_summarize_worker, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _bench_main_worker(rank, world, port, out_dir, extra):
+    """One rank of `bench.py --gpus 2 --stub-engine`: the environment torch.distributed.run would give it, stdout into a file."""
+    import contextlib
+    import io
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LOCAL_WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "5", "--decode-steps", "6", "--stub-engine"] + list(extra)
+    before = sorted(os.sched_getaffinity(0))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    with open(os.path.join(out_dir, f"rank{rank}.out"), "w") as f:
+        f.write(buf.getvalue())
+    with open(os.path.join(out_dir, f"rank{rank}.aff"), "w") as f:
+        f.write(",".join(map(str, sorted(os.sched_getaffinity(0)))) + "|" + ",".join(map(str, before)))
+    assert not dist.is_initialized()          # main() tore its process group down (before rank 0's host-side epilogue)
+
+
+@pytest.mark.parametrize("extra", [(), ("--scatter-inputs",), ("--encoder-cus", "0", "--length-dist", "forced")])
+def test_bench_main_control_flow_world2_gloo(tmp_path, extra):
+    """the WHOLE control flow of bench.main with two ranks before an 8-GPU node ever runs it -- placement of the ranks,
+    per-rank input shards (or the scatter from rank 0), warm-up, the barrier-bracketed timed steps with the pipelined encoder hand-over,
+    the gather of every step, max-over-ranks, the per-rank lists, the second figure's extra batches, the final barrier and the
+    process group's teardown BEFORE rank 0's host-side epilogue -- on CPU over gloo with stand-in engines (bench.py --stub-engine).
+    Exactly ONE JSON line, from rank 0, with n_gpus 2; the gathered rows are both ranks' rows in utterance order."""
+    import json
+    port = _free_port()
+    mp.spawn(_bench_main_worker, args=(2, port, str(tmp_path), extra), nprocs=2, join=True)
+    out0, out1 = (tmp_path / "rank0.out").read_text(), (tmp_path / "rank1.out").read_text()
+    assert out1.strip() == "", "only rank 0 prints"
+    lines = [l for l in out0.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["unit"] == "tokens/s" and d["vs_baseline"] is None and "cpu_baseline" not in d       # (the CPU leg is a one-rank leg)
+    assert d["config"]["batch_per_gpu"] == 5 and "dp2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 5 * 6 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"] + 0.1     # whole-job tokens / max-over-ranks time
+    pr = d["ms_per_step_per_rank"]
+    assert len(pr["all"]) == 2 and pr["max"] == max(pr["all"]) and d["ms_per_step"] >= pr["max"] - 0.02
+    assert d["gathered"]["rows"] == d["gathered"]["rows_expected"] == 10 and d["gathered"]["width"] == 3 + 6
+    assert len(d["inputs"]["ms_per_rank"]) == 2 and d["inputs"]["bytes_per_rank"] == 5 * 80 * 3000 * 2
+    assert ("scatter" in d["inputs"]["mode"]) == ("--scatter-inputs" in extra)
+    # the gathered rows: every rank's own shard, rank order = utterance order (the stand-in's token rows are a function of the clip alone)
+    import bench
+    import dp as _dp
+    want = []
+    for r in range(2):
+        if "--scatter-inputs" in extra:
+            g = torch.Generator().manual_seed(1234)
+            mel = (torch.randn((10, 80, 3000), generator=g) * 0.5).clamp_(-0.5, 1.5).half()[r * 5:(r + 1) * 5]
+        else:
+            g = torch.Generator().manual_seed(_dp.rank_seed(1234, r))
+            mel = (torch.randn((5, 80, 3000), generator=g) * 0.5).clamp_(-0.5, 1.5).half()
+        want.append(bench._StubEngines.token_rows(mel.float().mean(dim=(1, 2)), 9))
+    assert d["gathered"]["token_checksum"] == int(torch.cat(want).sum().item() % (1 << 31))
+    # placement: two ranks on this host were pinned to disjoint CPU sets (the GPU's NUMA node is unknown here: even slices)
+    aff = [(tmp_path / f"rank{r}.aff").read_text().split("|") for r in range(2)]
+    sets = [set(a[0].split(",")) for a in aff]
+    n_before = len(aff[0][1].split(","))
+    if n_before >= 2:
+        assert d["affinity"]["pinned"] and sets[0].isdisjoint(sets[1]) and sum(d["affinity"]["cpus_per_rank"]) <= n_before
+    if "--length-dist" not in extra:
+        sf = d["second_figure"]
+        assert sf["tokens_match_the_limits"] is True and sf["useful_tokens_per_s"] > 0 and sf["ms_per_batch_pipelined"] is not None
+
+
+def test_rank_placement_plan():
+    """dp.plan_rank_cpus: ranks that share their GPU's NUMA node get disjoint slices of it; an unknown node falls back to even slices."""
+    node_cpus = {0: list(range(0, 48)) + list(range(96, 144)), 1: list(range(48, 96)) + list(range(144, 192))}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = range(192)
+    got = [dp.plan_rank_cpus(r, 8, allowed, nodes, node_cpus)[0] for r in range(8)]
+    assert all(len(g) == 24 for g in got) and len(set().union(*map(set, got))) == 192
+    assert set(got[0]) <= set(node_cpus[0]) and set(got[5]) <= set(node_cpus[1])
+    assert dp.plan_rank_cpus(3, 8, range(16), [None] * 8, {})[0] == [6, 7]
+    assert dp.plan_rank_cpus(0, 1, range(8), [None], {})[0] == list(range(8))
+    assert dp._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert dp.rank_seed(1234, 0) == 1234 and len({dp.rank_seed(1234, r) for r in range(8)}) == 8

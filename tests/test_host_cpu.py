@@ -408,3 +408,32 @@ def test_no_prefetch_load_is_waited_for_where_it_is_issued():
     bad, report = mod.check()
     assert report, "no kernel found"
     assert not bad, bad
+
+
+def test_only_the_checkers_import_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it (the product
+    path has no CPU fallback).  Every Python file of the package, of scripts/ and the two root scripts is read; an `oracle` import
+    anywhere else -- or outside those two functions -- fails here (a script under scripts/ still did)."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for fn in ast.walk(tree):
+            for node in ast.iter_child_nodes(fn):
+                mod = node.module if isinstance(node, ast.ImportFrom) else None
+                names = [a.name for a in node.names] if isinstance(node, ast.Import) else []
+                if (mod and mod.split(".")[0] == "oracle") or any(n.split(".")[0] == "oracle" for n in names):
+                    hits.append(getattr(fn, "name", "<module>"))
+        return hits
+
+    offenders = []
+    for base in ("eddie-wang-hackathon2023_amd", "scripts"):
+        for dirpath, _, files in os.walk(os.path.join(root, base)):
+            for f in files:
+                if f.endswith(".py") and oracle_imports(os.path.join(dirpath, f)):
+                    offenders.append(os.path.relpath(os.path.join(dirpath, f), root))
+    assert offenders == [], offenders
+    assert set(oracle_imports(os.path.join(root, "bench.py"))) <= {"cpu_baseline"}
+    assert set(oracle_imports(os.path.join(root, "__graft_entry__.py"))) <= {"smoke"}
