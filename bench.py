@@ -604,6 +604,7 @@ def main():
               "ms": round((time.perf_counter() - t_in) * 1e3, 1), "bytes_per_rank": int(mel.numel() * mel.element_size())}
     width = dec.initial_token_length + T
 
+    first_token_events = []     # per step: (step start, encoder output ready, first sampled token exists, encoder was prefetched)
     loop_events = []            # (start, end) of every decode loop: torch events on the current stream, which main_loop
     last = {}                   # joins with its group streams before it returns
     stage_events = []           # per step: the stage boundaries (see step())
@@ -632,10 +633,14 @@ def main():
         if last["prefetched"]:
             enc.prefetch(mel, args.encoder_cus)
         e0 = mark()
+        ft = rt.event()
+        dec.first_token_event = ft
         tokens, sum_lp, _ = dec.main_loop(xa, ignore_eot=True)
+        dec.first_token_event = None
         enc.loop_ended()            # the prefetched pass gives back its CU budget once the GPU is past this point
         e1 = mark()
         loop_events.append((e0, e1, last["prefetched"]))
+        first_token_events.append((s0, s1, ft, was_prefetched))
         last["xa"] = xa
         res = dp.gather_results(tokens, sum_lp, n_total, width, dec.tokenizer.eot)
         stage_events.append((s0, s1, s2, e0, e1, mark(), was_prefetched))
@@ -648,6 +653,7 @@ def main():
     rt.sync()
     loop_events.clear()
     stage_events.clear()
+    first_token_events.clear()
     enc.prefetch_events = []
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -670,6 +676,12 @@ def main():
     # ---- where a step's time goes (GPU events of the timed steps; the review's "make the line tell the truth about the schedule") ----
     def _mean(xs):
         return round(float(np.mean(xs)), 2) if len(xs) else None
+
+    def _span(a, b):             # ms between two events, None when one of them was never recorded (the stand-in decoder of --stub-engine)
+        try:
+            return a.elapsed_time(b)
+        except Exception:        # noqa: BLE001
+            return None
     pre = list(getattr(enc, "prefetch_events", []))
     pipeline = {
         "encoder_in_the_open_ms": _mean([a[0].elapsed_time(a[1]) for a in stage_events if not a[6]]),
@@ -680,6 +692,11 @@ def main():
         "gather_ms": _mean([a[4].elapsed_time(a[5]) for a in stage_events]),
         "other_ms": _mean([a[2].elapsed_time(a[3]) for a in stage_events]),
         "sum_per_step_ms": round(sum(a[0].elapsed_time(a[5]) for a in stage_events) / max(len(stage_events), 1), 2),
+        # latency to the FIRST sampled token of a batch (W/run.py's user waits for this before any text exists): from the encoder's output
+        # being ready (cross-K/V projection + language pass + 3-token prefill + the first greedy step) and from the start of a step whose
+        # encoder ran in the open (the whole path from the mel)
+        "first_token_after_encoder_ms": _mean([x for x in (_span(a[1], a[2]) for a in first_token_events) if x is not None]),
+        "first_token_from_mel_ms": _mean([x for x in (_span(a[0], a[2]) for a in first_token_events if not a[3]) if x is not None]),
         "note": "means over the timed steps, GPU events on the stream that drives a step: the first step's encoder runs in the open, "
                 "the others beside the previous step's decode loop (encoder_prefetch_ms = that pass on its own stream, start to end; "
                 "collect_wait_ms = what the next step still waits for it after the loop has ended); sum_per_step_ms adds the stages of "

@@ -262,6 +262,7 @@ class WhisperDecoding:
         # and a group whose rows have all finished is no longer stepped.  Results are unchanged: a finished row is kept at
         # EOT whatever its logits.  Off for `ignore_eot` loops (benchmarks decode a fixed number of tokens).
         self.skip_finished_rows = True
+        self.first_token_event = None     # bench.py: an event recorded (current stream) when the first sampled token of a main_loop call exists
         self._streams = []
         self._no_dedicated_queues = False
         WhisperDecoding._instances.add(self)      # (weak: a give-up of a one-launch step drops the graphs of EVERY instance, _chain_gave_up)
@@ -961,6 +962,13 @@ class WhisperDecoding:
                     main.wait_stream(s_)
                 probs_at_sot = st['logits'][:, self.sot_index].float().softmax(dim=-1)
                 nsp_dev = probs_at_sot[:, self.tokenizer.no_speech]
+                for s_ in streams:
+                    s_.wait_stream(main)
+            if i == 0 and self.first_token_event is not None:
+                # latency probe (bench.py): the first sampled token of every row exists once the groups' first steps have run
+                for s_ in streams:
+                    main.wait_stream(s_)
+                self.first_token_event.record(main)
                 for s_ in streams:
                     s_.wait_stream(main)
             cur += 1
