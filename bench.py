@@ -192,6 +192,56 @@ def cpu_baseline(args, decode_steps: int, time_cap_s: float = 150.0):
     return out
 
 
+def wer_block(args) -> dict:
+    """BASELINE.json's third metric: WER of the benchmarked configuration against the fp16 engines on LibriSpeech test-clean, through
+    summarize.py (the reference's own evaluation, W/summarize.py:72-181: clips over 30 s skipped, English normaliser, corpus WER).
+    Needs real weights and real audio: WM_CHECKPOINT = an OpenAI `.pt` ({'dims', 'model_state_dict'}: W/build.py:146-147) and
+    WM_LIBRISPEECH = a test-clean directory (FLAC + *.trans.txt).  No box of this project has had either, so the block says
+    "not measured" and why -- it never invents a number.  With both: fp16 engines and the benchmarked config are built from the
+    checkpoint (int8 KV scales calibrated on the first utterance of each chapter, the reference's calibration set, W/trans_data.py:20-38),
+    both transcribe the set, the block carries both WERs and their difference (north_star: within 0.1)."""
+    ck, ds = os.environ.get("WM_CHECKPOINT"), os.environ.get("WM_LIBRISPEECH")
+    if not ck or not ds or not os.path.exists(ck) or not os.path.isdir(ds):
+        return {"wer": "not measured",
+                "why": "needs real weights and audio: set WM_CHECKPOINT (large-v2.pt) and WM_LIBRISPEECH (test-clean directory); "
+                       f"WM_CHECKPOINT {'missing' if not ck or not os.path.exists(ck) else 'present'}, "
+                       f"WM_LIBRISPEECH {'missing' if not ds or not os.path.isdir(ds) else 'present'} (SURVEY 8d: otherwise report not measured)"}
+    try:
+        import tempfile
+        import build as B
+        import summarize as S
+        import torch_whisper_convert as TWC
+        wo, i8kv = CONFIGS[args.config]
+        model = torch.load(ck, map_location="cpu")
+        out = {}
+        with tempfile.TemporaryDirectory(prefix="wm_wer_") as tmp:
+            base = ["--log_level", "error", "--use_gpt_attention_plugin", "--use_gemm_plugin", "--use_layernorm_plugin"]
+            fp16_dir = os.path.join(tmp, "fp16")
+            B.build_from_checkpoint(model, B.parse_arguments(["--output_dir", fp16_dir] + base))
+            cfg_dir = os.path.join(tmp, args.config)
+            argv = ["--output_dir", cfg_dir] + base + (["--use_weight_only"] if wo else []) + (["--weight_only_precision", "int4"] if wo == "int4" else [])
+            if i8kv:
+                pairs = S.discover(ds)
+                first_of_chapter = {}
+                for f, _ in pairs:
+                    first_of_chapter.setdefault(f.parent, f)
+                audio = [S.load_audio(str(f)) for f in sorted(first_of_chapter.values())[:87]]
+                mels = S.mel_batch(audio, torch.device("cuda"))
+                amax = TWC.capture_kv_activation_range(fp16_dir, mels, batch=8)
+                argv += ["--int8_kv_cache", "--quantize_dir", str(TWC.write_kv_scales(os.path.join(tmp, "quantize"), amax, {"source": "bench.py wer_block"}))]
+            B.build_from_checkpoint(model, B.parse_arguments(argv))
+            del model
+            for name, d in (("fp16", fp16_dir), (args.config, cfg_dir)):
+                rep = S.main(S.parse_arguments(["--test_trt_llm", "--engine_dir", d, "--dataset_dir", ds, "--batch_size", "64", "--log_level", "error"]))
+                r = rep["whisper-mi355"]
+                out[name] = {"wer_percent": round(100 * r["wer"], 3), "utterances": r["utterances"], "seconds": round(r["seconds"], 1)}
+        out["delta_percent_points"] = round(out[args.config]["wer_percent"] - out["fp16"]["wer_percent"], 3)
+        out["reference_published"] = "README.md:166-173: PyTorch fp16 4.19, TRT-LLM 3.91, int8 weight-only 2.76, int8 KV 4.32 (A10, other hardware)"
+        return {"wer": out}
+    except Exception as e:       # noqa: BLE001 -- an evaluation problem must not cost the bench line
+        return {"wer": "not measured", "why": f"WM_CHECKPOINT / WM_LIBRISPEECH are set but the evaluation failed: {type(e).__name__}: {e}"}
+
+
 def pmc_traffic(group: int, kv_bytes: int) -> dict:
     """`roofline.traffic`: HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE pass whose summary is committed under
     profiles/ (newest profiles/*_pmc_cross_attn.json: {"fetch_bytes_per_utterance_layer": ..., "source": ...})."""
@@ -1013,6 +1063,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
+            result.update(wer_block(args))          # "not measured" unless real weights and LibriSpeech are on the box
             result["cpu_baseline"] = cpu_baseline(args, T)
         if json_fd is None:
             print(json.dumps(result), flush=True)

@@ -437,3 +437,19 @@ def test_only_the_checkers_import_the_oracle():
     assert offenders == [], offenders
     assert set(oracle_imports(os.path.join(root, "bench.py"))) <= {"cpu_baseline"}
     assert set(oracle_imports(os.path.join(root, "__graft_entry__.py"))) <= {"smoke"}
+
+
+def test_bench_wer_block_says_not_measured_without_real_weights(monkeypatch):
+    """bench.py's `wer` block: without WM_CHECKPOINT / WM_LIBRISPEECH (no box of this project has real weights) it says "not measured" and
+    why -- never a number; a checkpoint path that does not exist is treated the same."""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.delenv("WM_CHECKPOINT", raising=False)
+    monkeypatch.delenv("WM_LIBRISPEECH", raising=False)
+    b = bench.wer_block(argparse.Namespace(config="int8"))
+    assert b["wer"] == "not measured" and "WM_CHECKPOINT missing" in b["why"]
+    monkeypatch.setenv("WM_CHECKPOINT", "/nonexistent/large-v2.pt")
+    monkeypatch.setenv("WM_LIBRISPEECH", "/nonexistent/test-clean")
+    assert bench.wer_block(argparse.Namespace(config="int8"))["wer"] == "not measured"
