@@ -27,6 +27,7 @@ _GENERATION = itertools.count(1)
 # CUs the encoder keeps when it runs beside a decode loop (WhisperEncoding.prefetch): measured at B = 576 on MI355X,
 # see DESIGN.md "encoder under the decode loop"
 DEFAULT_SHARED_CU_BUDGET = 96
+PREFETCH_QUEUE_DEFAULT = "pooled"      # hardware queue of the prefetched encoder pass: "pooled" | "dedicated" (WM_PREFETCH_QUEUE; _side_stream)
 
 
 def stamp_generation(audio_features):
@@ -111,7 +112,7 @@ class WhisperEncoding:
         import threading
         assert getattr(self, "_prefetch", None) is None, "one prefetch at a time"
         if getattr(self, "_prefetch_stream", None) is None:
-            self._prefetch_stream = torch.cuda.Stream(device=mel.device)
+            self._prefetch_stream = self._side_stream(mel.device)
         side, box = self._prefetch_stream, {"loop_done": None, "released_at": None}
         side.wait_stream(torch.cuda.current_stream())          # mel may still be in flight on the caller's stream
         device = mel.device
@@ -167,6 +168,24 @@ class WhisperEncoding:
         th = threading.Thread(target=work, name="wm-encoder-prefetch", daemon=True)
         th.start()
         self._prefetch = (th, box)
+
+    @staticmethod
+    def _side_stream(device):
+        """The stream the prefetched pass is issued on.  A torch pool stream shares one of ROCm's GPU_MAX_HW_QUEUES (4) hardware queues with
+        whatever else the process created -- including the caller's current stream: the marker a decode loop's group streams wait for then sits
+        BEHIND the chunk of encoder layers just issued.  Round 6 measured it (bench.py `pipeline.other_ms`, the span between two events on the
+        caller's idle stream around prefetch(): 5.7 ms at one clip, where a chunk is 20 layers; 2.9 at two, 1.5 at eight; the first sampled
+        token of a one-clip batch came 10.7 ms after its encoder output).  WM_PREFETCH_QUEUE=dedicated gives the pass a hardware queue of its
+        own (a stream created with a full CU mask is never multiplexed: decoding.py `_group_streams`); `pooled` is the torch pool stream."""
+        import os
+        if os.environ.get("WM_PREFETCH_QUEUE", PREFETCH_QUEUE_DEFAULT) == "dedicated":
+            try:
+                n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+                with torch.cuda.device(device):
+                    return native.create_masked_stream([True] * n_cu, 7)      # (index 7: the utterance groups use 0 .. 2)
+            except native.WmError:
+                pass
+        return torch.cuda.Stream(device=device)
 
     def loop_ended(self):
         """Tell a pass in flight (prefetch) that the decode loop it runs beside has been issued to its end: an event behind the loop on the
