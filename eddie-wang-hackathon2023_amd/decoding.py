@@ -262,6 +262,7 @@ class WhisperDecoding:
         # and a group whose rows have all finished is no longer stepped.  Results are unchanged: a finished row is kept at
         # EOT whatever its logits.  Off for `ignore_eot` loops (benchmarks decode a fixed number of tokens).
         self.skip_finished_rows = True
+        self.force_not_alone = False      # bench.py's probes step the groups one after the other but must run the kernels of the parallel schedule
         self.first_token_event = None     # bench.py: an event recorded (current stream) when the first sampled token of a main_loop call exists
         self._streams = []
         self._no_dedicated_queues = False
@@ -515,7 +516,7 @@ class WhisperDecoding:
         cfg = self.decoder_config
         st = self._fast_state(n_audio, dev)
         n_micro_, bounds_ = self._groups(n_audio)   # groups of up to eight rows stepped one at a time may run as ONE launch per step
-        one_row = (n_micro_ == 1 or self.lang_id_sequential) and any(hi - lo <= 8 for lo, hi in bounds_)
+        one_row = (n_micro_ == 1 or self.lang_id_sequential) and not self.force_not_alone and any(hi - lo <= 8 for lo, hi in bounds_)
         if one_row and native.chain_status()["error_pending"]:                  # (a peek at a host word: no synchronisation)
             self._chain_gave_up("found before the language pass", foreign=True)  # somebody else's give-up: said loudly, acknowledged, not ours to repeat
         cross = self._cross_persistent(audio_features, st)
@@ -533,7 +534,7 @@ class WhisperDecoding:
             self.decoder_session.decoder_step(st['sot'][lo:hi], self.positional_embedding[0:1],
                                               [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
                                               st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g,
-                                              not_alone=n_micro > 1 and not self.lang_id_sequential)
+                                              not_alone=(n_micro > 1 and not self.lang_id_sequential) or self.force_not_alone)
             main.wait_stream(streams[g])
         language_tokens, language_probs, languages = self._language_from_logits(
             st['lang_logits'][:, 0].float(), n_audio, single)                # (brings the logits to the host: the pass has finished)
@@ -857,7 +858,7 @@ class WhisperDecoding:
         V, cap = cfg['vocab_size'], cfg['num_text_ctx']
         st = self._fast_state(n_batch, dev)
         n_micro_, bounds_ = self._groups(n_batch)       # groups of up to eight rows stepped one at a time may run as ONE launch per token step
-        one_row = (n_micro_ == 1 or self.groups_sequential) and any(hi - lo <= 8 for lo, hi in bounds_)
+        one_row = (n_micro_ == 1 or self.groups_sequential) and not self.force_not_alone and any(hi - lo <= 8 for lo, hi in bounds_)
         if one_row and not _retry and native.chain_status()["error_pending"]:   # (a peek at a host word: no synchronisation)
             self._chain_gave_up("found before the decode loop", foreign=True)   # somebody else's give-up: said loudly, acknowledged, not ours to repeat
         if self.options.temperature != 0:     # a fresh seed per call from torch's generator: torch.manual_seed makes a run repeatable
@@ -896,7 +897,7 @@ class WhisperDecoding:
         use_graph = self.use_graphs and self.decoder_session.qkv_amax is None
         # stream-parallel groups: the steps of two groups are in flight at once, so none of them may take a one-launch form (two 256-workgroup
         # launches side by side can each hold half of the chip and wait for the other half: ADVICE r5, whisper_mi355.h `not_alone`)
-        shared = n_micro > 1 and not self.groups_sequential
+        shared = (n_micro > 1 and not self.groups_sequential) or self.force_not_alone
 
         def finish_step(gr, counter):
             # end of a group's step: advance its device step counter (graph replay) and, with per-row completion,
