@@ -947,7 +947,10 @@ class WhisperDecoding:
                         # (WhisperEncoding.prefetch), which waits for events and issues launches on its own stream.  Under the default
                         # "global" mode such a call from ANY thread while this capture is open invalidates it (hipErrorStreamCaptureInvalidated
                         # -- seen once in ~ 25 bench runs: the window is three captures of a millisecond or two against one event wait per
-                        # encoder layer); the lock keeps the helper out of the driver for the length of the capture as well
+                        # encoder layer); the lock keeps the helper out of the driver for the length of the capture as well.
+                        # (torch.cuda.graph's __enter__ synchronises the DEVICE while the lock is held: during a group's first capture the
+                        # helper cannot issue its next encoder layer until the layer in flight has finished -- 45-135 ms at B = 576, once
+                        # per group and process; the group stream was synchronised just above, so nothing of this loop is waited for)
                         with native.CAPTURE_LOCK, torch.cuda.graph(graph, stream=streams[slot], capture_error_mode="thread_local"):
                             sess.decoder_step(gr['tokens'], pos, gr['cross'], gr['kv'], cap, gr['kv'], cap,
                                               gr['logits'], 1, sm, slot=slot, n_past_dev=counter, n_new=1, live_rows=gr['live'],

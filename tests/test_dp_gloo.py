@@ -237,3 +237,38 @@ def test_rank_placement_plan():
     assert dp.plan_rank_cpus(0, 1, range(8), [None], {})[0] == list(range(8))
     assert dp._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert dp.rank_seed(1234, 0) == 1234 and len({dp.rank_seed(1234, r) for r in range(8)}) == 8
+
+
+def test_gpu_numa_node_from_a_sysfs_tree(tmp_path, monkeypatch):
+    """dp.gpu_numa_node / pin_rank_to_gpu_numa against a made-up sysfs: two CPU nodes in the KFD topology (simd_count 0), then four GPUs on
+    render minors 128..131, two per NUMA node; HIP_VISIBLE_DEVICES re-maps local ranks; a GPU whose numa_node reads -1 is 'unknown'."""
+    topo = tmp_path / "class/kfd/kfd/topology/nodes"
+    for n, (simd, minor) in enumerate([(0, -1), (0, -1), (1024, 128), (1024, 129), (1024, 130), (1024, 131)]):
+        d = topo / str(n)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 48}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    for minor, node in ((128, 0), (129, 0), (130, 1), (131, -1)):
+        d = tmp_path / f"class/drm/renderD{minor}/device"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+    for node, cpus in ((0, "0-3"), (1, "4-7")):
+        d = tmp_path / f"devices/system/node/node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    sysfs = str(tmp_path)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert [dp.gpu_numa_node(i, sysfs) for i in range(5)] == [0, 0, 1, None, None]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert dp._visible_index(0) == 2 and dp._visible_index(1) == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        rep = dp.pin_rank_to_gpu_numa(1, 4, sysfs)       # rank 1's GPU sits on node 0 with rank 0: the second half of node 0's CPUs that are allowed here
+        allowed0 = [c for c in (0, 1, 2, 3) if c in before]
+        if len(allowed0) >= 4:
+            assert rep["gpu_numa_node"] == 0 and sorted(os.sched_getaffinity(0)) == [2, 3] and rep["pinned"]
+        rep3 = dp.pin_rank_to_gpu_numa(3, 4, sysfs)      # numa_node -1: unknown -> an even slice of what is allowed NOW (never raises)
+        assert rep3["gpu_numa_node"] is None and "unknown" in rep3["how"]
+    finally:
+        os.sched_setaffinity(0, before)

@@ -2,6 +2,7 @@
 found by somebody else is said loudly, the by-name decode() looks at the give-up word itself."""
 import ctypes as C
 import logging
+import time
 
 import pytest
 import torch
@@ -132,6 +133,7 @@ def test_a_give_up_found_by_somebody_else_is_said_at_error_level_and_drops_every
     st = a._fast_state(1, xa.device)
     side = torch.cuda.Stream()
     native.check(lib.wm_debug_occupy(128, 100 * 1024, 3_000_000, side.cuda_stream), "wm_debug_occupy")
+    time.sleep(0.05)                 # (the occupying workgroups are resident before the one-launch step is dispatched)
     cap, V = a.decoder_config['num_text_ctx'], a.decoder_config['vocab_size']
     tok = torch.full((1, 1), a.tokenizer.sot, dtype=torch.int32, device=xa.device)
     logits = torch.empty((1, 1, V), dtype=torch.float16, device=xa.device)
@@ -170,6 +172,7 @@ def test_decode_by_name_looks_at_the_give_up_word_itself(lib, tmp_path_factory, 
     assert torch.equal(got, ref)
     side = torch.cuda.Stream()
     native.check(lib.wm_debug_occupy(128, 100 * 1024, 3_000_000, side.cuda_stream), "wm_debug_occupy")
+    time.sleep(0.05)                 # (the occupying workgroups are resident before the one-launch step is dispatched)
     got2, _ = dec.decode(x, cross)
     torch.cuda.synchronize()
     assert torch.equal(got2, ref)
