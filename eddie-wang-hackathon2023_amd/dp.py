@@ -142,13 +142,17 @@ def gpu_numa_node(gpu_index: int, sysfs: str = "/sys") -> Optional[int]:
         return None
 
 
+MIN_CPUS_PER_RANK = 4      # a rank = the Python thread that replays the graphs, the encoder's helper thread, RCCL's proxy threads: never squeeze it below this
+
+
 def plan_rank_cpus(local_rank: int, local_world: int, allowed: Sequence[int], nodes: Sequence[Optional[int]],
                    node_cpus: Dict[int, List[int]]) -> Tuple[List[int], str]:
     """The CPUs rank `local_rank` of `local_world` ranks on this host is pinned to (pure planning: testable without sysfs).
     `allowed` = the CPUs the process may use now, `nodes[r]` = NUMA node of rank r's GPU (None: unknown), `node_cpus` = node -> CPUs.
     A rank whose GPU's node is known gets that node's allowed CPUs, cut into disjoint contiguous slices among the ranks that share the
-    node (8 GPUs on 2 sockets: 4 ranks per node, a quarter of the node's cores each; never fewer than 2 CPUs -- then the whole node).
-    Unknown node: an even contiguous slice of everything allowed (ranks stay apart, locality is left to the OS)."""
+    node (8 GPUs on 2 sockets: 4 ranks per node, a quarter of the node's cores each; never fewer than MIN_CPUS_PER_RANK CPUs -- then the whole node).
+    Unknown node: an even contiguous slice of everything allowed (ranks stay apart, locality is left to the OS) -- unless that
+    would leave a rank fewer than MIN_CPUS_PER_RANK CPUs: then nothing is pinned."""
     allowed_sorted = sorted(allowed)
     node = nodes[local_rank] if local_rank < len(nodes) else None
     if node is not None and node in node_cpus:
@@ -157,13 +161,14 @@ def plan_rank_cpus(local_rank: int, local_world: int, allowed: Sequence[int], no
         if mine and local_rank in sharers:
             k, n = sharers.index(local_rank), len(sharers)
             lo, hi = k * len(mine) // n, (k + 1) * len(mine) // n
-            if hi - lo >= 2:
+            if hi - lo >= MIN_CPUS_PER_RANK:
                 return mine[lo:hi], f"NUMA node {node} of the rank's GPU, slice {k + 1}/{n} of its {len(mine)} CPUs"
             return mine, f"NUMA node {node} of the rank's GPU (all {len(mine)} CPUs: too few to cut {n} ways)"
     lo, hi = local_rank * len(allowed_sorted) // local_world, (local_rank + 1) * len(allowed_sorted) // local_world
-    if hi - lo >= 1:
+    if hi - lo >= MIN_CPUS_PER_RANK:
         return allowed_sorted[lo:hi], f"GPU NUMA node unknown: even slice {local_rank + 1}/{local_world} of the {len(allowed_sorted)} allowed CPUs"
-    return allowed_sorted, "fewer CPUs than ranks: not pinned"
+    return allowed_sorted, (f"GPU NUMA node unknown and fewer than {MIN_CPUS_PER_RANK} CPUs per rank ({len(allowed_sorted)} for {local_world}): not pinned "
+                            "(a rank is a Python thread, the encoder's helper thread and RCCL's proxy threads)")
 
 
 def pin_rank_to_gpu_numa(local_rank: int, local_world: int, sysfs: str = "/sys") -> dict:

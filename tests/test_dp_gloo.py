@@ -233,7 +233,11 @@ def test_rank_placement_plan():
     got = [dp.plan_rank_cpus(r, 8, allowed, nodes, node_cpus)[0] for r in range(8)]
     assert all(len(g) == 24 for g in got) and len(set().union(*map(set, got))) == 192
     assert set(got[0]) <= set(node_cpus[0]) and set(got[5]) <= set(node_cpus[1])
-    assert dp.plan_rank_cpus(3, 8, range(16), [None] * 8, {})[0] == [6, 7]
+    assert dp.plan_rank_cpus(3, 8, range(32), [None] * 8, {})[0] == [12, 13, 14, 15]
+    cpus, why = dp.plan_rank_cpus(3, 8, range(16), [None] * 8, {})          # 2 CPUs per rank: below the floor -> nothing is pinned
+    assert cpus == list(range(16)) and 'not pinned' in why
+    few = {0: [0, 1, 2, 3], 1: [4, 5, 6, 7]}                                  # a node too small to cut: the whole node, never a sliver
+    assert dp.plan_rank_cpus(1, 4, range(8), [0, 0, 1, 1], few)[0] == [0, 1, 2, 3]
     assert dp.plan_rank_cpus(0, 1, range(8), [None], {})[0] == list(range(8))
     assert dp._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert dp.rank_seed(1234, 0) == 1234 and len({dp.rank_seed(1234, r) for r in range(8)}) == 8
@@ -266,8 +270,8 @@ def test_gpu_numa_node_from_a_sysfs_tree(tmp_path, monkeypatch):
     try:
         rep = dp.pin_rank_to_gpu_numa(1, 4, sysfs)       # rank 1's GPU sits on node 0 with rank 0: the second half of node 0's CPUs that are allowed here
         allowed0 = [c for c in (0, 1, 2, 3) if c in before]
-        if len(allowed0) >= 4:
-            assert rep["gpu_numa_node"] == 0 and sorted(os.sched_getaffinity(0)) == [2, 3] and rep["pinned"]
+        if len(allowed0) >= 4:      # two ranks share node 0's four CPUs: too few to cut (dp.MIN_CPUS_PER_RANK) -> the whole node
+            assert rep["gpu_numa_node"] == 0 and sorted(os.sched_getaffinity(0)) == [0, 1, 2, 3] and rep["pinned"] == (len(before) > 4)
         rep3 = dp.pin_rank_to_gpu_numa(3, 4, sysfs)      # numa_node -1: unknown -> an even slice of what is allowed NOW (never raises)
         assert rep3["gpu_numa_node"] is None and "unknown" in rep3["how"]
     finally:
