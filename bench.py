@@ -628,6 +628,8 @@ def main():
         dec.use_graphs = False
     if args.groups > 0:
         dec.micro_batches = args.groups
+    if os.environ.get("WM_GRAPH_PREFILL") == "0":       # A/B: the language pass and the prefill issued eagerly for every batch (rounds 1-5)
+        dec.graph_prefill = False
     dims = synthetic.DIMS[args.model]
     B, T = args.batch, args.decode_steps
 
@@ -779,17 +781,17 @@ def main():
             # timed region never take the one-launch step there, so they must not take it here either (16 utterances = 2 x 8 rows)
             dec.force_not_alone = dec._groups(B)[0] > 1
             native.check(lib.wm_profile_configure(1, 1, 8192))
-            dec.lang_id_sequential = True
+            dec.lang_id_sequential = dec.profile_eager_passes = True      # (eager launches: the profiling events sit on them)
             for _ in range(2):
                 dec.detect_language(last["xa"])
             kernel_ms["best"] = read_samples()
-            dec.lang_id_sequential = keep[2]
+            dec.lang_id_sequential, dec.profile_eager_passes = keep[2], False
             dec.use_graphs, dec.groups_sequential, dec.sample_len = False, True, 5
             dec.main_loop(last["xa"], ignore_eot=True)
             kernel_ms["in_loop"] = read_samples()
         finally:
             dec.use_graphs, dec.sample_len, dec.lang_id_sequential, dec.groups_sequential = keep
-            dec.force_not_alone = False
+            dec.force_not_alone = dec.profile_eager_passes = False
             native.check(lib.wm_profile_configure(0, 1, 0))
     # (a) the encoder alone on the whole chip (MFMA roofline of the other big stage)
     enc_alone_ms = None

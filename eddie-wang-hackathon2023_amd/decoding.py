@@ -262,6 +262,8 @@ class WhisperDecoding:
         # and a group whose rows have all finished is no longer stepped.  Results are unchanged: a finished row is kept at
         # EOT whatever its logits.  Off for `ignore_eot` loops (benchmarks decode a fixed number of tokens).
         self.skip_finished_rows = True
+        self.profile_eager_passes = False  # bench.py's roofline probe: keep the language pass eager (its launches carry the profiling events)
+        self.graph_prefill = True         # replay the language pass and the prefill from captured graphs too (they are host-bound eagerly)
         self.force_not_alone = False      # bench.py's probes step the groups one after the other but must run the kernels of the parallel schedule
         self.first_token_event = None     # bench.py: an event recorded (current stream) when the first sampled token of a main_loop call exists
         self._streams = []
@@ -527,14 +529,27 @@ class WhisperDecoding:
         main = torch.cuda.current_stream()
         streams = self._group_streams(n_micro, dev)
         cap = cfg['num_text_ctx']
+        use_graph = self.use_graphs and self.graph_prefill and self.decoder_session.qkv_amax is None and not self.profile_eager_passes
         for g, (lo, hi) in enumerate(bounds):
             streams[g].wait_stream(main)
             if self.lang_id_sequential and g > 0:
                 streams[g].wait_stream(streams[g - 1])     # one group at a time: kernels are timed un-shared (bench.py)
-            self.decoder_session.decoder_step(st['sot'][lo:hi], self.positional_embedding[0:1],
-                                              [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
-                                              st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g,
-                                              not_alone=(n_micro > 1 and not self.lang_id_sequential) or self.force_not_alone)
+            na = (n_micro > 1 and not self.lang_id_sequential) or self.force_not_alone
+
+            def issue_lang(g=g, lo=lo, hi=hi, na=na):
+                self.decoder_session.decoder_step(st['sot'][lo:hi], self.positional_embedding[0:1],
+                                                  [t[lo:hi] for t in cross], None, cap, [t[lo:hi] for t in st['kv']], cap,
+                                                  st['lang_logits'][lo:hi], 0, streams[g].cuda_stream, slot=g, not_alone=na)
+            # a launch per kernel (more than eight rows, or groups side by side): ~ 290 eager launches per group -> a replayed graph from the
+            # second batch on.  (Up to eight rows alone the pass is the one-launch step: four launches, nothing to replay.)
+            lkey = (n_micro, g, 'lang', na)
+            if use_graph and (na or hi - lo > 8) and lkey in st['graphs']:
+                with torch.cuda.stream(streams[g]):
+                    st['graphs'][lkey].replay()
+            else:
+                issue_lang()
+                if use_graph and (na or hi - lo > 8):
+                    self._capture(st, lkey, streams[g], issue_lang)
             main.wait_stream(streams[g])
         language_tokens, language_probs, languages = self._language_from_logits(
             st['lang_logits'][:, 0].float(), n_audio, single)                # (brings the logits to the host: the pass has finished)
@@ -763,6 +778,15 @@ class WhisperDecoding:
             st['cross_key'], st['cross_xa'] = key, xa
         return st['cross']
 
+    def _capture(self, st, key, stream, issue):
+        """Capture what `issue()` enqueues on `stream` (it has just been issued eagerly once, so every buffer and every workspace state it
+        touches exists) into st['graphs'][key].  Thread-local error mode + CAPTURE_LOCK: see the token step's capture in main_loop."""
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with native.CAPTURE_LOCK, torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            issue()
+        st['graphs'][key] = graph
+
     def _chain_gave_up(self, where: str, foreign: bool = False) -> bool:
         """Did a one-launch decode step (csrc/gemv_chain.hip: groups of up to eight rows) give up waiting for its workgroups since the last look?
         The launch needs its workgroups resident together; another tenant holding CUs or LDS while it is dispatched makes its bounded
@@ -920,10 +944,24 @@ class WhisperDecoding:
                     last_issued = slot
                 gkey = (n_micro, slot, use_live)
                 if i == 0:
-                    sess.decoder_step(gr['tokens'][:, :L0], pos[0:L0], gr['cross'], None, cap, gr['kv'], cap,
-                                      gr['logits'], 0, sm, slot=slot, live_rows=gr['live'], not_alone=shared)
-                    self._greedy(st, lo, hi, gr['logits'].data_ptr() + (L0 - 1) * V * 2, L0 * V, cur, sm)
-                    finish_step(gr, None)
+                    # the prefill (L0 tokens on an empty cache) + the first greedy step.  Round 6: replayed from a graph from the second
+                    # batch on -- the call is the same for every batch (state buffers, L0 and the start position are fixed), and issued
+                    # eagerly its ~ 390 launches per group are HOST-bound at small and middle batches (7 us each: 2.7 ms per group where the
+                    # GPU needs 1.7 at one utterance; with the language pass 9.5 ms per batch of 2 x 8)
+                    pkey = (n_micro, slot, use_live, 'prefill', L0, shared)
+
+                    def issue_prefill(gr=gr, lo=lo, hi=hi, sm=sm, slot=slot):
+                        sess.decoder_step(gr['tokens'][:, :L0], pos[0:L0], gr['cross'], None, cap, gr['kv'], cap,
+                                          gr['logits'], 0, sm, slot=slot, live_rows=gr['live'], not_alone=shared)
+                        self._greedy(st, lo, hi, gr['logits'].data_ptr() + (L0 - 1) * V * 2, L0 * V, L0, sm)
+                        finish_step(gr, None)
+                    if use_graph and self.graph_prefill and pkey in st['graphs']:
+                        with torch.cuda.stream(streams[slot]):
+                            st['graphs'][pkey].replay()
+                    else:
+                        issue_prefill()
+                        if use_graph and self.graph_prefill and L0 <= 4:        # (longer start sequences run as 4-token passes with copies between them: eager)
+                            self._capture(st, pkey, streams[slot], issue_prefill)
                 elif use_graph and gkey in st['graphs']:
                     if i == 1 or st['counters'][gkey + ('fresh',)]:
                         # the device step counter holds n_past = cur - 1; (re)seed it on the group's stream

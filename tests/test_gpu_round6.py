@@ -216,3 +216,40 @@ def test_one_row_linear_is_inside_the_reference_tolerance_of_both_of_its_contrac
     print(f"{name}: |engine - GEMV kernel| {d_gemv:.4g}, |engine - CUTLASS| {d_cut:.4g}, |engine - (x @ q) * s| {d_truth:.4g}, tolerance {atol:.4g}")
     assert d_gemv <= atol / 10 and d_cut <= atol / 10 and d_truth <= atol / 10
     assert d_truth <= d_gemv + 1e-6 or d_cut <= d_gemv + 1e-6      # the engine sits on the exact-product side of the two
+
+
+# ------------------------------------------------------------------------------------------ language pass + prefill from graphs
+@pytest.mark.parametrize("n_batch", [1, 4, 12, 16])
+def test_language_pass_and_prefill_replayed_from_graphs_are_bit_identical(lib, tmp_path_factory, chain_rearmed, n_batch):
+    """Round 6: from the second batch on, the language pass (where it is a launch per kernel: more than eight rows, or groups side by side) and
+    the prefill + first greedy step are REPLAYED from graphs captured on the first batch -- issued eagerly their ~ 290 + 390 launches per group
+    are host-bound at small batches.  Three batches of different audio through a decoder with the replay and one without: languages, language
+    probabilities, tokens, log-probabilities, no-speech probabilities and every byte of the cache are identical batch by batch; the replaying
+    decoder holds the graphs it should (and none for a pass that is the one-launch step)."""
+    eng, dims = _engine(tmp_path_factory, f"pre{n_batch}")
+    enc = WhisperEncoding(eng)
+    xas = [enc.get_audio_features(synthetic_mel(n_batch, 2 * dims.n_audio_ctx, dims.n_mels, 70 + k).cuda()) for k in range(3)]
+    res = {}
+    for replay in (False, True):
+        dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=6))
+        dec.graph_prefill = replay
+        out = []
+        for xa in xas:
+            langs, probs = dec.detect_language(xa)
+            t, lp, nsp = dec.main_loop(xa, ignore_eot=True)
+            out.append((langs, probs, t.cpu(), lp.cpu(), list(nsp), [c.clone() for c in dec._state[n_batch]['kv']]))
+        keys = [k for st in dec._state.values() for k in st['graphs'] if isinstance(k, tuple) and ('prefill' in k or 'lang' in k)]
+        res[replay] = (out, keys)
+        del dec
+    assert res[False][1] == []
+    kinds = {("prefill" if "prefill" in k else "lang") for k in res[True][1]}
+    assert "prefill" in kinds
+    assert ("lang" in kinds) == (n_batch > 8), res[True][1]        # up to eight rows alone: the language pass is the one-launch step, nothing to capture
+    for a, b in zip(res[False][0], res[True][0]):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and a[4] == b[4]
+        for x, y in zip(a[5], b[5]):
+            assert torch.equal(x, y)
+    assert not torch.equal(res[True][0][0][2], res[True][0][1][2])     # (different audio: different tokens -- the replay reads the new batch's data)
+    st_ = native.chain_status()
+    assert not st_["error_pending"] and not st_["declined"]
