@@ -27,6 +27,7 @@ _GENERATION = itertools.count(1)
 # CUs the encoder keeps when it runs beside a decode loop (WhisperEncoding.prefetch): measured at B = 576 on MI355X,
 # see DESIGN.md "encoder under the decode loop"
 DEFAULT_SHARED_CU_BUDGET = 96
+PREFETCH_MIN_BATCH = 9           # prefetch() runs beside the decode loop from this many clips on; fewer: collect() runs the pass (see prefetch)
 PREFETCH_QUEUE_DEFAULT = "pooled"      # hardware queue of the prefetched encoder pass: "pooled" | "dedicated" (WM_PREFETCH_QUEUE; _side_stream)
 
 
@@ -111,6 +112,16 @@ class WhisperEncoding:
     def prefetch(self, mel, cu_budget: int = DEFAULT_SHARED_CU_BUDGET):
         import threading
         assert getattr(self, "_prefetch", None) is None, "one prefetch at a time"
+        if int(mel.shape[0]) < getattr(self, "prefetch_min_batch", PREFETCH_MIN_BATCH):      # (an attribute: tests of the helper path set it to 1)
+            # Round 6: batches of up to eight clips are NOT run beside the decode loop -- collect() runs the pass, on the caller's stream.
+            # (1) It does not pay there: the loop of such a batch is the one-launch step, which wants every CU for itself (one stage after
+            # the other is 0.5 % faster at one clip and 4 % at eight: profiles/r6a_*, r6z_*).  (2) It is not safe there: a one-launch step
+            # dispatched within ~ 2 ms of the START of a budget-confined pass gave up its bounded waits in 5 of 25 runs of bench.py --batch 5
+            # (profiles/r6o_*, r6p_*: the step's 256 workgroups must be resident together, the pass's first kernels take CUs away under it;
+            # recovered by decoding again, but a second lost and the device off the form).  Rounds 4-5 never saw it because the eagerly
+            # issued prefill kept the first step 2.7 ms behind the start of the pass.
+            self._prefetch = (None, {"deferred": mel})
+            return
         if getattr(self, "_prefetch_stream", None) is None:
             self._prefetch_stream = self._side_stream(mel.device)
         side, box = self._prefetch_stream, {"loop_done": None, "released_at": None}
@@ -202,6 +213,17 @@ class WhisperEncoding:
         self.loop_ended()                        # (a caller that did not say so: whatever it ran beside the pass lies before this point)
         th, box = self._prefetch
         self._prefetch = None
+        if th is None:                           # a small batch (prefetch): the pass runs now, on the caller's stream, with the whole chip
+            timed = bool(getattr(self, "time_prefetch", False))
+            if timed:
+                w0 = torch.cuda.Event(enable_timing=True); w0.record()
+            xa = self.get_audio_features_async(box["deferred"])
+            if timed:
+                w1 = torch.cuda.Event(enable_timing=True); w1.record()
+                self.prefetch_events = getattr(self, "prefetch_events", [])
+                self.prefetch_events.append((w0, w1, w0, w1))
+            self.last_release_layer = 0
+            return xa
         th.join()
         if "error" in box:
             raise box["error"]

@@ -248,6 +248,7 @@ def test_prefetched_encoder_and_pipelined_evaluation(tmpdir_module):
     dims = Dims(**synthetic.DIMS["micro-fullvocab"])
     eng = build_engine(tmpdir_module, "micro-fullvocab", 3)
     enc, dec = WhisperEncoding(eng), WhisperDecoding(eng)
+    enc.prefetch_min_batch = 1          # (round 6: batches of up to eight clips are not run beside the loop by default; the helper path is what is under test)
     dec.sample_len = 6
     mels = [synthetic_mel(4, 2 * dims.n_audio_ctx, dims.n_mels, 300 + i).cuda() for i in range(3)]
     plain = [S.eval_engines(enc, dec, m) for m in mels]

@@ -508,6 +508,7 @@ def test_prefetched_encoder_pass_is_bit_identical_whenever_the_budget_is_release
     import time
     eng, dims = _small_engine(tmpdir_module, "tiny", True, False)
     enc = WhisperEncoding(eng)
+    enc.prefetch_min_batch = 1          # (round 6: batches of up to eight clips are not run beside the loop by default; the helper path is what is under test)
     mel = synthetic_mel(6, 2 * dims.n_audio_ctx, dims.n_mels, 5).cuda()
     ref = enc.get_audio_features(mel).clone()
     released = []

@@ -253,3 +253,43 @@ def test_language_pass_and_prefill_replayed_from_graphs_are_bit_identical(lib, t
     assert not torch.equal(res[True][0][0][2], res[True][0][1][2])     # (different audio: different tokens -- the replay reads the new batch's data)
     st_ = native.chain_status()
     assert not st_["error_pending"] and not st_["declined"]
+
+
+def test_small_batches_are_not_encoded_beside_the_decode_loop(lib, tmp_path_factory, chain_rearmed):
+    """Round 6: WhisperEncoding.prefetch() of a batch of up to eight clips does not start a pass beside the decode loop (whose token step is
+    the one-launch form: it wants every CU, and a step dispatched within ~ 2 ms of the start of a budget-confined pass gave up in 5 of 25
+    bench runs at five utterances); collect() runs the pass.  Same audio features bit for bit, no helper thread, and five ragged batches
+    through the pipelined schedule of bench.py's second figure leave the one-launch step armed."""
+    import threading
+    eng, dims = _engine(tmp_path_factory, "defer")
+    enc = WhisperEncoding(eng)
+    mel = synthetic_mel(5, 2 * dims.n_audio_ctx, dims.n_mels, 61).cuda()
+    ref = enc.get_audio_features(mel).clone()
+    n_threads = threading.active_count()
+    enc.prefetch(mel, 96)
+    assert threading.active_count() == n_threads and enc._prefetch[0] is None
+    enc.loop_ended()
+    got = enc.collect()
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref) and enc._prefetch is None and enc.last_release_layer == 0
+    big = synthetic_mel(9, 2 * dims.n_audio_ctx, dims.n_mels, 62).cuda()
+    enc.prefetch(big, 96)
+    assert enc._prefetch[0] is not None                      # nine clips: the helper thread, as before
+    ref9 = enc.collect().clone()
+    assert torch.equal(ref9, enc.get_audio_features(big))
+    dec = WhisperDecoding(eng, options=DecodingOptions(sample_len=12))
+    limits = [[3, 9, 5, 12, 7], [2, 2, 11, 4, 6], [12, 1, 8, 8, 3], [5, 5, 5, 5, 5], [1, 12, 2, 10, 4]]
+    xa = enc.get_audio_features(mel)
+    before = native.chain_status()["launches"]
+    for k, lim in enumerate(limits):
+        dec.detect_language(xa)
+        if k + 1 < len(limits):
+            enc.prefetch(mel, 96)
+        t, _, _ = dec.main_loop(xa, row_limit=torch.tensor(lim, dtype=torch.int32))
+        enc.loop_ended()
+        if k + 1 < len(limits):
+            xa = enc.collect()
+        for b in range(5):
+            assert int((t[b, 3:] != 50257).sum()) == lim[b], (k, b)
+    st_ = native.chain_status()
+    assert st_["launches"] > before and not st_["declined"] and not st_["error_pending"], st_
