@@ -203,7 +203,7 @@ def wer_block(args) -> dict:
     ck, ds = os.environ.get("WM_CHECKPOINT"), os.environ.get("WM_LIBRISPEECH")
     if not ck or not ds or not os.path.exists(ck) or not os.path.isdir(ds):
         return {"wer": "not measured",
-                "why": "needs real weights and audio: set WM_CHECKPOINT (large-v2.pt) and WM_LIBRISPEECH (test-clean directory); "
+                "wer_note": "needs real weights and audio: set WM_CHECKPOINT (large-v2.pt) and WM_LIBRISPEECH (test-clean directory); "
                        f"WM_CHECKPOINT {'missing' if not ck or not os.path.exists(ck) else 'present'}, "
                        f"WM_LIBRISPEECH {'missing' if not ds or not os.path.isdir(ds) else 'present'} (SURVEY 8d: otherwise report not measured)"}
     try:
@@ -239,7 +239,7 @@ def wer_block(args) -> dict:
         out["reference_published"] = "README.md:166-173: PyTorch fp16 4.19, TRT-LLM 3.91, int8 weight-only 2.76, int8 KV 4.32 (A10, other hardware)"
         return {"wer": out}
     except Exception as e:       # noqa: BLE001 -- an evaluation problem must not cost the bench line
-        return {"wer": "not measured", "why": f"WM_CHECKPOINT / WM_LIBRISPEECH are set but the evaluation failed: {type(e).__name__}: {e}"}
+        return {"wer": "not measured", "wer_note": f"WM_CHECKPOINT / WM_LIBRISPEECH are set but the evaluation failed: {type(e).__name__}: {e}"}
 
 
 def pmc_traffic(group: int, kv_bytes: int) -> dict:

@@ -449,7 +449,7 @@ def test_bench_wer_block_says_not_measured_without_real_weights(monkeypatch):
     monkeypatch.delenv("WM_CHECKPOINT", raising=False)
     monkeypatch.delenv("WM_LIBRISPEECH", raising=False)
     b = bench.wer_block(argparse.Namespace(config="int8"))
-    assert b["wer"] == "not measured" and "WM_CHECKPOINT missing" in b["why"]
+    assert b["wer"] == "not measured" and "WM_CHECKPOINT missing" in b["wer_note"]
     monkeypatch.setenv("WM_CHECKPOINT", "/nonexistent/large-v2.pt")
     monkeypatch.setenv("WM_LIBRISPEECH", "/nonexistent/test-clean")
     assert bench.wer_block(argparse.Namespace(config="int8"))["wer"] == "not measured"
