@@ -177,8 +177,12 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_kernel(AttnEncParams p) {
             const float m_new = fmaxf(m_old, r16(mx[qb]));
             // explicit roundings (no fp-contract freedom): both template instantiations must give the same bits,
             // the result of a clip must not depend on how many clips share the launch
-            mL[qb] = __fmul_rn(m_new, LOG2E);
-            alpha[qb] = __builtin_amdgcn_exp2f(__fsub_rn(__fmul_rn(m_old, LOG2E), mL[qb]));   // exp(m_old - m_new); 0 on the first tile
+            // (HIP's __fmul_rn / __fsub_rn are plain operations under -ffp-contract=fast: in another context hipcc fused this multiply and
+            // subtraction into one v_fma_f32 and 0.5 % of the outputs moved by an fp16 ulp -- profiles/r6v_*.  The empty asm pins both products.)
+            float mn = __fmul_rn(m_new, LOG2E), mo = __fmul_rn(m_old, LOG2E);
+            asm volatile("" : "+v"(mn), "+v"(mo));              // (pinning only one of them made hipcc fuse the OTHER product into the subtraction)
+            mL[qb] = mn;
+            alpha[qb] = __builtin_amdgcn_exp2f(__fsub_rn(mo, mL[qb]));   // exp(m_old - m_new); 0 on the first tile
             moved |= (m_new != m_old);
             m_run[qb] = m_new;
         }
