@@ -743,9 +743,10 @@ class WhisperDecoding:
 
     def _groups(self, n_batch):
         # three groups from 128 utterances up (two chains of short kernels hide under the third group's K/V stream;
-        # four concurrent chains are slower again: 18.1 / 28.0 ms per step at B = 384), two from 16, else one
+        # four concurrent chains are slower again: 18.1 / 28.0 ms per step at B = 384), two from 13 (round 6: 14 utterances 2.29 against
+        # 2.39 ms per token step, 12: 2.15 either way, 10: 2.05 / 2.08; rounds 1-5: from 16), else one
         if self.micro_batches is None:
-            n_micro = 3 if n_batch >= 128 else 2 if n_batch >= 16 else 1
+            n_micro = 3 if n_batch >= 128 else 2 if n_batch >= 13 else 1
         else:
             n_micro = self.micro_batches if n_batch >= 4 * self.micro_batches else 1
         return n_micro, [(g * n_batch // n_micro, (g + 1) * n_batch // n_micro) for g in range(n_micro)]

@@ -159,7 +159,7 @@ typedef struct wm_decoder_io {
      * issue one eager call first (as WhisperDecoding.main_loop does) to keep it out of the graph. */
     uint64_t workspace_id;
     /* (ABI 8) non-zero: steps of OTHER utterance groups may be in flight on this device while this one runs (stream-parallel groups, as
-     * WhisperDecoding.main_loop issues them from 16 utterances up).  The one-launch forms of a group of up to eight rows need their 256
+     * WhisperDecoding.main_loop issues them from 13 utterances up).  The one-launch forms of a group of up to eight rows need their 256
      * workgroups resident TOGETHER; two such launches dispatched side by side can each hold half of the chip and wait for the other
      * half until the bounded waits give up -- so a step that is not alone always takes a launch per kernel.  0 = the caller issues one
      * decoder step at a time on this device (the reference's own schedule, W/decoding.py:785-821).  */
