@@ -276,3 +276,32 @@ def test_gpu_numa_node_from_a_sysfs_tree(tmp_path, monkeypatch):
         assert rep3["gpu_numa_node"] is None and "unknown" in rep3["how"]
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_rank_placement_plan_properties():
+    """dp.plan_rank_cpus over random hosts (hypothesis): every rank gets CPUs it is allowed to use; a rank is never squeezed below
+    dp.MIN_CPUS_PER_RANK unless it gets a whole node / everything; ranks that are cut apart on one node never share a CPU; a GPU on a known
+    node stays on that node."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 8), st.integers(1, 4), st.integers(1, 64), st.data())
+    def check(local_world, n_nodes, cpus_per_node, data):
+        node_cpus = {n: list(range(n * cpus_per_node, (n + 1) * cpus_per_node)) for n in range(n_nodes)}
+        allowed = sorted(data.draw(st.sets(st.integers(0, n_nodes * cpus_per_node - 1), min_size=1)))
+        nodes = [data.draw(st.one_of(st.none(), st.integers(0, n_nodes - 1))) for _ in range(local_world)]
+        plans = [dp.plan_rank_cpus(r, local_world, allowed, nodes, node_cpus) for r in range(local_world)]
+        for r, (cpus, why) in enumerate(plans):
+            assert cpus and set(cpus) <= set(allowed), (r, why)
+            on_node = nodes[r] is not None and any(c in set(allowed) for c in node_cpus[nodes[r]])
+            if on_node:
+                assert set(cpus) <= set(node_cpus[nodes[r]]), (r, why)
+            if len(cpus) < dp.MIN_CPUS_PER_RANK:        # only ever the whole node's allowed CPUs or everything allowed
+                whole = [c for c in node_cpus[nodes[r]] if c in set(allowed)] if on_node else allowed
+                assert cpus == whole, (r, why)
+        for a in range(local_world):
+            for b in range(a + 1, local_world):
+                sa, sb = set(plans[a][0]), set(plans[b][0])
+                if "slice" in plans[a][1] and "slice" in plans[b][1] and (nodes[a] == nodes[b]) and sa != sb:
+                    assert sa.isdisjoint(sb), (a, b, plans[a], plans[b])
+    check()
